@@ -1,0 +1,287 @@
+"""ctypes binding of libcapsaicin_hip.so (include/capsaicin_hip.h, include/capsaicin_scene.h).
+
+No rendering happens in Python and nothing here falls back to a CPU path: every call goes through the C ABI and
+raises CapError with cap_last_error() when the library reports a failure (e.g. no HIP device).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libcapsaicin_hip.so")
+
+RENDER_AOV = 1
+RENDER_EXT_MATERIALS = 2
+RENDER_STAGE_TIMERS = 4
+
+BUF_GBUFFER_GEO, BUF_DIRECT, BUF_ALBEDO, BUF_NORMAL_DEPTH, BUF_INDIRECT, BUF_COMBINED, BUF_ACCUM_SUM, BUF_ACCUM_MEAN = range(8)
+
+
+class CapError(RuntimeError):
+    pass
+
+
+class CameraData(C.Structure):
+    """CameraData, reference src/systems/camera_system.h:16-31 (72 bytes)."""
+    _fields_ = [("position", C.c_float * 3), ("focal_length", C.c_float), ("right", C.c_float * 3), ("znear", C.c_float),
+                ("forward", C.c_float * 3), ("focus_distance", C.c_float), ("up", C.c_float * 3), ("aperture", C.c_float),
+                ("sensor_size", C.c_float * 2)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_extension", C.c_uint64), ("rays_shadow", C.c_uint64),
+                ("shaded_vertices", C.c_uint64), ("frames", C.c_uint64), ("ms_total", C.c_double), ("ms_primary", C.c_double),
+                ("ms_trace_closest", C.c_double), ("ms_trace_any", C.c_double), ("ms_shade", C.c_double),
+                ("ms_resolve", C.c_double), ("launches_trace_closest", C.c_uint64), ("launches_trace_any", C.c_uint64),
+                ("launches_shade", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [("triangle_count", C.c_uint32), ("node_count", C.c_uint32), ("max_depth", C.c_uint32),
+                ("stack_entries", C.c_uint32), ("bounds_lo", C.c_float * 3), ("bounds_hi", C.c_float * 3),
+                ("build_ms", C.c_double)]
+
+
+class GeometryView(C.Structure):
+    _fields_ = [("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)), ("texcoords", C.POINTER(C.c_float)),
+                ("indices", C.POINTER(C.c_uint32)), ("meshes", C.POINTER(C.c_uint32)), ("vertex_count", C.c_uint32),
+                ("index_count", C.c_uint32), ("mesh_count", C.c_uint32), ("texture_count", C.c_uint32),
+                ("material_count", C.c_uint32)]
+
+
+# every symbol include/capsaicin_hip.h and include/capsaicin_scene.h declare: (restype, argtypes)
+_vp, _u32, _u64, _i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+SYMBOLS = {
+    "cap_last_error": (C.c_char_p, []),
+    "cap_device_count": (_i, []),
+    "cap_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "cap_ctx_destroy": (None, [_vp]),
+    "cap_scene_upload": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32]),
+    "cap_texture_upload": (_i, [_vp, _u32, _vp, _u32, _u32]),
+    "cap_bluenoise_upload": (_i, [_vp, _vp]),
+    "cap_materials_upload": (_i, [_vp, _vp, _u32]),
+    "cap_bvh_build": (_i, [_vp]),
+    "cap_bvh_info": (_i, [_vp, C.POINTER(BvhInfo)]),
+    "cap_bvh_readback": (_i, [_vp, _vp, _vp]),
+    "cap_camera_set": (_i, [_vp, C.POINTER(CameraData)]),
+    "cap_set_resolution": (_i, [_vp, _u32, _u32]),
+    "cap_set_shard": (_i, [_vp, _u32, _u32]),
+    "cap_set_batch_paths": (_i, [_vp, _u64]),
+    "cap_render": (_i, [_vp, _u32, _u32, _u32, _u32]),
+    "cap_accum_reset": (_i, [_vp]),
+    "cap_sync": (_i, [_vp]),
+    "cap_readback": (_i, [_vp, _i, _vp]),
+    "cap_stats_get": (_i, [_vp, C.POINTER(Stats)]),
+    "cap_stats_reset": (_i, [_vp]),
+    "cap_tile_buffer_floats": (_i, [_vp, C.POINTER(C.c_size_t)]),
+    "cap_resolve_tiles": (_i, [_vp, _vp]),
+    "cap_assemble_tiles": (_i, [_vp, _vp, _u32, _vp]),
+    "cap_obj_load": (_i, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
+    "cap_geometry_free": (None, [_vp]),
+    "cap_geometry_view": (_i, [_vp, C.POINTER(GeometryView)]),
+    "cap_geometry_texture_name": (C.c_char_p, [_vp, _u32]),
+    "cap_geometry_warning": (C.c_char_p, [_vp]),
+    "cap_geometry_materials": (_i, [_vp, _vp]),
+    "cap_scene_upload_geometry": (_i, [_vp, _vp]),
+}
+
+_LIB = None
+
+
+def build_native(force=False):
+    """Compile the HIP library in-tree with hipcc for gfx950 (capsaicin_amd/csrc/Makefile)."""
+    args = ["make", "-C", os.path.join(_PKG, "csrc"), "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise CapError("native library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise CapError("%s failed (status %d): %s" % (what, rc, lib().cap_last_error().decode()))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return int(lib().cap_device_count())
+
+
+def load_bluenoise(path=None):
+    """assets/bluenoise256.rgba: raw RGBA8 texels of the reference's blue-noise texture (the sampler's RNG)."""
+    path = path or os.path.join(_ROOT, "assets", "bluenoise256.rgba")
+    return np.fromfile(path, np.uint8).reshape(256, 256, 4)
+
+
+def cornell_camera(width, height):
+    """The Cornell-box view fixed by SURVEY.md 8d (basis from input_system.cpp:134-141, aspect rule camera_system.cpp:10-17)."""
+    cam = CameraData()
+    cam.position[:] = (-0.01, 0.995, 3.4)
+    cam.forward[:] = (0.0, 0.0, -1.0)
+    cam.right[:] = (-1.0, 0.0, 0.0)
+    cam.up[:] = (0.0, 1.0, 0.0)
+    cam.focal_length = 0.035
+    cam.sensor_size[0] = 0.036
+    cam.sensor_size[1] = np.float32(0.036) * (np.float32(height) / np.float32(width))
+    return cam
+
+
+class Geometry:
+    """Host-side GeometryStorage produced by the native OBJ loader (cap_obj_load)."""
+
+    def __init__(self, obj_path, mtl_dir=None):
+        self.h = C.c_void_p()
+        _check(lib().cap_obj_load(obj_path.encode(), (mtl_dir or "").encode(), C.byref(self.h)), "cap_obj_load")
+        v = GeometryView()
+        _check(lib().cap_geometry_view(self.h, C.byref(v)), "cap_geometry_view")
+        self.view = v
+        nv, ni, nm = v.vertex_count, v.index_count, v.mesh_count
+        self.positions = np.ctypeslib.as_array(v.positions, (3 * nv,)).copy() if nv else np.zeros(0, np.float32)
+        self.normals = np.ctypeslib.as_array(v.normals, (3 * nv,)).copy() if nv else np.zeros(0, np.float32)
+        self.texcoords = np.ctypeslib.as_array(v.texcoords, (2 * nv,)).copy() if nv else np.zeros(0, np.float32)
+        self.indices = np.ctypeslib.as_array(v.indices, (ni,)).copy() if ni else np.zeros(0, np.uint32)
+        self.meshes = np.ctypeslib.as_array(v.meshes, (nm * 8,)).copy().reshape(-1, 8) if nm else np.zeros((0, 8), np.uint32)
+        self.texture_names = [lib().cap_geometry_texture_name(self.h, i).decode() for i in range(v.texture_count)]
+        self.material_count = v.material_count
+        self.warning = lib().cap_geometry_warning(self.h).decode()
+
+    def materials(self):
+        m = np.zeros((self.meshes.shape[0], 12), np.float32)
+        _check(lib().cap_geometry_materials(self.h, _p(m)), "cap_geometry_materials")
+        return m
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().cap_geometry_free(self.h)
+            self.h = None
+
+
+class Renderer:
+    """One CapContext (= one GPU).  Mirrors what RaytracingSystem::Run consumes and produces."""
+
+    def __init__(self, device=0, stream=None):
+        self.ctx = C.c_void_p()
+        _check(lib().cap_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.ctx)), "cap_ctx_create")
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            lib().cap_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    # ---- scene ----
+    def upload_scene(self, positions, normals, texcoords, indices, meshes):
+        a = [np.ascontiguousarray(positions, np.float32).ravel(), np.ascontiguousarray(normals, np.float32).ravel(),
+             np.ascontiguousarray(texcoords, np.float32).ravel(), np.ascontiguousarray(indices, np.uint32).ravel(),
+             np.ascontiguousarray(meshes, np.uint32).reshape(-1, 8)]
+        _check(lib().cap_scene_upload(self.ctx, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), a[0].size // 3, a[3].size,
+                                      a[4].shape[0]), "cap_scene_upload")
+
+    def upload_geometry(self, geo):
+        _check(lib().cap_scene_upload_geometry(self.ctx, geo.h), "cap_scene_upload_geometry")
+
+    def upload_texture(self, index, rgba8):
+        if rgba8 is None:
+            _check(lib().cap_texture_upload(self.ctx, index, None, 0, 0), "cap_texture_upload")
+            return
+        t = np.ascontiguousarray(rgba8, np.uint8)
+        _check(lib().cap_texture_upload(self.ctx, index, _p(t), t.shape[1], t.shape[0]), "cap_texture_upload")
+
+    def upload_bluenoise(self, rgba8):
+        t = np.ascontiguousarray(rgba8, np.uint8)
+        assert t.size == 256 * 256 * 4
+        _check(lib().cap_bluenoise_upload(self.ctx, _p(t)), "cap_bluenoise_upload")
+
+    def upload_materials(self, materials):
+        m = np.ascontiguousarray(materials, np.float32).reshape(-1, 12)
+        _check(lib().cap_materials_upload(self.ctx, _p(m), m.shape[0]), "cap_materials_upload")
+
+    def build_bvh(self):
+        _check(lib().cap_bvh_build(self.ctx), "cap_bvh_build")
+        return self.bvh_info()
+
+    def bvh_info(self):
+        bi = BvhInfo()
+        _check(lib().cap_bvh_info(self.ctx, C.byref(bi)), "cap_bvh_info")
+        return bi
+
+    def bvh_readback(self):
+        bi = self.bvh_info()
+        nodes = np.zeros((bi.node_count, 16), np.float32)
+        leaves = np.zeros(bi.triangle_count, np.uint32)
+        _check(lib().cap_bvh_readback(self.ctx, _p(nodes), _p(leaves)), "cap_bvh_readback")
+        return nodes, leaves
+
+    # ---- view ----
+    def set_camera(self, cam):
+        _check(lib().cap_camera_set(self.ctx, C.byref(cam)), "cap_camera_set")
+
+    def set_resolution(self, width, height):
+        _check(lib().cap_set_resolution(self.ctx, width, height), "cap_set_resolution")
+        self.width, self.height = width, height
+
+    def set_shard(self, index, count):
+        _check(lib().cap_set_shard(self.ctx, index, count), "cap_set_shard")
+
+    def set_batch_paths(self, n):
+        _check(lib().cap_set_batch_paths(self.ctx, n), "cap_set_batch_paths")
+
+    # ---- render ----
+    def render(self, frame_begin, n_frames, num_bounces, flags=0):
+        _check(lib().cap_render(self.ctx, frame_begin, n_frames, num_bounces, flags), "cap_render")
+
+    def accum_reset(self):
+        _check(lib().cap_accum_reset(self.ctx), "cap_accum_reset")
+
+    def sync(self):
+        _check(lib().cap_sync(self.ctx), "cap_sync")
+
+    def readback(self, kind):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        _check(lib().cap_readback(self.ctx, kind, _p(out)), "cap_readback")
+        return out
+
+    def stats(self):
+        s = Stats()
+        _check(lib().cap_stats_get(self.ctx, C.byref(s)), "cap_stats_get")
+        return s
+
+    def stats_reset(self):
+        _check(lib().cap_stats_reset(self.ctx), "cap_stats_reset")
+
+    # ---- multi-GPU tile exchange ----
+    def tile_buffer_floats(self):
+        n = C.c_size_t()
+        _check(lib().cap_tile_buffer_floats(self.ctx, C.byref(n)), "cap_tile_buffer_floats")
+        return int(n.value)
+
+    def resolve_tiles(self, device_ptr):
+        _check(lib().cap_resolve_tiles(self.ctx, C.c_void_p(device_ptr)), "cap_resolve_tiles")
+
+    def assemble_tiles(self, device_src, shard_count, device_image):
+        _check(lib().cap_assemble_tiles(self.ctx, C.c_void_p(device_src), shard_count, C.c_void_p(device_image)), "cap_assemble_tiles")

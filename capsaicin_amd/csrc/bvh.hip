@@ -1,0 +1,341 @@
+// bvh.hip — explicit on-device LBVH build for gfx950.  Replaces the driver calls
+// BuildRaytracingAccelerationStructure of BLASSystem/TLASSystem (reference src/systems/blas_system.cpp:65,
+// tlas_system.cpp:72).  The reference's two-level structure (one identity-transform instance per mesh,
+// InstanceID = mesh.index, tlas_system.cpp:40-58) is folded into one level; (instance, primitive) ids stay
+// available per triangle.
+//
+// Pipeline (one stream, no host round trip): triangle setup + scene bounds -> 30-bit Morton codes ->
+// LSD radix sort (4 x 8 bit, stable) -> Karras 2012 hierarchy -> bottom-up refit with arrival counters.
+// The traversal result does not depend on the tree shape (closest hit = min t, ties to the lower triangle id).
+#include "cap_kernels.h"
+
+namespace cap
+{
+namespace
+{
+constexpr uint32_t kSortTile = 2048;  // elements per workgroup per radix pass
+
+__device__ __forceinline__ uint32_t float_to_ordered(float f)
+{
+    const uint32_t u = f2u(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t o)
+{
+    return u2f((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// Triangle setup: fetch through the reference's index/vertex indirection once (scene.h:13-45), emit the
+// intersection record (v0, e1, e2), the pre-gathered shading record and the triangle box; reduce scene bounds.
+__global__ __launch_bounds__(kBlock) void k_tri_setup(BvhBuildArgs a)
+{
+    float4* tri_box = a.tri_box;
+    const uint32_t g  = blockIdx.x * kBlock + threadIdx.x;
+    float          lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (g < a.tri_count)
+    {
+        const uint2    id  = a.tri_ids[g];
+        const uint4    mo  = a.mesh_offsets[id.x];
+        const uint32_t io  = mo.y + 3u * id.y;
+        const uint32_t i0 = mo.x + a.indices[io], i1 = mo.x + a.indices[io + 1], i2 = mo.x + a.indices[io + 2];
+        const float*   P = a.positions;
+        const float*   N = a.normals;
+        const float*   T = a.texcoords;
+        const v3 p0 = mk3(P[3 * i0], P[3 * i0 + 1], P[3 * i0 + 2]), p1 = mk3(P[3 * i1], P[3 * i1 + 1], P[3 * i1 + 2]),
+                 p2 = mk3(P[3 * i2], P[3 * i2 + 1], P[3 * i2 + 2]);
+        const v3 e1 = p1 - p0, e2 = p2 - p0;
+        a.tri_raw[3 * (size_t)g + 0] = make_float4(p0.x, p0.y, p0.z, e1.x);
+        a.tri_raw[3 * (size_t)g + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        a.tri_raw[3 * (size_t)g + 2] = make_float4(e2.z, u2f(g), 0.f, 0.f);
+        float4* st = a.shade_tris + 6 * (size_t)g;
+        st[0] = make_float4(p0.x, p0.y, p0.z, T[2 * i0]);
+        st[1] = make_float4(p1.x, p1.y, p1.z, T[2 * i0 + 1]);
+        st[2] = make_float4(p2.x, p2.y, p2.z, T[2 * i1]);
+        st[3] = make_float4(N[3 * i0], N[3 * i0 + 1], N[3 * i0 + 2], T[2 * i1 + 1]);
+        st[4] = make_float4(N[3 * i1], N[3 * i1 + 1], N[3 * i1 + 2], T[2 * i2]);
+        st[5] = make_float4(N[3 * i2], N[3 * i2 + 1], N[3 * i2 + 2], T[2 * i2 + 1]);
+        lo[0] = fminf(p0.x, fminf(p1.x, p2.x)), lo[1] = fminf(p0.y, fminf(p1.y, p2.y)), lo[2] = fminf(p0.z, fminf(p1.z, p2.z));
+        hi[0] = fmaxf(p0.x, fmaxf(p1.x, p2.x)), hi[1] = fmaxf(p0.y, fmaxf(p1.y, p2.y)), hi[2] = fmaxf(p0.z, fmaxf(p1.z, p2.z));
+        tri_box[2 * (size_t)g + 0] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        tri_box[2 * (size_t)g + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+    // wave reduction, then one atomic per wave and component
+    for (int k = 0; k < 3; ++k)
+    {
+        float l = lo[k], h = hi[k];
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            l = fminf(l, __shfl_down(l, off));
+            h = fmaxf(h, __shfl_down(h, off));
+        }
+        if ((threadIdx.x & 63u) == 0)
+        {
+            if (l != INFINITY) atomicMin(&a.bounds[k], float_to_ordered(l));
+            if (h != -INFINITY) atomicMax(&a.bounds[3 + k], float_to_ordered(h));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_morton(BvhBuildArgs a)
+{
+    const float4* tri_box = a.tri_box;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= a.tri_count) return;
+    const float4 lo = tri_box[2 * (size_t)g], hi = tri_box[2 * (size_t)g + 1];
+    uint32_t     q[3];
+    const float  c[3] = {(lo.x + hi.x) * 0.5f, (lo.y + hi.y) * 0.5f, (lo.z + hi.z) * 0.5f};
+    for (int k = 0; k < 3; ++k)
+    {
+        const float blo = ordered_to_float(a.bounds[k]), bhi = ordered_to_float(a.bounds[3 + k]);
+        const float ext = bhi - blo;
+        const float n   = ext > 0.0f ? (c[k] - blo) / ext : 0.0f;
+        q[k]            = (uint32_t)fminf(fmaxf(n * 1024.0f, 0.0f), 1023.0f);
+    }
+    a.keys[0][g] = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+    a.vals[0][g] = g;
+}
+
+// ---- stable LSD radix sort, 8 bits per pass ----
+__global__ __launch_bounds__(kBlock) void k_radix_hist(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t nblocks, uint32_t* hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+    for (uint32_t k = threadIdx.x; k < kSortTile; k += kBlock)
+    {
+        const uint32_t i = base + k;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of hist (digit-major, block-minor) by one workgroup
+__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* hist, uint32_t total)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < total; base += 1024)
+    {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < total ? hist[i] : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1)
+        {
+            const uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = part[threadIdx.x];
+        if (i < total) hist[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                                                          uint32_t* vals_out, uint32_t n, uint32_t shift, uint32_t nblocks,
+                                                          const uint32_t* hist)
+{
+    __shared__ uint32_t base[256];
+    __shared__ uint32_t wcount[kBlock / 64][256];
+    const uint32_t      wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    base[threadIdx.x] = hist[threadIdx.x * nblocks + blockIdx.x];
+    for (uint32_t w = 0; w < kBlock / 64; ++w) wcount[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile = blockIdx.x * kSortTile;
+    for (uint32_t k = 0; k < kSortTile; k += kBlock)
+    {
+        const uint32_t i      = tile + k + threadIdx.x;
+        const bool     active = i < n;
+        uint32_t       key = 0, val = 0, digit = 0;
+        if (active) key = keys_in[i], val = vals_in[i], digit = (key >> shift) & 255u;
+        unsigned long long peers = __ballot(active);
+        for (uint32_t b = 0; b < 8; ++b)
+        {
+            const unsigned long long m = __ballot(active && ((digit >> b) & 1u));
+            peers &= ((digit >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (active && rank == 0) wcount[wave][digit] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (active)
+        {
+            uint32_t off = base[digit] + rank;
+            for (uint32_t w = 0; w < wave; ++w) off += wcount[w][digit];
+            keys_out[off] = key;
+            vals_out[off] = val;
+        }
+        __syncthreads();
+        uint32_t add = 0;
+        for (uint32_t w = 0; w < kBlock / 64; ++w)
+        {
+            add += wcount[w][threadIdx.x];
+            wcount[w][threadIdx.x] = 0;
+        }
+        base[threadIdx.x] += add;
+        __syncthreads();
+    }
+}
+
+// ---- Karras 2012 ----
+__device__ __forceinline__ int delta(const uint32_t* keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = ((unsigned long long)keys[i] << 32) | (uint32_t)i, b = ((unsigned long long)keys[j] << 32) | (uint32_t)j;
+    return __clzll((long long)(a ^ b));
+}
+
+__global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t* keys, uint32_t n, float4* nodes, uint32_t* parent)
+{
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    const int N = (int)n;
+    if (i >= N - 1) return;
+    const int d    = (delta(keys, N, i, i + 1) - delta(keys, N, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, N, i, i - d);
+    int       lmax = 2;
+    while (delta(keys, N, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, N, i, i + (l + t) * d) > dmin) l += t;
+    const int j     = i + l * d;
+    const int dnode = delta(keys, N, i, j);
+    int       s = 0, t = l;
+    do
+    {
+        t = (t + 1) >> 1;
+        if (delta(keys, N, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int left = (lo == gamma) ? ~gamma : gamma, right = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
+    // q3 = (child0, child1); the boxes are filled by the refit
+    nodes[4 * (size_t)i + 3] = make_float4(u2f((uint32_t)left), u2f((uint32_t)right), 0.f, 0.f);
+    const uint32_t pl = ((uint32_t)i << 1), pr = ((uint32_t)i << 1) | 1u;
+    if (left < 0) parent[(N - 1) + gamma] = pl; else parent[gamma] = pl;
+    if (right < 0) parent[(N - 1) + gamma + 1] = pr; else parent[gamma + 1] = pr;
+    if (i == 0) parent[0] = 0xffffffffu;
+}
+
+__device__ __forceinline__ float load_agent(const float* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One thread per leaf: copy the triangle into leaf order, then climb.  The first thread to reach a node parks its
+// box in the node and leaves; the second merges both boxes and continues, so every internal node is completed once.
+__global__ __launch_bounds__(kBlock) void k_refit(BvhBuildArgs a, const uint32_t* vals_sorted)
+{
+    const float4* tri_box = a.tri_box;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n = a.tri_count;
+    if (i >= n) return;
+    const uint32_t g = vals_sorted[i];
+    a.leaf_tri[i]    = g;
+    a.tris_sorted[3 * (size_t)i + 0] = a.tri_raw[3 * (size_t)g + 0];
+    a.tris_sorted[3 * (size_t)i + 1] = a.tri_raw[3 * (size_t)g + 1];
+    a.tris_sorted[3 * (size_t)i + 2] = a.tri_raw[3 * (size_t)g + 2];
+    if (n < 2) return;
+    const float4 blo = tri_box[2 * (size_t)g], bhi = tri_box[2 * (size_t)g + 1];
+    float        lo[3] = {blo.x, blo.y, blo.z}, hi[3] = {bhi.x, bhi.y, bhi.z};
+    // pad: the box must contain every point the fp32 triangle test can report as a hit
+    for (int k = 0; k < 3; ++k)
+    {
+        const float pad = 1e-5f * fmaxf(1.0f, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+        lo[k] -= pad, hi[k] += pad;
+    }
+    uint32_t cur = a.parent[(n - 1) + i];
+    while (cur != 0xffffffffu)
+    {
+        const uint32_t p = cur >> 1, slot = cur & 1u;
+        float*         q = reinterpret_cast<float*>(a.nodes + 4 * (size_t)p);
+        float*         mine  = q + (slot ? 6 : 0);
+        const float*   other = q + (slot ? 0 : 6);
+        mine[0] = lo[0], mine[1] = lo[1], mine[2] = lo[2], mine[3] = hi[0], mine[4] = hi[1], mine[5] = hi[2];
+        __threadfence();
+        const uint32_t arrived = __hip_atomic_fetch_add(&a.flags[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == 0) return;
+        __threadfence();
+        for (int k = 0; k < 3; ++k)
+        {
+            lo[k] = fminf(lo[k], load_agent(other + k));
+            hi[k] = fmaxf(hi[k], load_agent(other + 3 + k));
+        }
+        cur = a.parent[p];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_depth(const uint32_t* parent, uint32_t n, uint32_t* max_depth)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t       depth = 0;
+    if (i < n && n >= 2)
+    {
+        uint32_t cur = parent[(n - 1) + i];
+        while (cur != 0xffffffffu)
+        {
+            ++depth;
+            cur = parent[cur >> 1];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) depth = max(depth, (uint32_t)__shfl_down(depth, off));
+    if ((threadIdx.x & 63u) == 0 && depth) atomicMax(max_depth, depth);
+}
+}  // namespace
+
+size_t bvh_radix_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
+
+void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
+{
+    const uint32_t n = a.tri_count;
+    if (n == 0) return;
+    const uint32_t blocks = (n + kBlock - 1) / kBlock;
+    // bounds = (+inf, +inf, +inf, -inf, -inf, -inf) in the ordered encoding; flags, depth = 0
+    const uint32_t init[6] = {0xFF800000u, 0xFF800000u, 0xFF800000u, 0x007FFFFFu, 0x007FFFFFu, 0x007FFFFFu};
+    hipMemcpyAsync(a.bounds, init, sizeof(init), hipMemcpyHostToDevice, stream);
+    hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * n, stream);
+    hipMemsetAsync(a.max_depth, 0, sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(k_tri_setup, dim3(blocks), dim3(kBlock), 0, stream, a);
+    const uint32_t* sorted_keys = a.keys[0];
+    const uint32_t* sorted_vals = a.vals[0];
+    if (n >= 2)
+    {
+        hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(kBlock), 0, stream, a);
+        const uint32_t nb = (uint32_t)bvh_radix_blocks(n);
+        int            src = 0;
+        for (uint32_t shift = 0; shift < 32; shift += 8)
+        {
+            hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(kBlock), 0, stream, a.keys[src], n, shift, nb, a.hist);
+            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, stream, a.hist, 256u * nb);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(kBlock), 0, stream, a.keys[src], a.vals[src], a.keys[src ^ 1],
+                               a.vals[src ^ 1], n, shift, nb, a.hist);
+            src ^= 1;
+        }
+        sorted_keys = a.keys[src];
+        sorted_vals = a.vals[src];
+        hipLaunchKernelGGL(k_hierarchy, dim3(blocks), dim3(kBlock), 0, stream, sorted_keys, n, a.nodes, a.parent);
+    }
+    else
+    {
+        const uint32_t zero = 0;
+        hipMemcpyAsync(a.vals[0], &zero, sizeof(zero), hipMemcpyHostToDevice, stream);
+    }
+    hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(kBlock), 0, stream, a, sorted_vals);
+    hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(kBlock), 0, stream, a.parent, n, a.max_depth);
+}
+}  // namespace cap

@@ -1,0 +1,117 @@
+// cap_device.h — device-side data layout shared by the kernels and the host context (DESIGN.md "Data layout in HBM").
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cap_math.h"
+
+namespace cap
+{
+constexpr uint32_t kInvalidId  = ~0u;  // data_payload.h:5
+constexpr uint32_t kTileDim    = 8;    // one 8x8 screen tile == one 64-lane wavefront of primary rays
+constexpr uint32_t kTilePixels = 64;
+constexpr uint32_t kPidShift   = 26;   // path id = (frame slot << 26) | local pixel
+constexpr uint32_t kPidMask    = (1u << kPidShift) - 1u;
+constexpr uint32_t kMaxFrameSlots = 64;
+constexpr uint32_t kBlock      = 256;  // threads per workgroup (4 waves, one per SIMD)
+
+// BVH node, 64 B = 4 x float4 (both children's boxes live in the parent, one fetch tests both):
+//   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
+//   q3 = (child0, child1, -, -) as int bits; child >= 0: internal node index, child < 0: ~leaf (sorted triangle) index
+// Intersection triangle, 48 B = 3 x float4, in leaf order:
+//   t0 = (v0.x v0.y v0.z e1.x)  t1 = (e1.y e1.z e2.x e2.y)  t2 = (e2.z, asfloat(global triangle id), -, -)
+// Shading triangle, 96 B = 6 x float4, in global triangle order (mesh order, then primitive order):
+//   s0 = (p0, uv0.x) s1 = (p1, uv0.y) s2 = (p2, uv1.x) s3 = (n0, uv1.y) s4 = (n1, uv2.x) s5 = (n2, uv2.y)
+struct BvhDev
+{
+    const float4* nodes;
+    const float4* tris;
+    int32_t       root;       // 0, or ~0 for a single triangle
+    uint32_t      tri_count;  // 0 -> every ray misses
+};
+
+struct TextureDev
+{
+    const uint8_t* rgba8;
+    uint32_t       width, height;
+};
+
+// Per-frame constants evaluated on the host with cap_math.h (camera.h:41 jitter, lighting.h:20-33 light).
+struct FrameConst
+{
+    float    jitter_x, jitter_y;
+    uint32_t frame_count;
+    uint32_t pad;
+    float    light_dir[3];
+    float    pad1;
+    float    light_intensity[3];
+    float    pad2;
+};
+
+struct CameraDev
+{
+    float position[3], focal_length;
+    float right[3], sensor_x;
+    float forward[3], sensor_y;
+    float up[3], pad;
+};
+
+// Screen decomposition of one context (shard): local pixel index pl = local_tile * 64 + (y_in_tile * 8 + x_in_tile),
+// global tile = local_tile * shard_count + shard_index, tiles are numbered row-major over the 8x8 tile grid.
+struct ScreenDev
+{
+    uint32_t width, height;
+    uint32_t tiles_x, tiles_y;
+    uint32_t tile_count;        // tiles_x * tiles_y
+    uint32_t shard_index, shard_count;
+    uint32_t local_tiles;       // tiles owned by this shard
+    uint32_t pixels_padded;     // Ppad = max_tiles_per_shard * 64 (identical on every shard)
+};
+
+__device__ __forceinline__ bool local_pixel_to_xy(const ScreenDev& sc, uint32_t pl, uint32_t& x, uint32_t& y)
+{
+    const uint32_t lt = pl >> 6, w = pl & 63u;
+    const uint32_t gt = lt * sc.shard_count + sc.shard_index;
+    const uint32_t ty = gt / sc.tiles_x, tx = gt - ty * sc.tiles_x;
+    x = tx * kTileDim + (w & 7u);
+    y = ty * kTileDim + (w >> 3);
+    return gt < sc.tile_count && x < sc.width && y < sc.height;
+}
+
+// Wavefront queues, all SoA planes of float4 (16 B per lane per access, 1 KiB per wave instruction).
+struct RayQueue
+{
+    float4*   org_tmin;  // (o.xyz, tmin)
+    float4*   dir_tmax;  // (d.xyz, tmax)
+    float4*   thr_pid;   // (throughput.xyz, asfloat(path id))
+    uint32_t* count;     // device counter
+};
+struct ShadowQueue
+{
+    float4*   org_tmin;
+    float4*   dir_tmax;
+    float4*   contrib_pid;  // (radiance added when unoccluded .xyz, asfloat(path id))
+    uint32_t* count;
+};
+
+struct SceneDev
+{
+    const float4*     shade_tris;  // 6 per triangle
+    const uint2*      tri_ids;     // (instance, primitive) per global triangle  (tlas_system.cpp:40-58)
+    const uint32_t*   mesh_texture;  // texture index per mesh (MeshComponent::material_index)
+    const TextureDev* textures;
+    uint32_t          texture_count;
+    const float2*     bluenoise;   // 256*256 (R,G)/255
+    float             kd_untextured;  // pow(0.75, 2.2), scene.h:55-58
+};
+
+struct Planes
+{
+    float4* color;   // [frame slot][Ppad]  indirect radiance (rt_indirect.hlsl color)
+    float4* direct;  // [frame slot][Ppad]
+    float4* albedo;  // [frame slot][Ppad]
+    float4* aov_geo;           // [Ppad] last frame only (CAP_RENDER_AOV)
+    float4* aov_normal_depth;  // [Ppad]
+};
+}  // namespace cap

@@ -1,0 +1,86 @@
+// cap_kernels.h — host-callable launchers of the gfx950 kernels (kernels.hip, bvh.hip).
+#pragma once
+
+#include "cap_device.h"
+
+namespace cap
+{
+struct LaunchCfg
+{
+    hipStream_t stream;
+    uint32_t    grid_blocks;    // persistent grid size for queue kernels
+    uint32_t    stack_entries;  // 32 or 64 (per-lane LDS traversal stack)
+};
+
+// ---- trace ----
+// Primary visibility (rt_primary_visibility.hlsl:35-49): generates camera rays for frame slots [0, n_slots) of
+// the batch and writes hit records (u, v, asfloat(global triangle id | ~0u), t) at index slot * Ppad + pl.
+void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraDev& cam, const ScreenDev& screen,
+                          const FrameConst* frames, uint32_t n_slots, float4* hits);
+// Closest hit for the extension-ray queue (rt_indirect.hlsl:173).
+void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits);
+// Any hit for the shadow-ray queue (lighting.h:48-61); unoccluded rays add contrib to target[plane index].
+void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target,
+                      uint32_t pixels_padded);
+
+// ---- shade ----
+struct ShadeArgs
+{
+    SceneDev          scene;
+    CameraDev         cam;
+    ScreenDev         screen;
+    const FrameConst* frames;
+    const float4*     hits;
+    RayQueue          in;       // unused for the first bounce (identity queue)
+    RayQueue          out;
+    ShadowQueue       shadow;
+    Planes            planes;
+    uint32_t          n_slots;     // frame slots in this batch
+    uint32_t          bounce;
+    uint32_t          num_bounces;
+    uint32_t          max_count;   // upper bound of the input queue length
+    uint32_t          aov_slot;    // frame slot whose AOVs are kept, or ~0u
+    uint64_t*         shaded_counter;
+};
+void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args);
+
+// ---- accumulate / exchange ----
+// accum[pl] += sum over slots (in slot order) of color*albedo + direct; .w counts frames.
+void launch_resolve(const LaunchCfg& cfg, const Planes& planes, uint32_t n_slots, uint32_t pixels_padded, float4* accum);
+// plane_kind: 0 copy, 1 combined (color*albedo+direct from the three planes at slot offset), 2 mean (xyz / w)
+void launch_untile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* src, const float4* albedo, const float4* direct,
+                   int plane_kind, float4* image);
+void launch_tiles_mean(const LaunchCfg& cfg, const float4* accum, uint32_t pixels_padded, float4* dst);
+void launch_assemble(const LaunchCfg& cfg, const ScreenDev& screen, const float4* gathered, uint32_t shard_count, float4* image);
+void launch_geo_aov(const LaunchCfg& cfg, const SceneDev& scene, const float4* hits_slot, uint32_t pixels_padded, float4* aov_geo);
+
+// ---- LBVH build (bvh.hip) ----
+struct BvhBuildArgs
+{
+    // inputs: GeometryStorage layout on the device
+    const float*    positions;
+    const float*    normals;
+    const float*    texcoords;
+    const uint32_t* indices;
+    const uint2*    tri_ids;        // (instance, primitive) per global triangle
+    const uint4*    mesh_offsets;   // per mesh: (first_vertex_offset, first_index_offset, -, -)
+    uint32_t        tri_count;
+    // outputs
+    float4*         shade_tris;     // 6 per triangle, global order
+    float4*         tris_sorted;    // 3 per triangle, leaf order
+    float4*         nodes;          // 4 per internal node
+    uint32_t*       leaf_tri;       // global triangle id per leaf
+    // scratch
+    float4*         tri_raw;        // 3 per triangle, global order
+    float4*         tri_box;        // 2 per triangle (lo, hi), global order
+    uint32_t*       keys[2];
+    uint32_t*       vals[2];
+    uint32_t*       hist;           // radix histogram scratch: 256 * blocks
+    uint32_t*       parent;         // [2*tri_count] parents of internal nodes then leaves, (parent << 1) | slot
+    uint32_t*       flags;          // [tri_count] refit arrival counters
+    uint32_t*       bounds;         // 6 orderable-uint encoded floats
+    uint32_t*       max_depth;      // 1
+};
+size_t bvh_radix_blocks(uint32_t n);
+void   launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a);
+}  // namespace cap

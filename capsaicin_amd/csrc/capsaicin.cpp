@@ -1,0 +1,303 @@
+// capsaicin.cpp — the reference's public API (src/core/src/capsaicin.cpp:20-103) on top of the C ABI.
+//
+// The reference wires six systems into a yecs World and orders them with Precede edges (capsaicin.cpp:38-45, 58-62):
+//   AssetLoad -> BLAS -> TLAS -> Camera -> Raytracing -> Composite -> GUI -> Render.
+// yecs is an empty submodule directory in the reference tree; this file keeps the same system boundaries and the same
+// total order in a small fixed-order world (the reference serialises the systems anyway, capsaicin.cpp:38-40 TODO).
+#include "capsaicin.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <vector>
+
+#include "../../include/capsaicin_hip.h"
+#include "../../include/capsaicin_scene.h"
+
+namespace capsaicin
+{
+namespace
+{
+void info(const std::string& s) { std::fprintf(stderr, "[info] %s\n", s.c_str()); }
+void warn(const std::string& s) { std::fprintf(stderr, "[warning] %s\n", s.c_str()); }
+[[noreturn]] void error_throw(const std::string& s)
+{
+    std::fprintf(stderr, "[error] %s\n", s.c_str());
+    throw std::runtime_error(s);  // dx12/common.h:17-32: log, then throw
+}
+void check(int rc, const char* what)
+{
+    if (rc != CAP_OK) error_throw(std::string(what) + ": " + cap_last_error());
+}
+
+struct AssetComponent
+{
+    std::string file_name;
+    bool        loaded = false;
+};
+
+std::string dir_of(const std::string& p)
+{
+    size_t s = p.find_last_of('/');
+    return s == std::string::npos ? std::string("") : p.substr(0, s + 1);
+}
+
+bool read_file(const std::string& path, std::vector<uint8_t>* out)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    out->assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return true;
+}
+
+// Binary PPM (P6, maxval 255) -> RGBA8; the only image container decoded natively (PNG/JPEG decoding was stb_image in the
+// reference, a vendored third-party header that is not re-implemented).
+bool decode_ppm(const std::vector<uint8_t>& d, std::vector<uint8_t>* rgba, uint32_t* w, uint32_t* h)
+{
+    size_t pos = 0;
+    auto   token = [&]() {
+        std::string t;
+        while (pos < d.size())
+        {
+            if (d[pos] == '#')
+                while (pos < d.size() && d[pos] != '\n') ++pos;
+            else if (std::isspace(d[pos]))
+                ++pos;
+            else
+                break;
+        }
+        while (pos < d.size() && !std::isspace(d[pos])) t += (char)d[pos++];
+        return t;
+    };
+    if (token() != "P6") return false;
+    long W = std::atol(token().c_str()), H = std::atol(token().c_str()), M = std::atol(token().c_str());
+    if (W <= 0 || H <= 0 || M != 255) return false;
+    ++pos;  // single whitespace after maxval
+    if (d.size() < pos + (size_t)W * H * 3) return false;
+    rgba->resize((size_t)W * H * 4);
+    for (size_t i = 0; i < (size_t)W * H; ++i)
+    {
+        (*rgba)[4 * i + 0] = d[pos + 3 * i + 0];
+        (*rgba)[4 * i + 1] = d[pos + 3 * i + 1];
+        (*rgba)[4 * i + 2] = d[pos + 3 * i + 2];
+        (*rgba)[4 * i + 3] = 255;
+    }
+    *w = (uint32_t)W, *h = (uint32_t)H;
+    return true;
+}
+
+struct World
+{
+    // components
+    std::vector<AssetComponent> assets;
+    CameraData                  camera;
+    Settings                    settings;
+    // RenderSystem state
+    RenderSessionParams session;
+    bool                session_active = false;
+    uint32_t            frame_count    = 0;
+    // GPU side
+    CapContext* ctx        = nullptr;
+    bool        tlas_built = false;  // tlas_system.cpp:111-121 `built` flag: the structure is built once
+    std::string assets_dir;
+};
+
+std::unique_ptr<World> g_world;
+
+World& world()
+{
+    if (!g_world) error_throw("capsaicin: Init() has not been called");
+    return *g_world;
+}
+
+std::string find_assets_dir(const std::string& obj_file)
+{
+    if (const char* e = std::getenv("CAPSAICIN_ASSETS")) return std::string(e) + (e[std::strlen(e) - 1] == '/' ? "" : "/");
+    return dir_of(obj_file);  // the reference hard-codes "../../../assets/" (asset_load_system.cpp:55)
+}
+
+// AssetLoadSystem::Run (asset_load_system.cpp:272-328) + TextureSystem (texture_system.cpp:38-118)
+void run_asset_load(World& w)
+{
+    for (auto& a : w.assets)
+    {
+        if (a.loaded) continue;
+        if (w.tlas_built) error_throw("AssetLoadSystem: the acceleration structure is built once; load scenes before the first Render()");
+        info("AssetLoadSystem: loading " + a.file_name);
+        w.assets_dir     = find_assets_dir(a.file_name);
+        CapGeometry* geo = nullptr;
+        check(cap_obj_load(a.file_name.c_str(), w.assets_dir.c_str(), &geo), "AssetLoadSystem");
+        if (*cap_geometry_warning(geo)) warn(cap_geometry_warning(geo));
+        CapGeometryView v;
+        check(cap_geometry_view(geo, &v), "AssetLoadSystem");
+        check(cap_scene_upload_geometry(w.ctx, geo), "AssetLoadSystem");
+        for (uint32_t t = 0; t < v.texture_count; ++t)
+        {
+            const std::string    full = w.assets_dir + "textures/" + cap_geometry_texture_name(geo, t);
+            std::vector<uint8_t> file, rgba;
+            uint32_t             tw = 0, th = 0;
+            if (read_file(full, &file) && decode_ppm(file, &rgba, &tw, &th))
+                check(cap_texture_upload(w.ctx, t, rgba.data(), tw, th), "TextureSystem");
+            else
+            {
+                warn("TextureSystem: texture " + full + " missing");  // texture_system.cpp:50-56
+                check(cap_texture_upload(w.ctx, t, nullptr, 0, 0), "TextureSystem");
+            }
+        }
+        cap_geometry_free(geo);
+        a.loaded = true;
+    }
+}
+
+// BLASSystem::Run + TLASSystem::Run (blas_system.cpp:69-113, tlas_system.cpp:81-122)
+void run_acceleration_structure(World& w)
+{
+    if (w.tlas_built) return;
+    bool any = false;
+    for (auto& a : w.assets) any |= a.loaded;
+    if (!any) return;
+    check(cap_bvh_build(w.ctx), "TLASSystem");
+    CapBvhInfo bi;
+    check(cap_bvh_info(w.ctx, &bi), "TLASSystem");
+    info("TLASSystem: LBVH over " + std::to_string(bi.triangle_count) + " triangles, depth " + std::to_string(bi.max_depth) + ", " +
+         std::to_string(bi.build_ms) + " ms");
+    w.tlas_built = true;
+}
+
+// CameraSystem::Run (camera_system.cpp:46-131) incl. AdjustCameraAspectBasedOnWindow (:10-17)
+void run_camera(World& w)
+{
+    const float aspect       = float(w.session.height) / w.session.width;
+    w.camera.sensor_size[1]  = w.camera.sensor_size[0] * aspect;
+    CapCameraData cd;
+    static_assert(sizeof(cd) == sizeof(CameraData), "layout");
+    std::memcpy(&cd, &w.camera, sizeof(cd));
+    check(cap_camera_set(w.ctx, &cd), "CameraSystem");
+}
+
+// RaytracingSystem::Run, ray passes (raytracing_system.cpp:266-292)
+void run_raytracing(World& w)
+{
+    if (!w.tlas_built) return;  // nothing to trace yet, as in the reference's first frames
+    if (!w.settings.accumulate) check(cap_accum_reset(w.ctx), "RaytracingSystem");
+    check(cap_render(w.ctx, w.frame_count, w.settings.frames_per_render, (uint32_t)std::max(0, w.settings.num_diffuse_bounces),
+                     CAP_RENDER_STAGE_TIMERS),
+          "RaytracingSystem");
+}
+}  // namespace
+
+void Init()
+{
+    info("capsaicin::Init()");
+    g_world.reset(new World);
+}
+
+void InitRenderSession(void* params)
+{
+    World& w = world();
+    if (!params) error_throw("InitRenderSession: params is null");
+    w.session = *static_cast<RenderSessionParams*>(params);
+    info("capsaicin::InitRenderSession()");
+    check(cap_ctx_create(w.session.device, nullptr, &w.ctx), "InitRenderSession");
+    check(cap_set_resolution(w.ctx, w.session.width, w.session.height), "InitRenderSession");
+    check(cap_set_shard(w.ctx, w.session.shard_index, w.session.shard_count), "InitRenderSession");
+    // blue-noise texture = the sampler's random numbers (raytracing_system.cpp:642-646)
+    std::vector<uint8_t> bn;
+    std::string          dir = std::getenv("CAPSAICIN_ASSETS") ? std::string(std::getenv("CAPSAICIN_ASSETS")) + "/" : std::string("assets/");
+    if (!read_file(dir + "bluenoise256.rgba", &bn) || bn.size() != 256 * 256 * 4)
+        error_throw("RaytracingSystem: cannot read " + dir + "bluenoise256.rgba (set CAPSAICIN_ASSETS)");
+    check(cap_bluenoise_upload(w.ctx, bn.data()), "RaytracingSystem");
+    w.session_active = true;
+}
+
+void LoadSceneFromOBJ(const std::string& file_name)
+{
+    info("capsaicin::LoadSceneFromOBJ(" + file_name + ")");
+    world().assets.push_back(AssetComponent{file_name, false});  // lazily loaded by the next Render(), capsaicin.cpp:65-71
+}
+
+void ProcessInput(void*) {}
+void Update(float) {}
+void SetOption() {}
+
+void Render()
+{
+    World& w = world();
+    if (!w.session_active) error_throw("Render: no render session");
+    run_asset_load(w);
+    run_acceleration_structure(w);
+    run_camera(w);
+    run_raytracing(w);
+    // RenderSystem::Run: submit + ++frame_count_ (render_system.cpp:53-84)
+    check(cap_sync(w.ctx), "RenderSystem");
+    w.frame_count += w.settings.frames_per_render;
+}
+
+void ShutdownRenderSession()
+{
+    World& w = world();
+    info("capsaicin::ShutdownRenderSession()");
+    if (w.ctx) cap_ctx_destroy(w.ctx);
+    w.ctx            = nullptr;
+    w.session_active = false;
+}
+
+void Shutdown()
+{
+    info("capsaicin::Shutdown()");
+    if (g_world && g_world->ctx) cap_ctx_destroy(g_world->ctx);
+    g_world.reset();
+}
+
+Settings&   GetSettings() { return world().settings; }
+CameraData& GetCamera() { return world().camera; }
+uint32_t    FrameCount() { return world().frame_count; }
+
+void ReadFrame(float* dst)
+{
+    World& w = world();
+    check(cap_readback(w.ctx, CAP_BUF_ACCUM_MEAN, dst), "ReadFrame");
+}
+
+void SaveFramePPM(const std::string& path)
+{
+    World&             w = world();
+    std::vector<float> img((size_t)w.session.width * w.session.height * 4);
+    ReadFrame(img.data());
+    std::ofstream f(path, std::ios::binary);
+    if (!f) error_throw("SaveFramePPM: cannot open " + path);
+    f << "P6\n" << w.session.width << " " << w.session.height << "\n255\n";
+    std::vector<uint8_t> row(3 * (size_t)w.session.width);
+    for (uint32_t y = 0; y < w.session.height; ++y)
+    {
+        const float* src = img.data() + 4 * (size_t)(w.session.height - 1 - y) * w.session.width;  // simple.hlsl:44 flips v
+        for (uint32_t x = 0; x < w.session.width; ++x)
+            for (int c = 0; c < 3; ++c)
+            {
+                float v = std::pow(std::fmax(src[4 * x + c], 0.f), 1.f / 2.2f);  // simple.hlsl:45
+                row[3 * x + c] = (uint8_t)std::fmin(255.f, std::floor(v * 255.f + 0.5f));
+            }
+        f.write((const char*)row.data(), row.size());
+    }
+}
+
+std::string TimingsReport()
+{
+    CapStats s;
+    check(cap_stats_get(world().ctx, &s), "TimingsReport");
+    std::ostringstream o;
+    o << "RaytracePrimaryVisibility: " << s.ms_primary << " ms\n"
+      << "RT Direct lighting + RT Indirect diffuse (shade): " << s.ms_shade << " ms\n"
+      << "RT Indirect diffuse (closest-hit traversal): " << s.ms_trace_closest << " ms\n"
+      << "RT shadow rays (any-hit traversal): " << s.ms_trace_any << " ms\n"
+      << "Accumulate: " << s.ms_resolve << " ms\n"
+      << "total: " << s.ms_total << " ms over " << s.frames << " frames, rays primary/extension/shadow = " << s.rays_primary << "/"
+      << s.rays_extension << "/" << s.rays_shadow << "\n";
+    return o.str();
+}
+}  // namespace capsaicin

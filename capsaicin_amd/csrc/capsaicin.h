@@ -1,0 +1,64 @@
+// capsaicin.h — host API with the reference's names and argument meaning (reference src/core/include/capsaicin.h:25-36),
+// for a display-less MI355X node.  The nine entry points keep their semantics; what was a Win32 HWND in
+// RenderSessionParams is a plain headless description, and the frame is fetched with the accessors below instead
+// of a swap chain (CompositeSystem blit, simple.hlsl:40-46).
+#pragma once
+
+#include <cstdint>
+#include <string>
+
+struct RenderSessionParams
+{
+    uint32_t width       = 1920;  // viewer window size, main.cpp:53-54
+    uint32_t height      = 1080;
+    int      device      = 0;     // HIP device
+    uint32_t shard_index = 0;     // screen-tile shard rendered by this process
+    uint32_t shard_count = 1;
+};
+
+namespace capsaicin
+{
+// Settings carried from SettingsComponent (gui_system.h:20-40); only what the ray passes read.
+struct Settings
+{
+    int      num_diffuse_bounces = 1;   // gui_system.h:39
+    uint32_t frames_per_render   = 1;   // reference: exactly one frame per Render()
+    bool     accumulate          = true;  // plain running mean instead of the temporal EMA
+};
+
+// CameraData (camera_system.h:16-31), defaults from CameraSystem's ctor (camera_system.cpp:25-33).
+struct CameraData
+{
+    float position[3]    = {0.f, 15.f, 0.f};
+    float focal_length   = 0.016f;
+    float right[3]       = {1.f, 0.f, 0.f};
+    float znear          = 0.f;
+    float forward[3]     = {0.f, 0.f, 1.f};
+    float focus_distance = 0.f;
+    float up[3]          = {0.f, 1.f, 0.f};
+    float aperture       = 0.f;
+    float sensor_size[2] = {0.036f, 0.024f};
+};
+static_assert(sizeof(CameraData) == 72, "CameraData must stay the reference's 72-byte POD");
+
+void Init();
+void InitRenderSession(void* params);  // RenderSessionParams*
+void LoadSceneFromOBJ(const std::string& file_name);
+void ProcessInput(void* input);  // interactive input does not exist on a headless node: accepted and ignored
+void Update(float time_ms);
+void Render();
+void SetOption();  // empty stub in the reference as well (capsaicin.cpp:89-92)
+void ShutdownRenderSession();
+void Shutdown();
+
+// ---- headless additions ----
+Settings&   GetSettings();
+CameraData& GetCamera();          // edit, then Render(); the sensor height follows the window aspect (camera_system.cpp:10-17)
+uint32_t    FrameCount();         // RenderSystem::frame_count()
+// Linear radiance (running mean) of the current image, width*height*4 floats, row 0 = pixel row 0.
+void ReadFrame(float* dst_rgba);
+// Gamma 1/2.2 8-bit PPM with the vertical flip of the reference blit (simple.hlsl:40-46).
+void SaveFramePPM(const std::string& path);
+// Per-pass GPU milliseconds under the reference's timestamp names (gui_system.cpp:94-104).
+std::string TimingsReport();
+}  // namespace capsaicin

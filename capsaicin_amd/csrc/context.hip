@@ -1,0 +1,839 @@
+// context.hip — implementation of the C ABI in include/capsaicin_hip.h: device memory ownership, uploads, the
+// per-batch wavefront loop (the MI355X counterpart of RaytracingSystem::Run, reference
+// src/systems/raytracing_system.cpp:230-318, ray passes only), readback, statistics.
+//
+// The product path is HIP only: every entry point that needs the GPU fails with CAP_ERR_HIP when no device or
+// kernel is available; there is no CPU fallback.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/capsaicin_hip.h"
+#include "cap_kernels.h"
+
+using namespace cap;
+
+namespace
+{
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+    do                                                                                                        \
+    {                                                                                                         \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(CAP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                                \
+    } while (0)
+
+template <typename T>
+struct DevBuf
+{
+    T*     p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr, n = 0;
+    }
+    hipError_t ensure(size_t count)
+    {
+        if (count <= n && p) return hipSuccess;
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+};
+
+enum StageId
+{
+    ST_PRIMARY,
+    ST_CLOSEST,
+    ST_ANY,
+    ST_SHADE,
+    ST_RESOLVE,
+    ST_COUNT
+};
+
+struct TimedSpan
+{
+    hipEvent_t a, b;
+    int        stage;
+};
+}  // namespace
+
+struct CapContext
+{
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    bool        own_stream = false;
+    int         cu_count = 256;
+
+    // scene (GeometryStorage layout, asset_load_system.h:16-27)
+    DevBuf<float>    positions, normals, texcoords;
+    DevBuf<uint32_t> indices;
+    DevBuf<uint2>    tri_ids;
+    DevBuf<uint4>    mesh_offsets;
+    DevBuf<uint32_t> mesh_texture;
+    uint32_t         vertex_count = 0, index_count = 0, mesh_count = 0, tri_count = 0;
+    bool             scene_ready = false;
+
+    std::vector<DevBuf<uint8_t>> texture_data;
+    std::vector<TextureDev>      texture_host;
+    DevBuf<TextureDev>           textures;
+    bool                         textures_dirty = true;
+    DevBuf<float2>               bluenoise;
+    bool                         bluenoise_ready = false;
+    std::vector<CapMaterial>     materials_host;
+    DevBuf<CapMaterial>          materials;
+
+    // BVH
+    DevBuf<float4>   shade_tris, tris_sorted, nodes, tri_raw, tri_box;
+    DevBuf<uint32_t> leaf_tri, keys0, keys1, vals0, vals1, hist, parent, flags, bvh_misc;  // bvh_misc: 6 bounds + depth
+    CapBvhInfo       bvh_info{};
+    bool             bvh_ready = false;
+
+    // camera / screen
+    CapCameraData camera{};
+    bool          camera_ready = false;
+    ScreenDev     screen{};
+    uint64_t      max_batch_paths = 0;
+
+    // wavefront state
+    DevBuf<float4>     hits, q_org[2], q_dir[2], q_thr[2], s_org, s_dir, s_con, pl_color, pl_direct, pl_albedo, aov_geo, aov_nd,
+        accum, image_tmp;
+    DevBuf<uint32_t>   counters;  // per batch: ext[0..D], shadow[0..D]
+    DevBuf<uint64_t>   shaded_counter;
+    DevBuf<FrameConst> frames;
+    uint32_t           slots_alloc = 0, bounces_alloc = 0;
+    uint32_t           last_slots = 0;     // frame slots of the last batch rendered (AOV readback)
+    bool               aov_valid = false;
+    uint64_t           frames_accumulated = 0;
+
+    // statistics
+    CapStats               stats{};
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    struct PendingCounters
+    {
+        std::vector<uint32_t> host;  // filled by an async copy
+        uint32_t              bounces;
+    };
+    std::vector<uint32_t*> pinned_pool;
+    std::vector<std::pair<uint32_t*, uint32_t>> pending;  // (pinned counters, bounces) per batch, read at sync
+    uint64_t*              pinned_shaded = nullptr;
+    hipEvent_t             ev_begin = nullptr, ev_end = nullptr;
+};
+
+namespace
+{
+int sync_and_collect(CapContext* c)
+{
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& sp : c->spans)
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess)
+        {
+            switch (sp.stage)
+            {
+            case ST_PRIMARY: c->stats.ms_primary += ms; break;
+            case ST_CLOSEST: c->stats.ms_trace_closest += ms; break;
+            case ST_ANY: c->stats.ms_trace_any += ms; break;
+            case ST_SHADE: c->stats.ms_shade += ms; break;
+            case ST_RESOLVE: c->stats.ms_resolve += ms; break;
+            case ST_COUNT: c->stats.ms_total += ms; break;
+            }
+        }
+        c->event_pool.push_back(sp.a);
+        c->event_pool.push_back(sp.b);
+    }
+    c->spans.clear();
+    for (auto& pc : c->pending)
+    {
+        const uint32_t D = pc.second;
+        for (uint32_t b = 0; b <= D; ++b)
+        {
+            c->stats.rays_extension += pc.first[b];
+            c->stats.rays_shadow += pc.first[(D + 1) + b];
+        }
+        c->pinned_pool.push_back(pc.first);
+    }
+    c->pending.clear();
+    if (c->pinned_shaded && c->shaded_counter.p)
+    {
+        HIP_TRY(hipMemcpy(c->pinned_shaded, c->shaded_counter.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+        c->stats.shaded_vertices = *c->pinned_shaded;
+    }
+    return CAP_OK;
+}
+
+hipEvent_t get_event(CapContext* c)
+{
+    if (!c->event_pool.empty())
+    {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct StageTimer
+{
+    CapContext* c;
+    TimedSpan   sp;
+    bool        on;
+    StageTimer(CapContext* ctx, int stage, bool enabled = true) : c(ctx), on(enabled)
+    {
+        if (!on) return;
+        sp.stage = stage;
+        sp.a     = get_event(c);
+        sp.b     = get_event(c);
+        (void)hipEventRecord(sp.a, c->stream);
+    }
+    ~StageTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(sp.b, c->stream);
+        c->spans.push_back(sp);
+    }
+};
+
+void update_screen(CapContext* c, uint32_t w, uint32_t h, uint32_t shard_index, uint32_t shard_count)
+{
+    ScreenDev& s  = c->screen;
+    s.width       = w;
+    s.height      = h;
+    s.tiles_x     = (w + kTileDim - 1) / kTileDim;
+    s.tiles_y     = (h + kTileDim - 1) / kTileDim;
+    s.tile_count  = s.tiles_x * s.tiles_y;
+    s.shard_index = shard_index;
+    s.shard_count = shard_count ? shard_count : 1;
+    const uint32_t max_local = (s.tile_count + s.shard_count - 1) / s.shard_count;
+    s.local_tiles   = s.tile_count > s.shard_index ? (s.tile_count - s.shard_index + s.shard_count - 1) / s.shard_count : 0;
+    s.pixels_padded = max_local * kTilePixels;
+    c->frames_accumulated = 0;
+    c->aov_valid = false;
+}
+
+CameraDev camera_dev(const CapCameraData& cd)
+{
+    CameraDev d{};
+    for (int k = 0; k < 3; ++k) d.position[k] = cd.position[k], d.right[k] = cd.right[k], d.forward[k] = cd.forward[k], d.up[k] = cd.up[k];
+    d.focal_length = cd.focal_length;
+    d.sensor_x     = cd.sensor_size[0];
+    d.sensor_y     = cd.sensor_size[1];
+    return d;
+}
+
+// lighting.h:20-33 + camera.h:41, evaluated once per frame on the host with the shared arithmetic contract
+FrameConst frame_const(uint32_t frame_count)
+{
+    FrameConst f{};
+    halton23(frame_count, f.jitter_x, f.jitter_y);
+    f.frame_count = frame_count;
+    const float t = 2.0f * 3.14f * (float)(frame_count % 4096) / 4096.0f;
+    float       st, ct;
+    sincos_c(t, st, ct);
+    const v3 dir = normalize3(mk3(40.0f * st, 100.0f, 40.0f * ct));
+    f.light_dir[0] = dir.x, f.light_dir[1] = dir.y, f.light_dir[2] = dir.z;
+    f.light_intensity[0] = 1.0f * (2.0f * 14.0f + 0.0f);
+    f.light_intensity[1] = 1.0f * (2.0f * 12.0f + 0.0f);
+    f.light_intensity[2] = 1.0f * (2.0f * 10.0f + (2.0f + 2.0f * ct));
+    return f;
+}
+
+BvhDev bvh_dev(const CapContext* c)
+{
+    BvhDev b{};
+    b.nodes     = c->nodes.p;
+    b.tris      = c->tris_sorted.p;
+    b.tri_count = c->tri_count;
+    b.root      = c->tri_count >= 2 ? 0 : ~0;
+    return b;
+}
+
+SceneDev scene_dev(const CapContext* c)
+{
+    SceneDev s{};
+    s.shade_tris    = c->shade_tris.p;
+    s.tri_ids       = c->tri_ids.p;
+    s.mesh_texture  = c->mesh_texture.p;
+    s.textures      = c->textures.p;
+    s.texture_count = (uint32_t)c->texture_host.size();
+    s.bluenoise     = c->bluenoise.p;
+    s.kd_untextured = pow22_c(0.75f);
+    return s;
+}
+
+int ensure_wavefront(CapContext* c, uint32_t slots, uint32_t bounces)
+{
+    const size_t np = (size_t)slots * c->screen.pixels_padded;
+    HIP_TRY(c->hits.ensure(np));
+    for (int k = 0; k < 2; ++k)
+    {
+        HIP_TRY(c->q_org[k].ensure(np));
+        HIP_TRY(c->q_dir[k].ensure(np));
+        HIP_TRY(c->q_thr[k].ensure(np));
+    }
+    HIP_TRY(c->s_org.ensure(np));
+    HIP_TRY(c->s_dir.ensure(np));
+    HIP_TRY(c->s_con.ensure(np));
+    HIP_TRY(c->pl_color.ensure(np));
+    HIP_TRY(c->pl_direct.ensure(np));
+    HIP_TRY(c->pl_albedo.ensure(np));
+    HIP_TRY(c->aov_geo.ensure(c->screen.pixels_padded));
+    HIP_TRY(c->aov_nd.ensure(c->screen.pixels_padded));
+    HIP_TRY(c->counters.ensure(2 * (size_t)(bounces + 1)));
+    if (!c->shaded_counter.p)
+    {
+        HIP_TRY(c->shaded_counter.ensure(1));
+        HIP_TRY(hipMemsetAsync(c->shaded_counter.p, 0, sizeof(uint64_t), c->stream));
+    }
+    if (!c->accum.p || c->accum.n < c->screen.pixels_padded)
+    {
+        HIP_TRY(c->accum.ensure(c->screen.pixels_padded));
+        HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(float4) * c->screen.pixels_padded, c->stream));
+        c->frames_accumulated = 0;
+    }
+    return CAP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* cap_last_error(void) { return g_error.c_str(); }
+// used by the host-side half of the library (obj_loader.cpp) so both report through cap_last_error()
+void cap_set_error_(const char* msg) { g_error = msg ? msg : ""; }
+
+int cap_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cap_ctx_create(int device_id, void* hip_stream, CapContext** out_ctx)
+{
+    if (!out_ctx) return fail(CAP_ERR_INVALID_ARG, "cap_ctx_create: out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n    = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(CAP_ERR_HIP, "cap_ctx_create: device %d not present (%d HIP devices)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    CapContext* c = new CapContext;
+    c->device     = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    if (hip_stream)
+        c->stream = (hipStream_t)hip_stream;
+    else
+    {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+        {
+            delete c;
+            return fail(CAP_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        c->own_stream = true;
+    }
+    (void)hipHostMalloc((void**)&c->pinned_shaded, sizeof(uint64_t), hipHostMallocDefault);
+    update_screen(c, 0, 0, 0, 1);
+    *out_ctx = c;
+    return CAP_OK;
+}
+
+void cap_ctx_destroy(CapContext* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& sp : c->spans)
+    {
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto& pc : c->pending) (void)hipHostFree(pc.first);
+    for (auto p : c->pinned_pool) (void)hipHostFree(p);
+    if (c->pinned_shaded) (void)hipHostFree(c->pinned_shaded);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int cap_scene_upload(CapContext* c, const float* positions, const float* normals, const float* texcoords, const uint32_t* indices,
+                     const CapMeshDesc* meshes, uint32_t vertex_count, uint32_t index_count, uint32_t mesh_count)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_scene_upload: ctx is NULL");
+    if ((vertex_count && (!positions || !normals || !texcoords)) || (index_count && !indices) || (mesh_count && !meshes))
+        return fail(CAP_ERR_INVALID_ARG, "cap_scene_upload: NULL array with non-zero count");
+    // validate the descriptors on the host: the kernels index with them unchecked
+    std::vector<uint2> tri_ids;
+    std::vector<uint4> mesh_offsets(mesh_count);
+    std::vector<uint32_t> mesh_texture(mesh_count);
+    for (uint32_t m = 0; m < mesh_count; ++m)
+    {
+        const CapMeshDesc& d = meshes[m];
+        if (d.index != m) return fail(CAP_ERR_INVALID_ARG, "mesh %u: index field is %u (InstanceID must equal the mesh slot)", m, d.index);
+        if (d.index_count % 3) return fail(CAP_ERR_INVALID_ARG, "mesh %u: index_count %u is not a multiple of 3", m, d.index_count);
+        if ((uint64_t)d.first_index_offset + d.index_count > index_count || (uint64_t)d.first_vertex_offset + d.vertex_count > vertex_count)
+            return fail(CAP_ERR_INVALID_ARG, "mesh %u: ranges exceed the pools", m);
+        for (uint32_t k = 0; k < d.index_count; ++k)
+            if (indices[d.first_index_offset + k] >= d.vertex_count)
+                return fail(CAP_ERR_INVALID_ARG, "mesh %u: index %u out of range", m, indices[d.first_index_offset + k]);
+        mesh_offsets[m] = make_uint4(d.first_vertex_offset, d.first_index_offset, 0, 0);
+        mesh_texture[m] = d.texture_index;
+        for (uint32_t p = 0; p < d.index_count / 3; ++p) tri_ids.push_back(make_uint2(m, p));
+    }
+    if (tri_ids.size() >= (1u << 30)) return fail(CAP_ERR_UNSUPPORTED, "too many triangles");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(c->positions.ensure(3 * (size_t)vertex_count));
+    HIP_TRY(c->normals.ensure(3 * (size_t)vertex_count));
+    HIP_TRY(c->texcoords.ensure(2 * (size_t)vertex_count));
+    HIP_TRY(c->indices.ensure(index_count));
+    HIP_TRY(c->tri_ids.ensure(tri_ids.size()));
+    HIP_TRY(c->mesh_offsets.ensure(mesh_count));
+    HIP_TRY(c->mesh_texture.ensure(mesh_count));
+    if (vertex_count)
+    {
+        HIP_TRY(hipMemcpy(c->positions.p, positions, sizeof(float) * 3 * vertex_count, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->normals.p, normals, sizeof(float) * 3 * vertex_count, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->texcoords.p, texcoords, sizeof(float) * 2 * vertex_count, hipMemcpyHostToDevice));
+    }
+    if (index_count) HIP_TRY(hipMemcpy(c->indices.p, indices, sizeof(uint32_t) * index_count, hipMemcpyHostToDevice));
+    if (!tri_ids.empty()) HIP_TRY(hipMemcpy(c->tri_ids.p, tri_ids.data(), sizeof(uint2) * tri_ids.size(), hipMemcpyHostToDevice));
+    if (mesh_count)
+    {
+        HIP_TRY(hipMemcpy(c->mesh_offsets.p, mesh_offsets.data(), sizeof(uint4) * mesh_count, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->mesh_texture.p, mesh_texture.data(), sizeof(uint32_t) * mesh_count, hipMemcpyHostToDevice));
+    }
+    c->vertex_count = vertex_count, c->index_count = index_count, c->mesh_count = mesh_count, c->tri_count = (uint32_t)tri_ids.size();
+    c->scene_ready = true;
+    c->bvh_ready   = false;
+    return CAP_OK;
+}
+
+int cap_texture_upload(CapContext* c, uint32_t index, const uint8_t* rgba8, uint32_t width, uint32_t height)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_texture_upload: ctx is NULL");
+    if (index >= 1024) return fail(CAP_ERR_INVALID_ARG, "texture index %u exceeds the reference's 1024-entry table", index);
+    static const uint8_t zero_texel[4] = {0, 0, 0, 0};  // texture_system.cpp:47-56
+    if (!rgba8) rgba8 = zero_texel, width = height = 1;
+    if (!width || !height) return fail(CAP_ERR_INVALID_ARG, "texture %u: empty extent", index);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->texture_host.size() <= index)
+    {
+        const size_t old = c->texture_host.size();
+        c->texture_data.resize(index + 1);
+        c->texture_host.resize(index + 1);
+        for (size_t i = old; i <= index; ++i)
+        {
+            // holes behave like the missing-texture texel
+            HIP_TRY(c->texture_data[i].ensure(4));
+            HIP_TRY(hipMemcpy(c->texture_data[i].p, zero_texel, 4, hipMemcpyHostToDevice));
+            c->texture_host[i] = TextureDev{c->texture_data[i].p, 1, 1};
+        }
+    }
+    const size_t bytes = 4 * (size_t)width * height;
+    c->texture_data[index].release();
+    HIP_TRY(c->texture_data[index].ensure(bytes));
+    HIP_TRY(hipMemcpy(c->texture_data[index].p, rgba8, bytes, hipMemcpyHostToDevice));
+    c->texture_host[index] = TextureDev{c->texture_data[index].p, width, height};
+    c->textures_dirty = true;
+    return CAP_OK;
+}
+
+int cap_bluenoise_upload(CapContext* c, const uint8_t* rgba8)
+{
+    if (!c || !rgba8) return fail(CAP_ERR_INVALID_ARG, "cap_bluenoise_upload: NULL argument");
+    std::vector<float2> lut(256 * 256);
+    for (size_t i = 0; i < lut.size(); ++i) lut[i] = make_float2((float)rgba8[4 * i] / 255.0f, (float)rgba8[4 * i + 1] / 255.0f);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(c->bluenoise.ensure(lut.size()));
+    HIP_TRY(hipMemcpy(c->bluenoise.p, lut.data(), sizeof(float2) * lut.size(), hipMemcpyHostToDevice));
+    c->bluenoise_ready = true;
+    return CAP_OK;
+}
+
+int cap_materials_upload(CapContext* c, const CapMaterial* materials, uint32_t mesh_count)
+{
+    if (!c || (!materials && mesh_count)) return fail(CAP_ERR_INVALID_ARG, "cap_materials_upload: NULL argument");
+    if (!c->scene_ready || mesh_count != c->mesh_count) return fail(CAP_ERR_STATE, "cap_materials_upload: expected %u materials (one per mesh)", c->mesh_count);
+    c->materials_host.assign(materials, materials + mesh_count);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->materials.ensure(mesh_count));
+    if (mesh_count) HIP_TRY(hipMemcpy(c->materials.p, materials, sizeof(CapMaterial) * mesh_count, hipMemcpyHostToDevice));
+    return CAP_OK;
+}
+
+int cap_bvh_build(CapContext* c)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_bvh_build: ctx is NULL");
+    if (!c->scene_ready) return fail(CAP_ERR_STATE, "cap_bvh_build: no scene uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = c->tri_count;
+    HIP_TRY(c->shade_tris.ensure(6 * (size_t)n));
+    HIP_TRY(c->tris_sorted.ensure(3 * (size_t)n));
+    HIP_TRY(c->tri_raw.ensure(3 * (size_t)n));
+    HIP_TRY(c->tri_box.ensure(2 * (size_t)n));
+    HIP_TRY(c->nodes.ensure(4 * (size_t)(n > 1 ? n - 1 : 1)));
+    HIP_TRY(c->leaf_tri.ensure(n));
+    HIP_TRY(c->keys0.ensure(n));
+    HIP_TRY(c->keys1.ensure(n));
+    HIP_TRY(c->vals0.ensure(n));
+    HIP_TRY(c->vals1.ensure(n));
+    HIP_TRY(c->hist.ensure(256 * bvh_radix_blocks(n)));
+    HIP_TRY(c->parent.ensure(2 * (size_t)n));
+    HIP_TRY(c->flags.ensure(n));
+    HIP_TRY(c->bvh_misc.ensure(8));
+    BvhBuildArgs a{};
+    a.positions = c->positions.p, a.normals = c->normals.p, a.texcoords = c->texcoords.p, a.indices = c->indices.p;
+    a.tri_ids = c->tri_ids.p, a.mesh_offsets = c->mesh_offsets.p, a.tri_count = n;
+    a.shade_tris = c->shade_tris.p, a.tris_sorted = c->tris_sorted.p, a.nodes = c->nodes.p, a.leaf_tri = c->leaf_tri.p;
+    a.tri_raw = c->tri_raw.p, a.tri_box = c->tri_box.p;
+    a.keys[0] = c->keys0.p, a.keys[1] = c->keys1.p, a.vals[0] = c->vals0.p, a.vals[1] = c->vals1.p;
+    a.hist = c->hist.p, a.parent = c->parent.p, a.flags = c->flags.p, a.bounds = c->bvh_misc.p, a.max_depth = c->bvh_misc.p + 6;
+    hipEvent_t e0 = get_event(c), e1 = get_event(c);
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    launch_bvh_build(c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    c->event_pool.push_back(e0), c->event_pool.push_back(e1);
+    uint32_t misc[8] = {0};
+    if (n) HIP_TRY(hipMemcpy(misc, c->bvh_misc.p, sizeof(misc), hipMemcpyDeviceToHost));
+    CapBvhInfo& bi    = c->bvh_info;
+    bi                = CapBvhInfo{};
+    bi.triangle_count = n;
+    bi.node_count     = n > 1 ? n - 1 : 0;
+    bi.max_depth      = n ? misc[6] : 0;
+    bi.build_ms       = ms;
+    for (int k = 0; k < 3 && n; ++k)
+    {
+        auto dec = [](uint32_t o) {
+            uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+            float    f;
+            memcpy(&f, &u, 4);
+            return f;
+        };
+        bi.bounds_lo[k] = dec(misc[k]), bi.bounds_hi[k] = dec(misc[3 + k]);
+    }
+    if (bi.max_depth > 64)
+        return fail(CAP_ERR_UNSUPPORTED, "LBVH depth %u exceeds the 64-entry traversal stack", bi.max_depth);
+    bi.stack_entries = bi.max_depth <= 32 ? 32 : 64;
+    c->bvh_ready     = true;
+    return CAP_OK;
+}
+
+int cap_bvh_info(CapContext* c, CapBvhInfo* out)
+{
+    if (!c || !out) return fail(CAP_ERR_INVALID_ARG, "cap_bvh_info: NULL argument");
+    if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_bvh_info: BVH not built");
+    *out = c->bvh_info;
+    return CAP_OK;
+}
+
+int cap_bvh_readback(CapContext* c, float* nodes, uint32_t* leaf_triangles)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_bvh_readback: ctx is NULL");
+    if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_bvh_readback: BVH not built");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (nodes && c->bvh_info.node_count)
+        HIP_TRY(hipMemcpy(nodes, c->nodes.p, sizeof(float4) * 4 * c->bvh_info.node_count, hipMemcpyDeviceToHost));
+    if (leaf_triangles && c->tri_count)
+        HIP_TRY(hipMemcpy(leaf_triangles, c->leaf_tri.p, sizeof(uint32_t) * c->tri_count, hipMemcpyDeviceToHost));
+    return CAP_OK;
+}
+
+int cap_camera_set(CapContext* c, const CapCameraData* camera)
+{
+    if (!c || !camera) return fail(CAP_ERR_INVALID_ARG, "cap_camera_set: NULL argument");
+    c->camera       = *camera;
+    c->camera_ready = true;
+    return CAP_OK;
+}
+
+int cap_set_resolution(CapContext* c, uint32_t width, uint32_t height)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_resolution: ctx is NULL");
+    if (!width || !height || width > 32768 || height > 32768) return fail(CAP_ERR_INVALID_ARG, "cap_set_resolution: bad extent %ux%u", width, height);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    update_screen(c, width, height, c->screen.shard_index, c->screen.shard_count);
+    if ((uint64_t)c->screen.pixels_padded > kPidMask) return fail(CAP_ERR_UNSUPPORTED, "too many pixels per shard");
+    c->accum.release();
+    return CAP_OK;
+}
+
+int cap_set_shard(CapContext* c, uint32_t shard_index, uint32_t shard_count)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_shard: ctx is NULL");
+    if (!shard_count || shard_index >= shard_count) return fail(CAP_ERR_INVALID_ARG, "cap_set_shard: bad shard %u of %u", shard_index, shard_count);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    update_screen(c, c->screen.width, c->screen.height, shard_index, shard_count);
+    c->accum.release();
+    return CAP_OK;
+}
+
+int cap_set_batch_paths(CapContext* c, uint64_t max_paths)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_batch_paths: ctx is NULL");
+    c->max_batch_paths = max_paths;
+    return CAP_OK;
+}
+
+int cap_accum_reset(CapContext* c)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_accum_reset: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->accum.p) HIP_TRY(hipMemsetAsync(c->accum.p, 0, sizeof(float4) * c->accum.n, c->stream));
+    c->frames_accumulated = 0;
+    return CAP_OK;
+}
+
+int cap_sync(CapContext* c)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_sync: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    return sync_and_collect(c);
+}
+
+int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t num_bounces, uint32_t flags)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_render: ctx is NULL");
+    if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_render: call cap_bvh_build first");
+    if (!c->camera_ready || !c->bluenoise_ready || !c->screen.width) return fail(CAP_ERR_STATE, "cap_render: camera, blue noise and resolution must be set");
+    if (flags & CAP_RENDER_EXT_MATERIALS) return fail(CAP_ERR_UNSUPPORTED, "cap_render: EXT materials are not available in this build");
+    if (num_bounces > 1024) return fail(CAP_ERR_INVALID_ARG, "cap_render: num_bounces too large");
+    if (!n_frames) return CAP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+
+    const uint32_t Ppad = c->screen.pixels_padded;
+    uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)8 << 20;
+    uint32_t       slots  = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / std::max(1u, Ppad), kMaxFrameSlots));
+    slots                 = std::min(slots, n_frames);
+    // drain the previous call (its per-frame constants and counters are reused below), then stage this call's constants
+    if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
+    if (ensure_wavefront(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
+    HIP_TRY(c->frames.ensure(n_frames));
+    {
+        std::vector<FrameConst> fcs(n_frames);
+        for (uint32_t f = 0; f < n_frames; ++f) fcs[f] = frame_const(frame_begin + f);
+        HIP_TRY(hipMemcpy(c->frames.p, fcs.data(), sizeof(FrameConst) * n_frames, hipMemcpyHostToDevice));
+    }
+    const bool st = (flags & CAP_RENDER_STAGE_TIMERS) != 0;
+    if (c->textures_dirty)
+    {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(c->textures.ensure(std::max<size_t>(1, c->texture_host.size())));
+        if (!c->texture_host.empty())
+            HIP_TRY(hipMemcpy(c->textures.p, c->texture_host.data(), sizeof(TextureDev) * c->texture_host.size(), hipMemcpyHostToDevice));
+        c->textures_dirty = false;
+    }
+
+    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, c->bvh_info.stack_entries};
+    const BvhDev    bvh   = bvh_dev(c);
+    const SceneDev  scene = scene_dev(c);
+    const CameraDev cam   = camera_dev(c->camera);
+    const uint32_t  D     = num_bounces;
+    StageTimer* total = new StageTimer(c, ST_COUNT);
+
+    for (uint32_t done = 0; done < n_frames; done += slots)
+    {
+        const uint32_t ns = std::min(slots, n_frames - done);
+        const FrameConst* frames = c->frames.p + done;
+        HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * 2 * (D + 1), c->stream));
+        uint32_t*      ext_count = c->counters.p;
+        uint32_t*      sh_count  = c->counters.p + (D + 1);
+        const bool     last_batch = done + ns >= n_frames;
+        const uint32_t aov_slot   = ((flags & CAP_RENDER_AOV) && last_batch) ? ns - 1 : ~0u;
+        const uint32_t max_count  = ns * Ppad;
+
+        {
+            StageTimer t(c, ST_PRIMARY, st);
+            launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, c->hits.p);
+        }
+        if (aov_slot != ~0u) launch_geo_aov(cfg, scene, c->hits.p + (size_t)aov_slot * Ppad, Ppad, c->aov_geo.p);
+
+        ShadeArgs sa{};
+        sa.scene = scene, sa.cam = cam, sa.screen = c->screen, sa.frames = frames, sa.hits = c->hits.p;
+        sa.planes = Planes{c->pl_color.p, c->pl_direct.p, c->pl_albedo.p, c->aov_geo.p, c->aov_nd.p};
+        sa.n_slots = ns, sa.num_bounces = D, sa.max_count = max_count, sa.aov_slot = aov_slot, sa.shaded_counter = c->shaded_counter.p;
+        for (uint32_t b = 0; b <= D; ++b)
+        {
+            const int pi = (int)(b & 1u), po = pi ^ 1;
+            sa.bounce    = b;
+            sa.in        = RayQueue{c->q_org[pi].p, c->q_dir[pi].p, c->q_thr[pi].p, b ? ext_count + (b - 1) : nullptr};
+            sa.out       = RayQueue{c->q_org[po].p, c->q_dir[po].p, c->q_thr[po].p, ext_count + b};
+            sa.shadow    = ShadowQueue{c->s_org.p, c->s_dir.p, c->s_con.p, sh_count + b};
+            {
+                StageTimer t(c, ST_SHADE, st);
+                launch_shade(cfg, sa);
+                ++c->stats.launches_shade;
+            }
+            {
+                StageTimer t(c, ST_ANY, st);
+                launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad);
+                ++c->stats.launches_trace_any;
+            }
+            if (b < D)
+            {
+                StageTimer t(c, ST_CLOSEST, st);
+                launch_trace_closest(cfg, bvh, sa.out, max_count, c->hits.p);
+                ++c->stats.launches_trace_closest;
+            }
+        }
+        {
+            StageTimer t(c, ST_RESOLVE, st);
+            launch_resolve(cfg, sa.planes, ns, Ppad, c->accum.p);
+        }
+        // queue lengths of this batch -> pinned host memory, summed at the next sync
+        uint32_t* pinned = nullptr;
+        if (!c->pinned_pool.empty())
+        {
+            pinned = c->pinned_pool.back();
+            c->pinned_pool.pop_back();
+        }
+        else
+            HIP_TRY(hipHostMalloc((void**)&pinned, sizeof(uint32_t) * 2 * 1025, hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(pinned, c->counters.p, sizeof(uint32_t) * 2 * (D + 1), hipMemcpyDeviceToHost, c->stream));
+        c->pending.push_back({pinned, D});
+        HIP_TRY(hipGetLastError());
+
+        // primary rays: one per valid pixel per frame
+        uint64_t valid = 0;
+        for (uint32_t lt = 0; lt < c->screen.local_tiles; ++lt)
+        {
+            const uint32_t gt = lt * c->screen.shard_count + c->screen.shard_index;
+            const uint32_t ty = gt / c->screen.tiles_x, tx = gt % c->screen.tiles_x;
+            const uint32_t w = std::min(kTileDim, c->screen.width - tx * kTileDim), h = std::min(kTileDim, c->screen.height - ty * kTileDim);
+            valid += (uint64_t)w * h;
+        }
+        c->stats.rays_primary += valid * ns;
+        c->stats.frames += ns;
+        c->frames_accumulated += ns;
+        c->last_slots = ns;
+        c->aov_valid  = aov_slot != ~0u;
+        // the next batch reuses counters/frames: serialise on the stream (already), and bound the event backlog
+        if (c->spans.size() > 4096)
+        {
+            delete total;
+            total = nullptr;
+            if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
+            total = new StageTimer(c, ST_COUNT);
+        }
+    }
+    delete total;
+    return CAP_OK;
+}
+
+int cap_readback(CapContext* c, CapBufferKind kind, float* dst)
+{
+    if (!c || !dst) return fail(CAP_ERR_INVALID_ARG, "cap_readback: NULL argument");
+    if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_readback: resolution not set");
+    HIP_TRY(hipSetDevice(c->device));
+    if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
+    const size_t npix = (size_t)c->screen.width * c->screen.height;
+    const uint32_t Ppad = c->screen.pixels_padded;
+    HIP_TRY(c->image_tmp.ensure(npix));
+    HIP_TRY(hipMemsetAsync(c->image_tmp.p, 0, sizeof(float4) * npix, c->stream));
+    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
+    const bool is_aov = kind <= CAP_BUF_COMBINED;
+    if (is_aov && !c->aov_valid) return fail(CAP_ERR_STATE, "cap_readback: no frame rendered with CAP_RENDER_AOV");
+    if (!is_aov && !c->accum.p) return fail(CAP_ERR_STATE, "cap_readback: nothing rendered");
+    const size_t off = (size_t)(c->last_slots ? c->last_slots - 1 : 0) * Ppad;
+    switch (kind)
+    {
+    case CAP_BUF_GBUFFER_GEO: launch_untile(cfg, c->screen, c->aov_geo.p, nullptr, nullptr, 0, c->image_tmp.p); break;
+    case CAP_BUF_NORMAL_DEPTH: launch_untile(cfg, c->screen, c->aov_nd.p, nullptr, nullptr, 0, c->image_tmp.p); break;
+    case CAP_BUF_DIRECT: launch_untile(cfg, c->screen, c->pl_direct.p + off, nullptr, nullptr, 0, c->image_tmp.p); break;
+    case CAP_BUF_ALBEDO: launch_untile(cfg, c->screen, c->pl_albedo.p + off, nullptr, nullptr, 0, c->image_tmp.p); break;
+    case CAP_BUF_INDIRECT: launch_untile(cfg, c->screen, c->pl_color.p + off, nullptr, nullptr, 0, c->image_tmp.p); break;
+    case CAP_BUF_COMBINED:
+        launch_untile(cfg, c->screen, c->pl_color.p + off, c->pl_albedo.p + off, c->pl_direct.p + off, 1, c->image_tmp.p);
+        break;
+    case CAP_BUF_ACCUM_SUM: launch_untile(cfg, c->screen, c->accum.p, nullptr, nullptr, 0, c->image_tmp.p); break;
+    case CAP_BUF_ACCUM_MEAN: launch_untile(cfg, c->screen, c->accum.p, nullptr, nullptr, 2, c->image_tmp.p); break;
+    default: return fail(CAP_ERR_INVALID_ARG, "cap_readback: unknown buffer kind %d", (int)kind);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(dst, c->image_tmp.p, sizeof(float4) * npix, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CAP_OK;
+}
+
+int cap_stats_get(CapContext* c, CapStats* out)
+{
+    if (!c || !out) return fail(CAP_ERR_INVALID_ARG, "cap_stats_get: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
+    *out = c->stats;
+    return CAP_OK;
+}
+
+int cap_stats_reset(CapContext* c)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_stats_reset: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
+    c->stats = CapStats{};
+    if (c->shaded_counter.p) HIP_TRY(hipMemset(c->shaded_counter.p, 0, sizeof(uint64_t)));
+    return CAP_OK;
+}
+
+int cap_tile_buffer_floats(CapContext* c, size_t* out_floats)
+{
+    if (!c || !out_floats) return fail(CAP_ERR_INVALID_ARG, "cap_tile_buffer_floats: NULL argument");
+    if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_tile_buffer_floats: resolution not set");
+    *out_floats = (size_t)c->screen.pixels_padded * 4;
+    return CAP_OK;
+}
+
+int cap_resolve_tiles(CapContext* c, float* device_dst)
+{
+    if (!c || !device_dst) return fail(CAP_ERR_INVALID_ARG, "cap_resolve_tiles: NULL argument");
+    if (!c->accum.p) return fail(CAP_ERR_STATE, "cap_resolve_tiles: nothing rendered");
+    HIP_TRY(hipSetDevice(c->device));
+    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
+    launch_tiles_mean(cfg, c->accum.p, c->screen.pixels_padded, reinterpret_cast<float4*>(device_dst));
+    HIP_TRY(hipGetLastError());
+    return CAP_OK;
+}
+
+int cap_assemble_tiles(CapContext* c, const float* device_src, uint32_t shard_count, float* device_image)
+{
+    if (!c || !device_src || !device_image) return fail(CAP_ERR_INVALID_ARG, "cap_assemble_tiles: NULL argument");
+    if (shard_count != c->screen.shard_count) return fail(CAP_ERR_INVALID_ARG, "cap_assemble_tiles: shard_count %u != context's %u", shard_count, c->screen.shard_count);
+    HIP_TRY(hipSetDevice(c->device));
+    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
+    launch_assemble(cfg, c->screen, reinterpret_cast<const float4*>(device_src), shard_count, reinterpret_cast<float4*>(device_image));
+    HIP_TRY(hipGetLastError());
+    return CAP_OK;
+}
+}

@@ -1,0 +1,685 @@
+// kernels.hip — gfx950 (CDNA4) kernels of the wavefront path tracer: BVH traversal / triangle intersection,
+// shading + BSDF sampling + 64-lane queue compaction, radiance accumulate and tile exchange helpers.
+//
+// Reference semantics (paths relative to /root/reference/src/core/shaders): rt_primary_visibility.hlsl,
+// rt_direct_lighting.hlsl, rt_indirect.hlsl, camera.h, sampling.h, lighting.h, shading.h, scene.h.
+// The DXR TraceRay / acceleration structure (driver code in the reference) is replaced by the explicit
+// traversal below.  No MFMA: nothing here is a dense contraction.
+#include "cap_kernels.h"
+
+namespace cap
+{
+// ------------------------------------------------------------------------------------------------
+// Traversal
+// ------------------------------------------------------------------------------------------------
+struct Ray
+{
+    v3    o, d, inv;
+    float tmin, tmax;
+};
+
+__device__ __forceinline__ Ray make_ray(v3 o, v3 d, float tmin, float tmax)
+{
+    Ray r;
+    r.o = o, r.d = d, r.tmin = tmin, r.tmax = tmax;
+    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    return r;
+}
+
+// Conservative slab test: returns entry distance, hit when entry <= exit * (1 + 2ulp).  NaNs from 0 * inf are
+// dropped by fminf/fmaxf (IEEE minNum/maxNum), which only widens the interval.
+__device__ __forceinline__ bool slab(const Ray& r, float lox, float loy, float loz, float hix, float hiy, float hiz, float tfar,
+                                     float& tnear_out)
+{
+    const float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
+    const float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
+    const float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), r.tmin));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tfar));
+    tnear_out      = tn;
+    return tn <= tf * 1.0000004f;
+}
+
+// Two-sided Moller-Trumbore in the determinant-scaled domain; one division per accepted candidate.
+// Hit rule: tmin < t < tmax (DXR triangle rule); barycentrics weight v1, v2 (scene.h:46-49).
+__device__ __forceinline__ bool tri_test(const Ray& r, const float4 t0, const float4 t1, const float4 t2, float& t, float& u, float& v)
+{
+    const v3    v0 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x);
+    const v3    pvec = cross3(r.d, e2);
+    float       det  = dot3(e1, pvec);
+    const v3    tvec = r.o - v0;
+    const v3    qvec = cross3(tvec, e1);
+    float       U = dot3(tvec, pvec), V = dot3(r.d, qvec), T = dot3(e2, qvec);
+    if (det < 0.0f)
+    {
+        U = -U, V = -V, T = -T, det = -det;
+    }
+    if (!(det > 0.0f)) return false;
+    if (!(U >= 0.0f && V >= 0.0f && U + V <= det)) return false;
+    const float inv = 1.0f / det;
+    const float tt  = T * inv;
+    if (!(tt > r.tmin && tt < r.tmax)) return false;
+    t = tt, u = U * inv, v = V * inv;
+    return true;
+}
+
+// Closest hit: minimum t, equal t resolved towards the lower global triangle id (visit-order independent).
+// stack: this lane's column of the per-wave LDS stack; entry k lives at stack[k * kBlock].
+template <int STACK>
+__device__ __forceinline__ void traverse_closest(const BvhDev& bvh, const Ray& r, uint32_t* stack, float& best_t, float& best_u,
+                                                 float& best_v, uint32_t& best_gid)
+{
+    best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
+    if (bvh.tri_count == 0) return;
+    int node = bvh.root;
+    int sp   = 0;
+    while (true)
+    {
+        if (node >= 0)
+        {
+            const float4 q0 = bvh.nodes[4 * node + 0], q1 = bvh.nodes[4 * node + 1], q2 = bvh.nodes[4 * node + 2],
+                         q3 = bvh.nodes[4 * node + 3];
+            float      tn0, tn1;
+            const bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tn0);
+            const bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tn1);
+            const int  c0 = (int)f2u(q3.x), c1 = (int)f2u(q3.y);
+            if (h0 && h1)
+            {
+                const bool swap = tn1 < tn0;
+                if (sp < STACK) stack[(sp++) * kBlock] = (uint32_t)(swap ? c0 : c1);
+                node = swap ? c1 : c0;
+                continue;
+            }
+            if (h0 || h1)
+            {
+                node = h0 ? c0 : c1;
+                continue;
+            }
+        }
+        else
+        {
+            const uint32_t leaf = (uint32_t)~node;
+            const float4   t0 = bvh.tris[3 * leaf + 0], t1 = bvh.tris[3 * leaf + 1], t2 = bvh.tris[3 * leaf + 2];
+            float          t, u, v;
+            if (tri_test(r, t0, t1, t2, t, u, v))
+            {
+                const uint32_t gid = f2u(t2.y);
+                if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+            }
+        }
+        if (sp == 0) break;
+        node = (int)stack[(--sp) * kBlock];
+    }
+}
+
+// Any hit (RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH, lighting.h:49): true when some triangle has tmin < t < tmax.
+template <int STACK>
+__device__ __forceinline__ bool traverse_any(const BvhDev& bvh, const Ray& r, uint32_t* stack)
+{
+    if (bvh.tri_count == 0) return false;
+    int node = bvh.root;
+    int sp   = 0;
+    while (true)
+    {
+        if (node >= 0)
+        {
+            const float4 q0 = bvh.nodes[4 * node + 0], q1 = bvh.nodes[4 * node + 1], q2 = bvh.nodes[4 * node + 2],
+                         q3 = bvh.nodes[4 * node + 3];
+            float      tn0, tn1;
+            const bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.tmax, tn0);
+            const bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.tmax, tn1);
+            const int  c0 = (int)f2u(q3.x), c1 = (int)f2u(q3.y);
+            if (h0 && h1)
+            {
+                if (sp < STACK) stack[(sp++) * kBlock] = (uint32_t)c1;
+                node = c0;
+                continue;
+            }
+            if (h0 || h1)
+            {
+                node = h0 ? c0 : c1;
+                continue;
+            }
+        }
+        else
+        {
+            const uint32_t leaf = (uint32_t)~node;
+            const float4   t0 = bvh.tris[3 * leaf + 0], t1 = bvh.tris[3 * leaf + 1], t2 = bvh.tris[3 * leaf + 2];
+            float          t, u, v;
+            if (tri_test(r, t0, t1, t2, t, u, v)) return true;
+        }
+        if (sp == 0) break;
+        node = (int)stack[(--sp) * kBlock];
+    }
+    return false;
+}
+
+// Work distribution of the queue kernels: the grid is persistent (fixed size, independent of the device-side
+// queue length); each wave takes 64-ray chunks strided by the number of waves in the grid.  A wave whose first
+// chunk is past the end leaves at once, so the grid always drains.
+__device__ __forceinline__ uint32_t wave_global_id() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
+__device__ __forceinline__ uint32_t wave_total() { return gridDim.x * (kBlock / 64); }
+
+// camera.h:39-63
+__device__ __forceinline__ v3 primary_dir(const CameraDev& cam, const ScreenDev& sc, const FrameConst& fc, uint32_t x, uint32_t y)
+{
+    const float ix = ((float)x + fc.jitter_x) / (float)sc.width, iy = ((float)y + fc.jitter_y) / (float)sc.height;
+    const float cx = (ix - 0.5f) * cam.sensor_x, cy = (iy - 0.5f) * cam.sensor_y;
+    const v3    d  = mk3(fmaf(cy, cam.up[0], fmaf(cx, cam.right[0], cam.focal_length * cam.forward[0])),
+                         fmaf(cy, cam.up[1], fmaf(cx, cam.right[1], cam.focal_length * cam.forward[1])),
+                         fmaf(cy, cam.up[2], fmaf(cx, cam.right[2], cam.focal_length * cam.forward[2])));
+    return normalize3(d);
+}
+
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void k_trace_primary(BvhDev bvh, CameraDev cam, ScreenDev screen, const FrameConst* frames,
+                                                          float4* hits)
+{
+    __shared__ uint32_t lds_stack[STACK * kBlock];
+    uint32_t*           stack  = lds_stack + threadIdx.x;
+    const uint32_t      slot   = blockIdx.y;
+    const FrameConst    fc     = frames[slot];
+    const uint32_t      chunks = screen.pixels_padded >> 6;
+    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
+    {
+        const uint32_t pl = chunk * 64 + (threadIdx.x & 63u);
+        uint32_t       x, y;
+        float          t = kPrimaryFar, u = 0.0f, v = 0.0f;
+        uint32_t       gid = kInvalidId;
+        if (local_pixel_to_xy(screen, pl, x, y))
+        {
+            const Ray r = make_ray(mk3(cam.position[0], cam.position[1], cam.position[2]), primary_dir(cam, screen, fc, x, y), 0.0f,
+                                   kPrimaryFar);
+            traverse_closest<STACK>(bvh, r, stack, t, u, v, gid);
+        }
+        hits[(size_t)slot * screen.pixels_padded + pl] = make_float4(u, v, u2f(gid), t);
+    }
+}
+
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(BvhDev bvh, RayQueue q, float4* hits)
+{
+    __shared__ uint32_t lds_stack[STACK * kBlock];
+    uint32_t*           stack  = lds_stack + threadIdx.x;
+    const uint32_t      count  = *q.count;
+    const uint32_t      chunks = (count + 63u) >> 6;
+    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
+    {
+        const uint32_t i = chunk * 64 + (threadIdx.x & 63u);
+        if (i < count)
+        {
+            const float4 a = q.org_tmin[i], b = q.dir_tmax[i];
+            const Ray    r = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
+            float        t, u, v;
+            uint32_t     gid;
+            traverse_closest<STACK>(bvh, r, stack, t, u, v, gid);
+            hits[i] = make_float4(u, v, u2f(gid), t);
+        }
+    }
+}
+
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded)
+{
+    __shared__ uint32_t lds_stack[STACK * kBlock];
+    uint32_t*           stack  = lds_stack + threadIdx.x;
+    const uint32_t      count  = *q.count;
+    const uint32_t      chunks = (count + 63u) >> 6;
+    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
+    {
+        const uint32_t i = chunk * 64 + (threadIdx.x & 63u);
+        if (i < count)
+        {
+            const float4 a = q.org_tmin[i], b = q.dir_tmax[i];
+            const Ray    r = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
+            if (!traverse_any<STACK>(bvh, r, stack))
+            {
+                // lighting.h:57-60: unoccluded -> the contribution evaluated at shading time is added.  One shadow ray
+                // per path per bounce, so the read-modify-write needs no atomic.
+                const float4   c   = q.contrib_pid[i];
+                const uint32_t pid = f2u(c.w);
+                const size_t   idx = (size_t)(pid >> kPidShift) * pixels_padded + (pid & kPidMask);
+                float4         tv  = target[idx];
+                tv.x = tv.x + c.x, tv.y = tv.y + c.y, tv.z = tv.z + c.z;
+                target[idx] = tv;
+            }
+        }
+    }
+}
+
+void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraDev& cam, const ScreenDev& screen,
+                          const FrameConst* frames, uint32_t n_slots, float4* hits)
+{
+    const uint32_t chunks = screen.pixels_padded >> 6;
+    uint32_t       gx     = (chunks + 3) / 4;
+    if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
+    if (gx == 0) gx = 1;
+    dim3 grid(gx, n_slots);
+    if (cfg.stack_entries <= 32)
+        hipLaunchKernelGGL(k_trace_primary<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, cam, screen, frames, hits);
+    else
+        hipLaunchKernelGGL(k_trace_primary<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, cam, screen, frames, hits);
+}
+
+static uint32_t queue_grid(const LaunchCfg& cfg, uint32_t max_count)
+{
+    uint32_t g = (max_count + kBlock - 1) / kBlock;
+    if (g > cfg.grid_blocks) g = cfg.grid_blocks;
+    return g ? g : 1;
+}
+
+void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits)
+{
+    dim3 grid(queue_grid(cfg, max_count));
+    if (cfg.stack_entries <= 32)
+        hipLaunchKernelGGL(k_trace_closest<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
+    else
+        hipLaunchKernelGGL(k_trace_closest<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
+}
+
+void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target,
+                      uint32_t pixels_padded)
+{
+    dim3 grid(queue_grid(cfg, max_count));
+    if (cfg.stack_entries <= 32)
+        hipLaunchKernelGGL(k_trace_any<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded);
+    else
+        hipLaunchKernelGGL(k_trace_any<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shading
+// ------------------------------------------------------------------------------------------------
+// sampling.h:13-23 with the texel pre-divided by 255 on the host (identical fp32 quotient).
+__device__ __forceinline__ void bluenoise4x4(const float2* tex, uint32_t x, uint32_t y, uint32_t count, float& s0, float& s1)
+{
+    const uint32_t px = (count % 16u) % 4u, py = (count % 16u) / 4u;
+    const uint32_t sx = (x * 4u + px) % 256u, sy = (y * 4u + py) % 256u;
+    const float2   t  = tex[sy * 256u + sx];
+    const float    k  = 0.61803398875f * (float)(count / 16u);
+    const float    a = t.x + k, b = t.y + k;
+    s0 = a - floorf(a);
+    s1 = b - floorf(b);
+}
+
+// sampling.h:91-111
+__device__ __forceinline__ v3 ortho_vector(v3 n)
+{
+    if (fabsf(n.z) > 0.0f)
+    {
+        const float k = sqrtf(fmaf(n.z, n.z, n.y * n.y));
+        return mk3(0.0f, -n.z / k, n.y / k);
+    }
+    const float k = sqrtf(fmaf(n.y, n.y, n.x * n.x));
+    return mk3(n.y / k, -n.x / k, 0.0f);
+}
+
+// sampling.h:113-132 with e = 1 (shading.h:26): pow(1 - r2, 1/2) == sqrt(1 - r2)
+__device__ __forceinline__ v3 map_to_hemisphere(float r1, float r2, v3 n)
+{
+    v3       u = ortho_vector(n);
+    const v3 v = cross3(u, n);
+    u          = cross3(n, v);
+    float sin_psi, cos_psi;
+    sincos_c((2.0f * kPi) * r1, sin_psi, cos_psi);
+    const float cos_theta = sqrtf(1.0f - r2);
+    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    const float a = sin_theta * cos_psi, b = sin_theta * sin_psi;
+    return normalize3(mk3(fmaf(n.x, cos_theta, fmaf(v.x, b, u.x * a)), fmaf(n.y, cos_theta, fmaf(v.y, b, u.y * a)),
+                          fmaf(n.z, cos_theta, fmaf(v.z, b, u.z * a))));
+}
+
+// math_functions.h:36-47
+__device__ __forceinline__ void oct_encode(v3 n, float& ox, float& oy)
+{
+    const float s = fabsf(n.x) + fabsf(n.y) + fabsf(n.z);
+    n             = mk3(n.x / s, n.y / s, n.z / s);
+    ox = n.x, oy = n.y;
+    if (!(n.z >= 0.0f))
+    {
+        ox = (1.0f - fabsf(n.y)) * (n.x >= 0.0f ? 1.0f : -1.0f);
+        oy = (1.0f - fabsf(n.x)) * (n.y >= 0.0f ? 1.0f : -1.0f);
+    }
+    ox = ox * 0.5f + 0.5f;
+    oy = oy * 0.5f + 0.5f;
+}
+
+__device__ __forceinline__ uint32_t wrap_texel(float f, uint32_t n)
+{
+    const float m = f - floorf(f / (float)n) * (float)n;
+    int         i = (int)m;
+    if (i < 0) i = 0;
+    if ((uint32_t)i >= n) i = 0;
+    return (uint32_t)i;
+}
+
+// SampleLevel(..., 0) bilinear + WRAP on RGBA8 (scene.h:57, raytracing_system.cpp:377)
+__device__ __forceinline__ v3 sample_texture(const TextureDev& tex, float u, float v)
+{
+    const float    fx = fmaf(u, (float)tex.width, -0.5f), fy = fmaf(v, (float)tex.height, -0.5f);
+    const float    x0f = floorf(fx), y0f = floorf(fy);
+    const float    wx = fx - x0f, wy = fy - y0f;
+    const uint32_t x0 = wrap_texel(x0f, tex.width), y0 = wrap_texel(y0f, tex.height);
+    const uint32_t x1 = (x0 + 1 == tex.width) ? 0 : x0 + 1, y1 = (y0 + 1 == tex.height) ? 0 : y0 + 1;
+    const uchar4*  t   = reinterpret_cast<const uchar4*>(tex.rgba8);
+    const uchar4   c00 = t[y0 * tex.width + x0], c10 = t[y0 * tex.width + x1], c01 = t[y1 * tex.width + x0], c11 = t[y1 * tex.width + x1];
+    auto           lerp2 = [&](uint8_t a00, uint8_t a10, uint8_t a01, uint8_t a11) {
+        const float f00 = (float)a00 / 255.0f, f10 = (float)a10 / 255.0f, f01 = (float)a01 / 255.0f, f11 = (float)a11 / 255.0f;
+        const float top = fmaf(f10 - f00, wx, f00);
+        const float bot = fmaf(f11 - f01, wx, f01);
+        return fmaf(bot - top, wy, top);
+    };
+    return mk3(lerp2(c00.x, c10.x, c01.x, c11.x), lerp2(c00.y, c10.y, c01.y, c11.y), lerp2(c00.z, c10.z, c01.z, c11.z));
+}
+
+// Append one item per active lane to a device queue: one atomic per wave (64-lane ballot + popcount prefix).
+__device__ __forceinline__ uint32_t wave_append(bool emit, uint32_t* counter)
+{
+    const unsigned long long mask = __ballot(emit);
+    if (mask == 0ull) return 0;
+    const uint32_t lane   = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t       base   = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
+{
+    const uint32_t Ppad = a.screen.pixels_padded;
+    uint32_t       count, chunks;
+    if (FIRST)
+    {
+        count  = Ppad;  // identity queue: item i of slot blockIdx.y is local pixel i
+        chunks = Ppad >> 6;
+    }
+    else
+    {
+        count  = *a.in.count;
+        chunks = (count + 63u) >> 6;
+    }
+    uint32_t n_shaded = 0;
+    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
+    {
+        const uint32_t i      = chunk * 64 + (threadIdx.x & 63u);
+        const bool     active = i < count;
+        uint32_t       pid = 0, slot = 0, pl = 0;
+        float4         hit = make_float4(0.f, 0.f, u2f(kInvalidId), 0.f);
+        v3             thr = mk3(1.0f, 1.0f, 1.0f);
+        if (active)
+        {
+            if (FIRST)
+            {
+                slot = blockIdx.y, pl = i, pid = (slot << kPidShift) | pl;
+                hit  = a.hits[(size_t)slot * Ppad + pl];
+            }
+            else
+            {
+                const float4 tp = a.in.thr_pid[i];
+                thr = mk3(tp.x, tp.y, tp.z), pid = f2u(tp.w), slot = pid >> kPidShift, pl = pid & kPidMask;
+                hit = a.hits[i];
+            }
+        }
+        const size_t plane_idx = (size_t)slot * Ppad + pl;
+        uint32_t     x = 0, y = 0;
+        const bool   valid = active && local_pixel_to_xy(a.screen, pl, x, y);
+        const uint32_t gid = f2u(hit.z);
+
+        bool   emit_shadow = false, emit_ext = false;
+        v3     p = mk3(0, 0, 0), dir = mk3(0, 0, 0), contrib = mk3(0, 0, 0);
+        FrameConst fc;
+        if (valid) fc = a.frames[slot];
+
+        if (FIRST && active && !valid)
+        {
+            // padding lane of a partial / absent tile: define the planes so the resolve adds exact zeros
+            a.planes.color[plane_idx]  = make_float4(0, 0, 0, 0);
+            a.planes.direct[plane_idx] = make_float4(0, 0, 0, 0);
+            a.planes.albedo[plane_idx] = make_float4(0, 0, 0, 0);
+        }
+        if (valid && gid == kInvalidId)
+        {
+            if (FIRST)
+            {
+                // rt_direct_lighting.hlsl:53-59, rt_indirect.hlsl:75-79
+                a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
+                a.planes.direct[plane_idx] = make_float4(0.7f, 0.7f, 0.85f, 1.f);
+                a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (slot == a.aov_slot) a.planes.aov_normal_depth[pl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            else
+            {
+                // rt_indirect.hlsl:94-99  color += throughput * sky
+                float4 c = a.planes.color[plane_idx];
+                c.x = c.x + thr.x * 0.7f, c.y = c.y + thr.y * 0.7f, c.z = c.z + thr.z * 0.85f;
+                a.planes.color[plane_idx] = c;
+            }
+        }
+        else if (valid)
+        {
+            ++n_shaded;
+            // scene.h:5-50 InterpolateAttributes on the pre-gathered triangle record
+            const float4* st = a.scene.shade_tris + 6 * (size_t)gid;
+            const float4  s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3], s4 = st[4], s5 = st[5];
+            const float   u = hit.x, v = hit.y, w = (1.0f - u) - v;
+            auto          mix = [&](float c0, float c1, float c2) { return fmaf(c2, v, fmaf(c1, u, c0 * w)); };
+            const v3      n = normalize3(mk3(mix(s3.x, s4.x, s5.x), mix(s3.y, s4.y, s5.y), mix(s3.z, s4.z, s5.z)));
+            p = mk3(mix(s0.x, s1.x, s2.x), mix(s0.y, s1.y, s2.y), mix(s0.z, s1.z, s2.z));
+            // scene.h:52-61 GetMaterial
+            v3             kd   = mk3(a.scene.kd_untextured, a.scene.kd_untextured, a.scene.kd_untextured);
+            const uint32_t inst = a.scene.tri_ids[gid].x;
+            const uint32_t tex  = a.scene.mesh_texture[inst];
+            if (tex != kInvalidId && tex < a.scene.texture_count)
+            {
+                const float tu = mix(s0.w, s2.w, s4.w), tv = mix(s1.w, s3.w, s5.w);
+                const v3    c  = sample_texture(a.scene.textures[tex], tu, 1.0f - tv);
+                kd             = mk3(pow22_c(c.x), pow22_c(c.y), pow22_c(c.z));
+            }
+            const bool black = kd.x < 1e-5f && kd.y < 1e-5f && kd.z < 1e-5f;  // rt_direct_lighting.hlsl:68, rt_indirect.hlsl:108
+            if (FIRST)
+            {
+                a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
+                a.planes.direct[plane_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
+                a.planes.albedo[plane_idx] = black ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(kd.x, kd.y, kd.z, 1.f);
+                if (slot == a.aov_slot)
+                {
+                    float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!black)
+                    {
+                        oct_encode(n, nd.x, nd.y);
+                        nd.z = (float)inst;
+                        nd.w = length3(mk3(a.cam.position[0], a.cam.position[1], a.cam.position[2]) - p);
+                    }
+                    a.planes.aov_normal_depth[pl] = nd;
+                }
+            }
+            if (!black)
+            {
+                // lighting.h:35-61: unshadowed direct term; the visibility ray is queued for the any-hit kernel
+                const v3    L   = mk3(fc.light_dir[0], fc.light_dir[1], fc.light_dir[2]);
+                const float ndl = fmaxf(0.0f, dot3(n, L));
+                v3          c   = mk3(((fc.light_intensity[0] * kd.x) * kInvPi) * ndl, ((fc.light_intensity[1] * kd.y) * kInvPi) * ndl,
+                                      ((fc.light_intensity[2] * kd.z) * kInvPi) * ndl);
+                if (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f)
+                {
+                    emit_shadow = true;
+                    contrib     = FIRST ? c : thr * c;  // rt_direct_lighting.hlsl:77 / rt_indirect.hlsl:136
+                }
+                // rt_indirect.hlsl:149-170
+                float r1, r2;
+                bluenoise4x4(a.scene.bluenoise, x, y, fc.frame_count * 25u + a.bounce, r1, r2);
+                dir             = map_to_hemisphere(r1, r2, n);
+                const float ndd = dot3(n, dir);
+                const float pdf = fmaxf(0.0f, ndd) / kPi;  // shading.h:19-22
+                if (!(pdf < 1e-5f))
+                {
+                    const float f = (kInvPi * fmaxf(ndd, 0.0f)) / pdf;
+                    thr           = thr * f;
+                    if (!FIRST) thr = thr * kd;
+                    // the reference traces one more ray after the last bounce whose payload is never read (:91,:173)
+                    emit_ext = a.bounce < a.num_bounces;
+                }
+            }
+        }
+
+        const uint32_t si = wave_append(emit_shadow, a.shadow.count);
+        if (emit_shadow)
+        {
+            const FrameConst& f = fc;
+            a.shadow.org_tmin[si]    = make_float4(p.x, p.y, p.z, kRayEps);
+            a.shadow.dir_tmax[si]    = make_float4(f.light_dir[0], f.light_dir[1], f.light_dir[2], kRayFar);
+            a.shadow.contrib_pid[si] = make_float4(contrib.x, contrib.y, contrib.z, u2f(pid));
+        }
+        const uint32_t ei = wave_append(emit_ext, a.out.count);
+        if (emit_ext)
+        {
+            a.out.org_tmin[ei] = make_float4(p.x, p.y, p.z, kRayEps);
+            a.out.dir_tmax[ei] = make_float4(dir.x, dir.y, dir.z, kRayFar);
+            a.out.thr_pid[ei]  = make_float4(thr.x, thr.y, thr.z, u2f(pid));
+        }
+    }
+    // statistics: shaded vertices, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
+    if ((threadIdx.x & 63u) == 0 && n_shaded) atomicAdd((unsigned long long*)a.shaded_counter, (unsigned long long)n_shaded);
+}
+
+void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args)
+{
+    if (args.bounce == 0)
+    {
+        const uint32_t chunks = args.screen.pixels_padded >> 6;
+        uint32_t       gx     = (chunks + 3) / 4;
+        if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
+        if (gx == 0) gx = 1;
+        hipLaunchKernelGGL(k_shade<true>, dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, args);
+    }
+    else
+    {
+        hipLaunchKernelGGL(k_shade<false>, dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Accumulate / exchange
+// ------------------------------------------------------------------------------------------------
+// combine_illumination.hlsl:29 per frame, then a plain running fp32 sum in frame order.
+__global__ __launch_bounds__(kBlock) void k_resolve(Planes planes, uint32_t n_slots, uint32_t Ppad, float4* accum)
+{
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < Ppad; pl += gridDim.x * kBlock)
+    {
+        float4 acc = accum[pl];
+        for (uint32_t s = 0; s < n_slots; ++s)
+        {
+            const size_t idx = (size_t)s * Ppad + pl;
+            const float4 c = planes.color[idx], al = planes.albedo[idx], d = planes.direct[idx];
+            acc.x = acc.x + (c.x * al.x + d.x);
+            acc.y = acc.y + (c.y * al.y + d.y);
+            acc.z = acc.z + (c.z * al.z + d.z);
+            acc.w = acc.w + 1.0f;
+        }
+        accum[pl] = acc;
+    }
+}
+
+void launch_resolve(const LaunchCfg& cfg, const Planes& planes, uint32_t n_slots, uint32_t Ppad, float4* accum)
+{
+    uint32_t g = (Ppad + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_resolve, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, planes, n_slots, Ppad, accum);
+}
+
+__global__ __launch_bounds__(kBlock) void k_untile(ScreenDev sc, const float4* src, const float4* albedo, const float4* direct,
+                                                   int kind, float4* image)
+{
+    const uint32_t n = sc.local_tiles * kTilePixels;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < n; pl += gridDim.x * kBlock)
+    {
+        uint32_t x, y;
+        if (!local_pixel_to_xy(sc, pl, x, y)) continue;
+        float4 v = src[pl];
+        if (kind == 1)
+        {
+            const float4 al = albedo[pl], d = direct[pl];
+            // combine_illumination.hlsl:24,29 (indirect.w is forced to 1 before the multiply-add)
+            v = make_float4(v.x * al.x + d.x, v.y * al.y + d.y, v.z * al.z + d.z, 1.0f * al.w + d.w);
+        }
+        else if (kind == 2)
+        {
+            v = make_float4(v.x / v.w, v.y / v.w, v.z / v.w, v.w);
+        }
+        image[(size_t)y * sc.width + x] = v;
+    }
+}
+
+void launch_untile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* src, const float4* albedo, const float4* direct,
+                   int plane_kind, float4* image)
+{
+    uint32_t g = (screen.local_tiles * kTilePixels + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_untile, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, screen, src, albedo, direct, plane_kind, image);
+}
+
+__global__ __launch_bounds__(kBlock) void k_tiles_mean(const float4* accum, uint32_t Ppad, float4* dst)
+{
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < Ppad; pl += gridDim.x * kBlock)
+    {
+        const float4 v = accum[pl];
+        dst[pl] = v.w > 0.0f ? make_float4(v.x / v.w, v.y / v.w, v.z / v.w, v.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+void launch_tiles_mean(const LaunchCfg& cfg, const float4* accum, uint32_t Ppad, float4* dst)
+{
+    uint32_t g = (Ppad + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_tiles_mean, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, accum, Ppad, dst);
+}
+
+// gathered: [shard][Ppad] tile-ordered pixels -> row-major image
+__global__ __launch_bounds__(kBlock) void k_assemble(ScreenDev sc, const float4* gathered, uint32_t shard_count, float4* image)
+{
+    const uint32_t total = sc.tile_count * kTilePixels;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock)
+    {
+        const uint32_t gt = i >> 6, w = i & 63u;
+        const uint32_t shard = gt % shard_count, lt = gt / shard_count;
+        const uint32_t ty = gt / sc.tiles_x, tx = gt - ty * sc.tiles_x;
+        const uint32_t x = tx * kTileDim + (w & 7u), y = ty * kTileDim + (w >> 3);
+        if (x < sc.width && y < sc.height)
+            image[(size_t)y * sc.width + x] = gathered[(size_t)shard * sc.pixels_padded + lt * kTilePixels + w];
+    }
+}
+
+void launch_assemble(const LaunchCfg& cfg, const ScreenDev& screen, const float4* gathered, uint32_t shard_count, float4* image)
+{
+    uint32_t g = (screen.tile_count * kTilePixels + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_assemble, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, screen, gathered, shard_count, image);
+}
+
+// rt_primary_visibility.hlsl:46: (uv, asfloat(InstanceID), asfloat(PrimitiveIndex)); a miss keeps uv = 0, ids = ~0u (:41-43)
+__global__ __launch_bounds__(kBlock) void k_geo_aov(SceneDev scene, const float4* hits, uint32_t Ppad, float4* out)
+{
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < Ppad; pl += gridDim.x * kBlock)
+    {
+        const float4   h   = hits[pl];
+        const uint32_t gid = f2u(h.z);
+        if (gid == kInvalidId)
+            out[pl] = make_float4(0.f, 0.f, u2f(kInvalidId), u2f(kInvalidId));
+        else
+        {
+            const uint2 id = scene.tri_ids[gid];
+            out[pl]        = make_float4(h.x, h.y, u2f(id.x), u2f(id.y));
+        }
+    }
+}
+
+void launch_geo_aov(const LaunchCfg& cfg, const SceneDev& scene, const float4* hits_slot, uint32_t Ppad, float4* aov_geo)
+{
+    uint32_t g = (Ppad + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_geo_aov, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, scene, hits_slot, Ppad, aov_geo);
+}
+}  // namespace cap

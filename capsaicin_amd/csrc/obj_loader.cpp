@@ -1,0 +1,360 @@
+// obj_loader.cpp — OBJ/MTL parser behind the tinyobj-shaped surface of obj_loader.h, plus the C ABI of
+// include/capsaicin_scene.h: LoadObjFile's per-shape (vertex, normal, texcoord) de-duplication and the CPU half of
+// CreateGeometryStorage (reference src/systems/asset_load_system.cpp:43-160, 162-233).
+#include "obj_loader.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <tuple>
+
+#include "../../include/capsaicin_scene.h"
+
+namespace tinyobj
+{
+namespace
+{
+// Tokenise on blanks/tabs; strips a trailing '\r'.
+std::vector<std::string> split_ws(const std::string& line)
+{
+    std::vector<std::string> out;
+    size_t                   i = 0, n = line.size();
+    while (i < n)
+    {
+        while (i < n && (line[i] == ' ' || line[i] == '\t' || line[i] == '\r')) ++i;
+        size_t j = i;
+        while (j < n && line[j] != ' ' && line[j] != '\t' && line[j] != '\r') ++j;
+        if (j > i) out.emplace_back(line, i, j - i);
+        i = j;
+    }
+    return out;
+}
+
+bool parse_float(const std::string& s, float* out)
+{
+    char*  end = nullptr;
+    double v   = std::strtod(s.c_str(), &end);
+    if (end == s.c_str()) return false;
+    *out = (float)v;
+    return true;
+}
+
+// OBJ indices are 1-based; negative values count back from the current end of the attribute array.
+bool fix_index(const std::string& s, int count, int* out)
+{
+    char* end = nullptr;
+    long  v   = std::strtol(s.c_str(), &end, 10);
+    if (end == s.c_str() || v == 0) return false;
+    *out = v > 0 ? (int)v - 1 : count + (int)v;
+    return *out >= 0 && *out < count;
+}
+
+std::string join_from(const std::vector<std::string>& t, size_t first)
+{
+    std::string s;
+    for (size_t i = first; i < t.size(); ++i) s += (i > first ? " " : "") + t[i];
+    return s;
+}
+
+bool load_mtl(const std::string& path, std::vector<material_t>* materials, std::map<std::string, int>* by_name)
+{
+    std::ifstream f(path);
+    if (!f) return false;
+    std::string line;
+    material_t* cur = nullptr;
+    while (std::getline(f, line))
+    {
+        auto t = split_ws(line);
+        if (t.empty() || t[0][0] == '#') continue;
+        if (t[0] == "newmtl")
+        {
+            materials->emplace_back();
+            cur             = &materials->back();
+            cur->name       = join_from(t, 1);
+            (*by_name)[cur->name] = (int)materials->size() - 1;
+        }
+        else if (cur && (t[0] == "Kd" || t[0] == "Ks" || t[0] == "Ke") && t.size() >= 4)
+        {
+            float* dst = t[0] == "Kd" ? cur->diffuse : t[0] == "Ks" ? cur->specular : cur->emission;
+            for (int k = 0; k < 3; ++k) parse_float(t[1 + k], &dst[k]);
+        }
+        else if (cur && t[0] == "Ns" && t.size() >= 2)
+            parse_float(t[1], &cur->shininess);
+        else if (cur && t[0] == "map_Kd" && t.size() >= 2)
+            cur->diffuse_texname = t.back();
+    }
+    return true;
+}
+}  // namespace
+
+bool LoadObj(attrib_t* attrib, std::vector<shape_t>* shapes, std::vector<material_t>* materials, std::string* warn,
+             std::string* err, const char* filename, const char* mtl_basedir)
+{
+    attrib->vertices.clear(), attrib->normals.clear(), attrib->texcoords.clear();
+    shapes->clear(), materials->clear();
+    std::ifstream f(filename);
+    if (!f)
+    {
+        if (err) *err += std::string("Cannot open file [") + filename + "]\n";
+        return false;
+    }
+    std::string basedir;
+    if (mtl_basedir && *mtl_basedir)
+    {
+        basedir = mtl_basedir;
+        if (basedir.back() != '/') basedir += '/';
+    }
+    else
+    {
+        std::string fn(filename);
+        size_t      slash = fn.find_last_of('/');
+        basedir           = slash == std::string::npos ? "" : fn.substr(0, slash + 1);
+    }
+    std::map<std::string, int> material_by_name;
+    shape_t                    cur;
+    int                        cur_material = -1;
+    std::string                line;
+    size_t                     line_no = 0;
+    auto flush = [&]() {
+        if (!cur.mesh.indices.empty()) shapes->push_back(cur);
+        cur = shape_t();
+    };
+    while (std::getline(f, line))
+    {
+        ++line_no;
+        auto t = split_ws(line);
+        if (t.empty() || t[0][0] == '#') continue;
+        const std::string& k = t[0];
+        auto bad = [&](const char* what) {
+            if (err) *err += std::string(filename) + ":" + std::to_string(line_no) + ": " + what + "\n";
+            return false;
+        };
+        if (k == "v" || k == "vn")
+        {
+            if (t.size() < 4) return bad("expected 3 coordinates");
+            float v[3];
+            for (int c = 0; c < 3; ++c)
+                if (!parse_float(t[1 + c], &v[c])) return bad("malformed number");
+            auto& dst = k == "v" ? attrib->vertices : attrib->normals;
+            dst.insert(dst.end(), v, v + 3);
+        }
+        else if (k == "vt")
+        {
+            if (t.size() < 2) return bad("expected texture coordinates");
+            float u = 0.f, v = 0.f;
+            if (!parse_float(t[1], &u)) return bad("malformed number");
+            if (t.size() > 2 && !parse_float(t[2], &v)) return bad("malformed number");
+            attrib->texcoords.push_back(u), attrib->texcoords.push_back(v);
+        }
+        else if (k == "f")
+        {
+            std::vector<index_t> face;
+            for (size_t i = 1; i < t.size(); ++i)
+            {
+                index_t     idx{-1, -1, -1};
+                std::string tok = t[i];
+                size_t      s1  = tok.find('/');
+                std::string a = tok.substr(0, s1), b, c;
+                if (s1 != std::string::npos)
+                {
+                    size_t s2 = tok.find('/', s1 + 1);
+                    b         = tok.substr(s1 + 1, s2 == std::string::npos ? std::string::npos : s2 - s1 - 1);
+                    if (s2 != std::string::npos) c = tok.substr(s2 + 1);
+                }
+                if (!fix_index(a, (int)attrib->vertices.size() / 3, &idx.vertex_index)) return bad("vertex index out of range");
+                if (!b.empty() && !fix_index(b, (int)attrib->texcoords.size() / 2, &idx.texcoord_index)) return bad("texcoord index out of range");
+                if (!c.empty() && !fix_index(c, (int)attrib->normals.size() / 3, &idx.normal_index)) return bad("normal index out of range");
+                face.push_back(idx);
+            }
+            if (face.size() < 3) return bad("face with fewer than 3 vertices");
+            for (size_t j = 2; j < face.size(); ++j)  // fan: (0, j-1, j)
+            {
+                cur.mesh.indices.push_back(face[0]);
+                cur.mesh.indices.push_back(face[j - 1]);
+                cur.mesh.indices.push_back(face[j]);
+                cur.mesh.material_ids.push_back(cur_material);
+            }
+        }
+        else if (k == "o" || k == "g")
+        {
+            flush();
+            cur.name = join_from(t, 1);
+        }
+        else if (k == "usemtl")
+        {
+            auto it      = material_by_name.find(join_from(t, 1));
+            cur_material = it == material_by_name.end() ? -1 : it->second;
+        }
+        else if (k == "mtllib")
+        {
+            for (size_t i = 1; i < t.size(); ++i)
+                if (!load_mtl(basedir + t[i], materials, &material_by_name) && warn)
+                    *warn += "Material file [ " + t[i] + " ] not found in a path : " + basedir + "\n";
+        }
+        // s, l, p and unknown records are ignored
+    }
+    flush();
+    return true;
+}
+}  // namespace tinyobj
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI (include/capsaicin_scene.h)
+// ---------------------------------------------------------------------------------------------------------
+struct CapGeometry
+{
+    std::vector<float>       positions, normals, texcoords;
+    std::vector<uint32_t>    indices;
+    std::vector<CapMeshDesc> meshes;
+    std::vector<std::string> texture_names;
+    std::vector<CapMaterial> mesh_materials;
+    uint32_t                 material_count = 0;
+    std::string              warn;
+};
+
+// Both halves of the library report through the same cap_last_error(); the setter lives in context.hip.
+extern "C" void cap_set_error_(const char* msg);
+
+extern "C" {
+
+int cap_obj_load(const char* obj_path, const char* mtl_dir, CapGeometry** out)
+{
+    if (!obj_path || !out)
+    {
+        cap_set_error_("cap_obj_load: NULL argument");
+        return CAP_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    tinyobj::attrib_t                attrib;
+    std::vector<tinyobj::shape_t>    shapes;
+    std::vector<tinyobj::material_t> objmaterials;
+    std::string                      warn, err;
+    // asset_load_system.cpp:54-67: a non-empty err or a false return throws in the reference
+    bool ret = tinyobj::LoadObj(&attrib, &shapes, &objmaterials, &warn, &err, obj_path, mtl_dir);
+    if (!err.empty() || !ret)
+    {
+        cap_set_error_(("AssetLoadSystem: Couldn't load " + std::string(obj_path) + ": " + err).c_str());
+        return CAP_ERR_IO;
+    }
+    CapGeometry* g    = new CapGeometry;
+    g->warn           = warn;
+    g->material_count = (uint32_t)objmaterials.size();
+    // asset_load_system.cpp:76-89: texture index per material (name -> index in first-use order, texture_system.cpp:20-36)
+    std::vector<uint32_t> texture_indices;
+    for (auto& m : objmaterials)
+    {
+        if (m.diffuse_texname.empty())
+        {
+            texture_indices.push_back(~0u);
+            continue;
+        }
+        uint32_t idx = 0;
+        for (; idx < g->texture_names.size(); ++idx)
+            if (g->texture_names[idx] == m.diffuse_texname) break;
+        if (idx == g->texture_names.size()) g->texture_names.push_back(m.diffuse_texname);
+        texture_indices.push_back(idx);
+    }
+    const float kd_default = std::pow(0.75f, 2.2f);  // only a display default for the EXT material table
+    uint32_t    vertex_total = 0, index_total = 0;
+    for (uint32_t si = 0; si < shapes.size(); ++si)
+    {
+        // asset_load_system.cpp:100-142
+        std::map<std::tuple<int, int, int>, uint32_t> cache;
+        const auto&                                   sh = shapes[si];
+        uint32_t                                      nverts = 0;
+        const uint32_t                                first_index = index_total;
+        for (const auto& ix : sh.mesh.indices)
+        {
+            auto key = std::make_tuple(ix.vertex_index, ix.normal_index, ix.texcoord_index);
+            auto it  = cache.find(key);
+            if (it != cache.end())
+            {
+                g->indices.push_back(it->second);
+                continue;
+            }
+            cache[key] = nverts;
+            g->indices.push_back(nverts++);
+            for (int k = 0; k < 3; ++k) g->positions.push_back(attrib.vertices[3 * ix.vertex_index + k]);
+            for (int k = 0; k < 3; ++k) g->normals.push_back(ix.normal_index != -1 ? attrib.normals[3 * ix.normal_index + k] : 0.f);
+            for (int k = 0; k < 2; ++k) g->texcoords.push_back(ix.texcoord_index != -1 ? attrib.texcoords[2 * ix.texcoord_index + k] : 0.f);
+        }
+        index_total += (uint32_t)sh.mesh.indices.size();
+        // asset_load_system.cpp:146-150 and 171-179
+        const int   mat = sh.mesh.material_ids.empty() ? -1 : sh.mesh.material_ids[0];
+        CapMeshDesc d{};
+        d.vertex_count        = nverts;
+        d.first_vertex_offset = vertex_total;
+        d.index_count         = (uint32_t)sh.mesh.indices.size();
+        d.first_index_offset  = first_index;
+        d.index               = si;
+        d.texture_index       = mat == -1 ? ~0u : texture_indices[mat];
+        g->meshes.push_back(d);
+        vertex_total += nverts;
+        CapMaterial cm{};
+        if (mat == -1)
+            cm.kd[0] = cm.kd[1] = cm.kd[2] = kd_default, cm.roughness = 1.f;
+        else
+        {
+            const auto& m = objmaterials[mat];
+            for (int k = 0; k < 3; ++k) cm.kd[k] = m.diffuse[k], cm.ks[k] = m.specular[k], cm.ke[k] = m.emission[k];
+            // Blinn-Phong exponent -> GGX alpha = sqrt(2 / (Ns + 2)); roughness = sqrt(alpha)
+            cm.roughness = std::sqrt(std::sqrt(2.0f / (m.shininess + 2.0f)));
+        }
+        g->mesh_materials.push_back(cm);
+    }
+    *out = g;
+    return CAP_OK;
+}
+
+void cap_geometry_free(CapGeometry* g) { delete g; }
+
+int cap_geometry_view(const CapGeometry* g, CapGeometryView* out)
+{
+    if (!g || !out)
+    {
+        cap_set_error_("cap_geometry_view: NULL argument");
+        return CAP_ERR_INVALID_ARG;
+    }
+    out->positions      = g->positions.data();
+    out->normals        = g->normals.data();
+    out->texcoords      = g->texcoords.data();
+    out->indices        = g->indices.data();
+    out->meshes         = g->meshes.data();
+    out->vertex_count   = (uint32_t)(g->positions.size() / 3);
+    out->index_count    = (uint32_t)g->indices.size();
+    out->mesh_count     = (uint32_t)g->meshes.size();
+    out->texture_count  = (uint32_t)g->texture_names.size();
+    out->material_count = g->material_count;
+    return CAP_OK;
+}
+
+const char* cap_geometry_texture_name(const CapGeometry* g, uint32_t i)
+{
+    return (g && i < g->texture_names.size()) ? g->texture_names[i].c_str() : nullptr;
+}
+
+const char* cap_geometry_warning(const CapGeometry* g) { return g ? g->warn.c_str() : ""; }
+
+int cap_geometry_materials(const CapGeometry* g, CapMaterial* out)
+{
+    if (!g || !out)
+    {
+        cap_set_error_("cap_geometry_materials: NULL argument");
+        return CAP_ERR_INVALID_ARG;
+    }
+    std::memcpy(out, g->mesh_materials.data(), sizeof(CapMaterial) * g->mesh_materials.size());
+    return CAP_OK;
+}
+
+int cap_scene_upload_geometry(CapContext* ctx, const CapGeometry* g)
+{
+    CapGeometryView v;
+    int             rc = cap_geometry_view(g, &v);
+    if (rc) return rc;
+    return cap_scene_upload(ctx, v.positions, v.normals, v.texcoords, v.indices, v.meshes, v.vertex_count, v.index_count, v.mesh_count);
+}
+}

@@ -1,0 +1,63 @@
+// viewer_main.cpp — headless counterpart of the reference viewer (src/viewer/main.cpp:50-107): same call sequence
+// (Init, InitRenderSession, LoadSceneFromOBJ, Render per frame, ShutdownRenderSession, Shutdown), a frame loop
+// instead of the Win32 message pump, a PPM file instead of the swap chain.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "capsaicin.h"
+
+int main(int argc, char** argv)
+{
+    RenderSessionParams params;  // 1920x1080 like main.cpp:53-54
+    std::string         scene = "assets/cornell_box.obj", out = "frame.ppm";
+    int                 frames = 64, bounces = 1;
+    bool                cornell_camera = true;
+    for (int i = 1; i < argc; ++i)
+    {
+        auto next = [&]() { return i + 1 < argc ? argv[++i] : ""; };
+        if (!std::strcmp(argv[i], "--scene")) scene = next();
+        else if (!std::strcmp(argv[i], "--out")) out = next();
+        else if (!std::strcmp(argv[i], "--width")) params.width = (uint32_t)std::atoi(next());
+        else if (!std::strcmp(argv[i], "--height")) params.height = (uint32_t)std::atoi(next());
+        else if (!std::strcmp(argv[i], "--frames")) frames = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--bounces")) bounces = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--device")) params.device = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--default-camera")) cornell_camera = false;
+        else
+        {
+            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--default-camera]\n", argv[0]);
+            return 2;
+        }
+    }
+    try
+    {
+        capsaicin::Init();
+        capsaicin::InitRenderSession(&params);
+        capsaicin::LoadSceneFromOBJ(scene);
+        capsaicin::GetSettings().num_diffuse_bounces = bounces;
+        if (cornell_camera)
+        {
+            // the reference default (0,15,0)/+z is tuned for Sponza; SURVEY.md 8d fixes this view for the Cornell box
+            auto& cam = capsaicin::GetCamera();
+            cam.position[0] = -0.01f, cam.position[1] = 0.995f, cam.position[2] = 3.4f;
+            cam.forward[0] = 0.f, cam.forward[1] = 0.f, cam.forward[2] = -1.f;
+            cam.right[0] = -1.f, cam.right[1] = 0.f, cam.right[2] = 0.f;
+            cam.up[0] = 0.f, cam.up[1] = 1.f, cam.up[2] = 0.f;
+            cam.focal_length = 0.035f;
+        }
+        for (int f = 0; f < frames; ++f) capsaicin::Render();  // one Render() per WM_PAINT in the reference (main.cpp:17-19)
+        capsaicin::SaveFramePPM(out);
+        std::fputs(capsaicin::TimingsReport().c_str(), stderr);
+        capsaicin::ShutdownRenderSession();
+        capsaicin::Shutdown();
+    }
+    catch (const std::exception& e)
+    {
+        std::fprintf(stderr, "fatal: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

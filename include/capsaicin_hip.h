@@ -1,0 +1,186 @@
+/*
+ * capsaicin_hip.h — C ABI of the MI355X (gfx950) wavefront path tracer: the device-side drop-in for the
+ * reference's RaytracingSystem + BLAS/TLAS systems.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to /root/reference/src/core).
+ * All functions return CAP_OK (0) or a CapStatus error; cap_last_error() gives the thread-local message.
+ * No exception crosses this boundary.  A context is single-threaded (the reference runs every system on the
+ * UI thread, capsaicin.cpp:38-45, main.cpp:17-19); use one context per GPU.
+ * Host pointers are borrowed for the duration of the call only.  Pointers documented as "device" must be
+ * device-accessible on the context's GPU.
+ */
+#ifndef CAPSAICIN_HIP_H
+#define CAPSAICIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct CapContext CapContext;
+
+typedef enum CapStatus
+{
+    CAP_OK                = 0,
+    CAP_ERR_INVALID_ARG   = 1,
+    CAP_ERR_HIP           = 2, /* a HIP runtime call failed (no GPU, out of memory, ...) */
+    CAP_ERR_STATE         = 3, /* call order violated (e.g. render before bvh_build) */
+    CAP_ERR_UNSUPPORTED   = 4,
+    CAP_ERR_IO            = 5
+} CapStatus;
+
+/* CameraData, src/systems/camera_system.h:16-31 == shaders/data_payload.h:7-18 (72 bytes). */
+typedef struct CapCameraData
+{
+    float position[3];
+    float focal_length;
+    float right[3];
+    float znear;
+    float forward[3];
+    float focus_distance;
+    float up[3];
+    float aperture;
+    float sensor_size[2];
+} CapCameraData;
+
+/* MeshComponent, src/systems/asset_load_system.h:29-39 == shaders/data_payload.h:20-30 (32 bytes). */
+typedef struct CapMeshDesc
+{
+    uint32_t vertex_count;
+    uint32_t first_vertex_offset;
+    uint32_t index_count;
+    uint32_t first_index_offset;
+    uint32_t index;
+    uint32_t texture_index; /* MeshComponent::material_index; ~0u = untextured */
+    uint32_t padding[2];
+} CapMeshDesc;
+
+/* EXT (no reference counterpart): per-mesh material for CAP_RENDER_EXT_MATERIALS. */
+typedef struct CapMaterial
+{
+    float kd[3];
+    float roughness;
+    float ks[3];
+    float pad0;
+    float ke[3];
+    float pad1;
+} CapMaterial;
+
+/* cap_render flags */
+enum
+{
+    CAP_RENDER_AOV           = 1u << 0, /* keep the per-frame planes of the LAST frame for cap_readback */
+    CAP_RENDER_EXT_MATERIALS = 1u << 1, /* EXT shading model (materials uploaded with cap_materials_upload) */
+    CAP_RENDER_STAGE_TIMERS  = 1u << 2  /* bracket every kernel with hipEvents (fills CapStats::ms_<stage>) */
+};
+
+/* cap_readback kinds: the reference's RaytracingSystem outputs (raytracing_system.h, cpp:466-575). */
+typedef enum CapBufferKind
+{
+    CAP_BUF_GBUFFER_GEO  = 0, /* rt_primary_visibility.hlsl:46  (u, v, asfloat(instance), asfloat(prim)) */
+    CAP_BUF_DIRECT       = 1, /* rt_direct_lighting.hlsl:78      output_direct_                           */
+    CAP_BUF_ALBEDO       = 2, /* rt_direct_lighting.hlsl:79      gbuffer_albedo_                          */
+    CAP_BUF_NORMAL_DEPTH = 3, /* rt_direct_lighting.hlsl:80      gbuffer_normal_depth_                    */
+    CAP_BUF_INDIRECT     = 4, /* rt_indirect.hlsl:176            output_indirect_                         */
+    CAP_BUF_COMBINED     = 5, /* combine_illumination.hlsl:29    indirect*albedo + direct (xyz; w = 1)    */
+    CAP_BUF_ACCUM_SUM    = 6, /* running fp32 sum of COMBINED over all frames since cap_accum_reset (w = frames) */
+    CAP_BUF_ACCUM_MEAN   = 7  /* ACCUM_SUM / frames                                                       */
+} CapBufferKind;
+
+/* Per-stage names follow the reference's timestamp labels (raytracing_system.cpp:1024, 1099, 1207). */
+typedef struct CapStats
+{
+    uint64_t rays_primary;   /* rays actually traced since the last cap_stats_reset */
+    uint64_t rays_extension;
+    uint64_t rays_shadow;
+    uint64_t shaded_vertices;
+    uint64_t frames;
+    double   ms_total;          /* GPU time of cap_render calls (hipEvent, context stream) */
+    double   ms_primary;        /* "RaytracePrimaryVisibility" */
+    double   ms_trace_closest;  /* extension-ray traversal ("RT Indirect diffuse", trace part) */
+    double   ms_trace_any;      /* shadow-ray traversal */
+    double   ms_shade;          /* shading / BSDF sampling / compaction */
+    double   ms_resolve;        /* radiance accumulate */
+    uint64_t launches_trace_closest;
+    uint64_t launches_trace_any;
+    uint64_t launches_shade;
+} CapStats;
+
+typedef struct CapBvhInfo
+{
+    uint32_t triangle_count;
+    uint32_t node_count;  /* internal nodes (triangle_count - 1, or 0) */
+    uint32_t max_depth;
+    uint32_t stack_entries; /* per-lane LDS traversal stack the trace kernels were specialised for */
+    float    bounds_lo[3];
+    float    bounds_hi[3];
+    double   build_ms;
+} CapBvhInfo;
+
+const char* cap_last_error(void);
+/* number of HIP devices visible (0 without a GPU); never fails */
+int cap_device_count(void);
+
+/* Replaces Dx12 device/queue creation (dx12/dx12.cpp:165-235) + RaytracingSystem ctor (raytracing_system.cpp:182).
+ * hip_stream: an existing hipStream_t to run on (e.g. the caller's torch stream), or NULL to create one. */
+int  cap_ctx_create(int device_id, void* hip_stream, CapContext** out_ctx);
+void cap_ctx_destroy(CapContext* ctx);
+
+/* GeometryStorage upload, CreateGeometryStorage (asset_load_system.cpp:162-255): pooled positions/normals
+ * (3 floats per vertex), texcoords (2 per vertex), mesh-local uint32 indices, 32-byte mesh descriptors. */
+int cap_scene_upload(CapContext* ctx, const float* positions, const float* normals, const float* texcoords,
+                     const uint32_t* indices, const CapMeshDesc* meshes, uint32_t vertex_count, uint32_t index_count,
+                     uint32_t mesh_count);
+/* TextureSystem::LoadTexture upload half (texture_system.cpp:58-118): RGBA8, row 0 first. rgba8 == NULL
+ * installs the reference's "missing texture" 1x1 zero texel (texture_system.cpp:47-56). */
+int cap_texture_upload(CapContext* ctx, uint32_t index, const uint8_t* rgba8, uint32_t width, uint32_t height);
+/* Blue-noise texture load (raytracing_system.cpp:642-646): 256x256 RGBA8; only R,G are read (sampling.h:13-23). */
+int cap_bluenoise_upload(CapContext* ctx, const uint8_t* rgba8_256x256);
+/* EXT */
+int cap_materials_upload(CapContext* ctx, const CapMaterial* materials, uint32_t mesh_count);
+
+/* Replaces BLASSystem::BuildBLAS + TLASSystem::BuildTLAS (blas_system.cpp:14-67, tlas_system.cpp:11-73):
+ * explicit on-device LBVH over all meshes; (instance, primitive) ids are kept per triangle. */
+int cap_bvh_build(CapContext* ctx);
+int cap_bvh_info(CapContext* ctx, CapBvhInfo* out);
+/* Debug/test readback: nodes = node_count * 16 floats (see DESIGN.md "BVH node"), leaf_triangles = triangle ids in leaf order. */
+int cap_bvh_readback(CapContext* ctx, float* nodes, uint32_t* leaf_triangles);
+
+/* CameraSystem::Run upload (camera_system.cpp:89-131). sensor_size is used as given (the caller applies
+ * AdjustCameraAspectBasedOnWindow, camera_system.cpp:10-17). */
+int cap_camera_set(CapContext* ctx, const CapCameraData* camera);
+/* RenderSystem::window_width/height (render_system.h) */
+int cap_set_resolution(CapContext* ctx, uint32_t width, uint32_t height);
+/* Screen-tile sharding: this context renders the 8x8 tiles t with t % shard_count == shard_index. */
+int cap_set_shard(CapContext* ctx, uint32_t shard_index, uint32_t shard_count);
+/* Upper bound of (frame, pixel) paths kept in flight per batch (0 = default). */
+int cap_set_batch_paths(CapContext* ctx, uint64_t max_paths);
+
+/* RaytracingSystem::Run ray passes (raytracing_system.cpp:266-292) for frame_count = frame_begin ..
+ * frame_begin + n_frames - 1, each frame's COMBINED added to the accumulation buffer in frame order.
+ * num_bounces == SettingsComponent::num_diffuse_bounces (gui_system.h:39).  Asynchronous on the context
+ * stream; cap_readback / cap_stats_get / cap_sync wait for it. */
+int cap_render(CapContext* ctx, uint32_t frame_begin, uint32_t n_frames, uint32_t num_bounces, uint32_t flags);
+int cap_accum_reset(CapContext* ctx);
+int cap_sync(CapContext* ctx);
+
+/* dst: width*height*4 floats (host), row 0 = pixel row 0.  Pixels outside this context's shard read 0. */
+int cap_readback(CapContext* ctx, CapBufferKind kind, float* dst);
+
+int cap_stats_get(CapContext* ctx, CapStats* out);
+int cap_stats_reset(CapContext* ctx);
+
+/* ---- multi-GPU tile exchange (one gather of tile radiance at frame end) ---- */
+/* floats in this context's tile-ordered radiance buffer: max_tiles_per_shard * 64 * 4 (same on every shard) */
+int cap_tile_buffer_floats(CapContext* ctx, size_t* out_floats);
+/* writes ACCUM_MEAN of the local tiles, tile order, into a DEVICE buffer of cap_tile_buffer_floats floats */
+int cap_resolve_tiles(CapContext* ctx, float* device_dst);
+/* device_src: shard_count tile buffers back to back (the gather result); device_image: width*height*4 floats */
+int cap_assemble_tiles(CapContext* ctx, const float* device_src, uint32_t shard_count, float* device_image);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPSAICIN_HIP_H */

@@ -1,0 +1,54 @@
+/*
+ * capsaicin_scene.h — C ABI of the host-side scene surface kept from the reference: OBJ/MTL ingestion into the
+ * pooled GeometryStorage layout.  Replaces AssetLoadSystem::LoadObjFile + the CPU half of CreateGeometryStorage
+ * (src/systems/asset_load_system.cpp:43-160, 162-233) and the tinyobjloader call it wraps (:54-55; the
+ * submodule is empty in the reference tree, its consumed behaviour is re-implemented).
+ * No GPU is touched by these functions.
+ */
+#ifndef CAPSAICIN_SCENE_H
+#define CAPSAICIN_SCENE_H
+
+#include <stdint.h>
+
+#include "capsaicin_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct CapGeometry CapGeometry;
+
+/* LoadObjFile (asset_load_system.cpp:43-160).  mtl_dir: directory searched for `mtllib` files ("" or NULL =
+ * directory of the OBJ; the reference passes "../../../assets/", :55).  A missing MTL file is a warning, not an
+ * error, and leaves every mesh untextured.  Parse errors return CAP_ERR_IO (the reference throws). */
+int  cap_obj_load(const char* obj_path, const char* mtl_dir, CapGeometry** out_geometry);
+void cap_geometry_free(CapGeometry* g);
+
+typedef struct CapGeometryView
+{
+    const float*       positions; /* 3 * vertex_count */
+    const float*       normals;   /* 3 * vertex_count */
+    const float*       texcoords; /* 2 * vertex_count */
+    const uint32_t*    indices;   /* index_count, mesh-local */
+    const CapMeshDesc* meshes;    /* mesh_count */
+    uint32_t           vertex_count;
+    uint32_t           index_count;
+    uint32_t           mesh_count;
+    uint32_t           texture_count;  /* distinct diffuse_texname values, in first-use order */
+    uint32_t           material_count; /* materials parsed from the MTL files that could be opened */
+} CapGeometryView;
+
+int         cap_geometry_view(const CapGeometry* g, CapGeometryView* out);
+const char* cap_geometry_texture_name(const CapGeometry* g, uint32_t texture_index);
+const char* cap_geometry_warning(const CapGeometry* g);
+/* EXT: one CapMaterial per mesh from the MTL's Kd/Ks/Ns/Ke of the mesh's first face material (mesh_count entries).
+ * Meshes without a material get kd = 0.75^2.2 (the reference's untextured albedo), ks = ke = 0. */
+int cap_geometry_materials(const CapGeometry* g, CapMaterial* out_materials);
+
+/* Convenience: cap_scene_upload(ctx, view...) */
+int cap_scene_upload_geometry(CapContext* ctx, const CapGeometry* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

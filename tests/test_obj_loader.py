@@ -1,0 +1,104 @@
+"""Native OBJ/MTL ingestion (cap_obj_load) against the pure-Python restatement of asset_load_system.cpp:43-255."""
+import os
+
+import numpy as np
+import pytest
+
+from capsaicin_amd import capi
+from oracle import obj_oracle
+
+
+def _same(native, ref):
+    assert np.array_equal(native.positions.view(np.uint32), ref["positions"].view(np.uint32))
+    assert np.array_equal(native.normals.view(np.uint32), ref["normals"].view(np.uint32))
+    assert np.array_equal(native.texcoords.view(np.uint32), ref["texcoords"].view(np.uint32))
+    assert np.array_equal(native.indices, ref["indices"])
+    assert np.array_equal(native.meshes, ref["meshes"])
+
+
+def test_cornell_box(native_lib, cornell_path):
+    g = capi.Geometry(cornell_path)
+    _same(g, obj_oracle.load_geometry(cornell_path))
+    assert g.meshes.shape == (8, 8) and g.positions.size == 64 * 3 and g.indices.size == 96
+    assert "cornellbox.mtl" in g.warning and g.material_count == 0  # missing MTL is a warning only
+
+
+OBJ_MIXED = """# mixed records
+mtllib a.mtl missing.mtl
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0.5 0.5 1
+vt 0 0
+vt 1 0
+vt 1 1
+vn 0 0 1
+o first
+usemtl red
+f 1/1/1 2/2/1 3/3/1 4/1/1
+f 1 2 5
+g second group
+usemtl tex
+f -1//1 -2//1 -3//1
+f 1/1 2/2 3/3 4/1 5/2
+o empty
+o third
+usemtl nothing
+s off
+f 3/3/1 2/2/1 1/1/1
+"""
+MTL_A = """newmtl red
+Kd 1 0 0
+Ks 0.5 0.5 0.5
+Ns 98
+newmtl tex
+Kd 1 1 1
+map_Kd checker.ppm
+Ke 1 2 3
+"""
+
+
+def test_mixed_records(native_lib, tmp_path):
+    (tmp_path / "m.obj").write_text(OBJ_MIXED)
+    (tmp_path / "a.mtl").write_text(MTL_A)
+    g = capi.Geometry(str(tmp_path / "m.obj"))
+    ref = obj_oracle.load_geometry(str(tmp_path / "m.obj"))
+    _same(g, ref)
+    assert g.meshes.shape[0] == 3  # the empty `o` produces no shape
+    assert list(g.meshes[:, 5]) == [0xFFFFFFFF, 0, 0xFFFFFFFF]  # texture of material_ids[0] only (asset_load_system.cpp:146-150)
+    assert g.texture_names == ["checker.ppm"] and g.material_count == 2 and "missing.mtl" in g.warning
+    # fan triangulation: quad -> 2, pentagon -> 3 triangles
+    assert list(g.meshes[:, 2]) == [9, 12, 3]
+    m = g.materials()
+    np.testing.assert_allclose(m[0, :3], (1, 0, 0))
+    np.testing.assert_allclose(m[1, 8:11], (1, 2, 3))
+    # explicit mtl directory (the reference passes "../../../assets/", asset_load_system.cpp:55)
+    os.makedirs(tmp_path / "mats")
+    (tmp_path / "mats" / "a.mtl").write_text(MTL_A.replace("checker.ppm", "other.ppm"))
+    g2 = capi.Geometry(str(tmp_path / "m.obj"), str(tmp_path / "mats"))
+    assert g2.texture_names == ["other.ppm"]
+    _same(g2, obj_oracle.load_geometry(str(tmp_path / "m.obj"), str(tmp_path / "mats")))
+
+
+def test_missing_normals_and_uvs_become_zero(native_lib, tmp_path):
+    (tmp_path / "t.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    g = capi.Geometry(str(tmp_path / "t.obj"))
+    assert np.all(g.normals == 0) and np.all(g.texcoords == 0) and g.meshes.shape[0] == 1  # asset_load_system.cpp:124-140
+
+
+def test_errors_are_reported_not_swallowed(native_lib, tmp_path):
+    with pytest.raises(capi.CapError):
+        capi.Geometry(str(tmp_path / "does_not_exist.obj"))  # asset_load_system.cpp:57-67 throws
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(capi.CapError):
+        capi.Geometry(str(tmp_path / "bad.obj"))
+    (tmp_path / "bad2.obj").write_text("v 0 0\n")
+    with pytest.raises(capi.CapError):
+        capi.Geometry(str(tmp_path / "bad2.obj"))
+
+
+def test_empty_file(native_lib, tmp_path):
+    (tmp_path / "e.obj").write_text("# nothing\n")
+    g = capi.Geometry(str(tmp_path / "e.obj"))
+    assert g.meshes.shape[0] == 0 and g.indices.size == 0
