@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + extension + shadow rays actually traced) of the HIP wavefront path tracer on
+BASELINE.json configs[1]: cornell_box.obj, 1920x1080, 64 spp, depth 8, on N MI355X GPUs of one node.
+
+One "step" = one complete render of that image: 64 frames (frame_count 0..63) through ray generation -> BVH traversal ->
+shading/BSDF sampling -> radiance accumulate; for N > 1 the frame is sharded by 8x8 screen tiles (tile t -> rank t % N) and a
+step ends with ONE gather of tile radiance to rank 0 (RCCL) + the assembly of the image there.  Total work is fixed as N
+grows ("strong" scaling).  Scene, BVH and blue-noise texture are resident in HBM before the timed region.
+
+Prints one JSON line (rank 0) with the bench contract fields plus `roofline` (dominant kernel: closest-hit traversal of
+extension rays, timed with HIP events on the render stream) and `cpu_baseline` (the scalar CPU oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 64, 8
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.3 TB/s is the measured achievable stream rate
+BYTES_CLOSEST, BYTES_ANY, BYTES_VERTEX = 48, 36, 144  # SURVEY.md 8d algorithmic queue-stream bytes per ray / shaded vertex
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle (kind "port": scalar C++ restatement, BVH mode) on the same scene/camera/depth, 1 frame at a time."""
+    from capsaicin_amd import capi
+    from oracle import cap_oracle as O
+    from oracle import obj_oracle
+    bn = capi.load_bluenoise()
+    g = obj_oracle.load_geometry(os.path.join(ROOT, "assets", "cornell_box.obj"))
+    sc = O.Scene(g["positions"], g["normals"], g["texcoords"], g["indices"], g["meshes"])
+    cam = capi.cornell_camera(WIDTH, HEIGHT)
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0],
+                         cam.sensor_size[1], cam.focal_length)
+    cores = os.cpu_count() or 1
+    rays, frames, t0 = 0, 0, time.time()
+    while True:
+        r = sc.render_frame(ocam, bn, WIDTH, HEIGHT, frames, DEPTH, flags=O.FLAG_USE_BVH, threads=cores)
+        rays += sum(r["rays"])
+        frames += 1
+        el = time.time() - t0
+        if el > budget_s or frames >= 16:
+            break
+    return {"value": rays / el / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d frame(s) of %dx%d depth %d (of the %d spp workload), oracle BVH mode, %d threads, %.1f s" %
+                      (frames, WIDTH, HEIGHT, DEPTH, SPP, cores, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # debugging only; the contract run uses 64
+    ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--batch-paths", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--traversal", type=int, default=0, help=argparse.SUPPRESS)  # 0 auto (contract run), 1 stack, 2 exhaustive
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from capsaicin_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the renderer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        r = capi.Renderer(local_rank, stream.cuda_stream)
+        r.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
+        r.upload_bluenoise(capi.load_bluenoise())
+        bvh = r.build_bvh()
+        r.set_resolution(WIDTH, HEIGHT)
+        r.set_shard(rank, world)
+        r.set_camera(capi.cornell_camera(WIDTH, HEIGHT))
+        if args.batch_paths:
+            r.set_batch_paths(args.batch_paths)
+        r.set_traversal(args.traversal)
+        tile_floats = r.tile_buffer_floats()
+        tile_buf = torch.zeros(tile_floats, dtype=torch.float32, device="cuda")
+        gathered = torch.zeros(tile_floats * world, dtype=torch.float32, device="cuda") if rank == 0 else None
+        image = torch.zeros(WIDTH * HEIGHT * 4, dtype=torch.float32, device="cuda") if rank == 0 else None
+
+        def step(flags=0):
+            r.accum_reset()
+            r.render(0, args.spp, DEPTH, flags)
+            r.resolve_tiles(tile_buf.data_ptr())
+            if world > 1:
+                # the single data-path collective: tile radiance -> rank 0 over xGMI
+                dist.gather(tile_buf, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                r.assemble_tiles((gathered if world > 1 else tile_buf).data_ptr(), world, image.data_ptr())
+
+        def fence():
+            r.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        r.stats_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        st = r.stats()
+
+        # whole-job numbers: MAX time over ranks, SUM of rays over ranks
+        red = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        cnt = torch.tensor([st.rays_primary, st.rays_extension, st.rays_shadow, st.shaded_vertices], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(red, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dt = float(red.item())
+        rays_p, rays_e, rays_s, verts = (float(x) for x in cnt.tolist())
+        rays = rays_p + rays_e + rays_s
+
+        # dominant kernel, timed live with HIP events on the render stream (one extra step with per-kernel event brackets)
+        r.stats_reset()
+        step(capi.RENDER_STAGE_TIMERS)
+        fence()
+        sp = r.stats()
+        roofline = None
+        if rank == 0 and sp.launches_trace_closest:
+            avg_ms = sp.ms_trace_closest / sp.launches_trace_closest
+            bytes_per_launch = BYTES_CLOSEST * sp.rays_extension / sp.launches_trace_closest
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            all_bytes = BYTES_CLOSEST * (sp.rays_extension) + 16 * sp.rays_primary + BYTES_ANY * sp.rays_shadow + BYTES_VERTEX * sp.shaded_vertices
+            roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": avg_ms, "launches": int(sp.launches_trace_closest),
+                        "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_ray": BYTES_CLOSEST,
+                        "rays_per_launch": sp.rays_extension / sp.launches_trace_closest,
+                        "kernel_mrays_per_s": sp.rays_extension / (sp.ms_trace_closest * 1e-3) / 1e6,
+                        "whole_step_queue_stream_gbs": all_bytes / (sp.ms_total * 1e-3) / 1e9,
+                        "stage_ms": {"primary": sp.ms_primary, "trace_closest": sp.ms_trace_closest, "trace_any": sp.ms_trace_any,
+                                     "shade": sp.ms_shade, "resolve": sp.ms_resolve, "total": sp.ms_total}}
+
+        if rank == 0:
+            # sanity of the product of the timed region: finite image, every pixel accumulated spp frames
+            img = image.cpu().numpy().reshape(HEIGHT, WIDTH, 4)
+            assert np.isfinite(img).all() and (img[..., 3] == args.spp).all(), "bench image is incomplete"
+            out = {"metric": "Mrays/sec (primary+secondary), cornell_box 1080p 64spp", "value": rays / dt / 1e6, "unit": "Mrays/s",
+                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": "cornell_box.obj %dx%d %dspp depth=%d (reference shading: Lambert + directional light + sky), "
+                                          "tile-sharded over %d GPU(s)" % (WIDTH, HEIGHT, args.spp, DEPTH, world),
+                              "triangles": int(bvh.triangle_count), "bvh_depth": int(bvh.max_depth),
+                              "rays_per_step": {"primary": rays_p / args.steps, "extension": rays_e / args.steps, "shadow": rays_s / args.steps},
+                              "parallelism": "tiles%d" % world},
+                   "roofline": roofline}
+            out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()  # rank 0, N = 1 only
+            print(json.dumps(out), flush=True)
+        r.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,7 @@ SYMBOLS = {
     "cap_set_resolution": (_i, [_vp, _u32, _u32]),
     "cap_set_shard": (_i, [_vp, _u32, _u32]),
     "cap_set_batch_paths": (_i, [_vp, _u64]),
+    "cap_set_traversal": (_i, [_vp, _u32]),
     "cap_render": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "cap_accum_reset": (_i, [_vp]),
     "cap_sync": (_i, [_vp]),
@@ -109,6 +110,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise CapError("native library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % LIB_PATH)
+        # PyTorch-ROCm bundles its own copy of the HIP runtime (same SONAME).  A process must hold exactly one runtime: if torch
+        # is going to be used next to this library (device buffers for the tile gather, torch.distributed), its copy has to be
+        # the one already loaded when libcapsaicin_hip.so resolves libamdhip64.so.7; the other order leaves torch with
+        # "No HIP GPUs are available".  torch is plumbing only; nothing below needs it.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch-less host: the system runtime is used
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
@@ -247,6 +256,10 @@ class Renderer:
 
     def set_shard(self, index, count):
         _check(lib().cap_set_shard(self.ctx, index, count), "cap_set_shard")
+
+    def set_traversal(self, mode):
+        """0 auto, 1 LBVH + LDS stack, 2 exhaustive (small scenes)."""
+        _check(lib().cap_set_traversal(self.ctx, mode), "cap_set_traversal")
 
     def set_batch_paths(self, n):
         _check(lib().cap_set_batch_paths(self.ctx, n), "cap_set_batch_paths")

@@ -44,9 +44,11 @@ __global__ __launch_bounds__(kBlock) void k_tri_setup(BvhBuildArgs a)
         const v3 p0 = mk3(P[3 * i0], P[3 * i0 + 1], P[3 * i0 + 2]), p1 = mk3(P[3 * i1], P[3 * i1 + 1], P[3 * i1 + 2]),
                  p2 = mk3(P[3 * i2], P[3 * i2 + 1], P[3 * i2 + 2]);
         const v3 e1 = p1 - p0, e2 = p2 - p0;
-        a.tri_raw[3 * (size_t)g + 0] = make_float4(p0.x, p0.y, p0.z, e1.x);
-        a.tri_raw[3 * (size_t)g + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-        a.tri_raw[3 * (size_t)g + 2] = make_float4(e2.z, u2f(g), 0.f, 0.f);
+        const v3 n = cross3(e1, e2);  // plane normal of the intersection contract, evaluated once per triangle
+        a.tri_raw[4 * (size_t)g + 0] = make_float4(p0.x, p0.y, p0.z, e1.x);
+        a.tri_raw[4 * (size_t)g + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        a.tri_raw[4 * (size_t)g + 2] = make_float4(e2.z, n.x, n.y, n.z);
+        a.tri_raw[4 * (size_t)g + 3] = make_float4(u2f(g), 0.f, 0.f, 0.f);
         float4* st = a.shade_tris + 6 * (size_t)g;
         st[0] = make_float4(p0.x, p0.y, p0.z, T[2 * i0]);
         st[1] = make_float4(p1.x, p1.y, p1.z, T[2 * i0 + 1]);
@@ -247,9 +249,10 @@ __global__ __launch_bounds__(kBlock) void k_refit(BvhBuildArgs a, const uint32_t
     if (i >= n) return;
     const uint32_t g = vals_sorted[i];
     a.leaf_tri[i]    = g;
-    a.tris_sorted[3 * (size_t)i + 0] = a.tri_raw[3 * (size_t)g + 0];
-    a.tris_sorted[3 * (size_t)i + 1] = a.tri_raw[3 * (size_t)g + 1];
-    a.tris_sorted[3 * (size_t)i + 2] = a.tri_raw[3 * (size_t)g + 2];
+    a.tris_sorted[4 * (size_t)i + 0] = a.tri_raw[4 * (size_t)g + 0];
+    a.tris_sorted[4 * (size_t)i + 1] = a.tri_raw[4 * (size_t)g + 1];
+    a.tris_sorted[4 * (size_t)i + 2] = a.tri_raw[4 * (size_t)g + 2];
+    a.tris_sorted[4 * (size_t)i + 3] = a.tri_raw[4 * (size_t)g + 3];
     if (n < 2) return;
     const float4 blo = tri_box[2 * (size_t)g], bhi = tri_box[2 * (size_t)g + 1];
     float        lo[3] = {blo.x, blo.y, blo.z}, hi[3] = {bhi.x, bhi.y, bhi.z};
@@ -307,9 +310,9 @@ void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
     const uint32_t blocks = (n + kBlock - 1) / kBlock;
     // bounds = (+inf, +inf, +inf, -inf, -inf, -inf) in the ordered encoding; flags, depth = 0
     const uint32_t init[6] = {0xFF800000u, 0xFF800000u, 0xFF800000u, 0x007FFFFFu, 0x007FFFFFu, 0x007FFFFFu};
-    hipMemcpyAsync(a.bounds, init, sizeof(init), hipMemcpyHostToDevice, stream);
-    hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * n, stream);
-    hipMemsetAsync(a.max_depth, 0, sizeof(uint32_t), stream);
+    (void)hipMemcpyAsync(a.bounds, init, sizeof(init), hipMemcpyHostToDevice, stream);
+    (void)hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * n, stream);
+    (void)hipMemsetAsync(a.max_depth, 0, sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_tri_setup, dim3(blocks), dim3(kBlock), 0, stream, a);
     const uint32_t* sorted_keys = a.keys[0];
     const uint32_t* sorted_vals = a.vals[0];
@@ -333,7 +336,7 @@ void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
     else
     {
         const uint32_t zero = 0;
-        hipMemcpyAsync(a.vals[0], &zero, sizeof(zero), hipMemcpyHostToDevice, stream);
+        (void)hipMemcpyAsync(a.vals[0], &zero, sizeof(zero), hipMemcpyHostToDevice, stream);
     }
     hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(kBlock), 0, stream, a, sorted_vals);
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(kBlock), 0, stream, a.parent, n, a.max_depth);

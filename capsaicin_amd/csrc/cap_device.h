@@ -15,12 +15,19 @@ constexpr uint32_t kPidShift   = 26;   // path id = (frame slot << 26) | local p
 constexpr uint32_t kPidMask    = (1u << kPidShift) - 1u;
 constexpr uint32_t kMaxFrameSlots = 64;
 constexpr uint32_t kBlock      = 256;  // threads per workgroup (4 waves, one per SIMD)
+// Queue classes.  A device-scope atomic on ONE word saturates near 88 ops/us on MI355X (MI355X_MICROARCH.md "dequeue"),
+// far below what one append per wave needs, so every queue is split into kQueueClasses independent sub-queues, each with
+// its own counter on its own 128-byte line.  A path's class is fixed at bounce 0 (64-path chunk index mod kQueueClasses)
+// and never changes, so sub-queue k can never hold more than the class-k paths: static capacity, no overflow handling.
+constexpr uint32_t kQueueClasses  = 64;
+constexpr uint32_t kCounterStride = 32;  // uint32 words between two class counters (128 B)
+constexpr uint32_t kExhaustiveMax = 64;  // scenes up to this many triangles are traced exhaustively (kernels.hip)
 
 // BVH node, 64 B = 4 x float4 (both children's boxes live in the parent, one fetch tests both):
 //   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
 //   q3 = (child0, child1, -, -) as int bits; child >= 0: internal node index, child < 0: ~leaf (sorted triangle) index
-// Intersection triangle, 48 B = 3 x float4, in leaf order:
-//   t0 = (v0.x v0.y v0.z e1.x)  t1 = (e1.y e1.z e2.x e2.y)  t2 = (e2.z, asfloat(global triangle id), -, -)
+// Intersection triangle, 64 B = 4 x float4, in leaf order (n = cross(e1, e2)):
+//   t0 = (v0.x v0.y v0.z e1.x)  t1 = (e1.y e1.z e2.x e2.y)  t2 = (e2.z n.x n.y n.z)  t3 = (asfloat(global triangle id), -, -, -)
 // Shading triangle, 96 B = 6 x float4, in global triangle order (mesh order, then primitive order):
 //   s0 = (p0, uv0.x) s1 = (p1, uv0.y) s2 = (p2, uv1.x) s3 = (n0, uv1.y) s4 = (n1, uv2.x) s5 = (n2, uv2.y)
 struct BvhDev
@@ -80,12 +87,14 @@ __device__ __forceinline__ bool local_pixel_to_xy(const ScreenDev& sc, uint32_t 
 }
 
 // Wavefront queues, all SoA planes of float4 (16 B per lane per access, 1 KiB per wave instruction).
+// Sub-queue k occupies entries [k * class_capacity, (k + 1) * class_capacity) and is counted by count[k * kCounterStride].
 struct RayQueue
 {
     float4*   org_tmin;  // (o.xyz, tmin)
     float4*   dir_tmax;  // (d.xyz, tmax)
     float4*   thr_pid;   // (throughput.xyz, asfloat(path id))
-    uint32_t* count;     // device counter
+    uint32_t* count;     // kQueueClasses device counters, kCounterStride apart
+    uint32_t  class_capacity;  // entries per class, a multiple of 64
 };
 struct ShadowQueue
 {
@@ -93,7 +102,21 @@ struct ShadowQueue
     float4*   dir_tmax;
     float4*   contrib_pid;  // (radiance added when unoccluded .xyz, asfloat(path id))
     uint32_t* count;
+    uint32_t  class_capacity;
 };
+
+// Consumers walk "chunk slots": slot cs = j * kQueueClasses + k is the j-th 64-entry chunk of class k (class-minor order, so
+// the occupied slots of all classes come first and spread evenly over the waves of the persistent grid).
+__device__ __forceinline__ bool queue_chunk(const uint32_t* count, uint32_t class_capacity, uint32_t cs, uint32_t lane, uint32_t& index,
+                                            uint32_t& klass)
+{
+    klass                = cs % kQueueClasses;
+    const uint32_t j     = cs / kQueueClasses;
+    const uint32_t n     = count[klass * kCounterStride];
+    const uint32_t local = j * 64u + lane;
+    index                = klass * class_capacity + local;
+    return local < n;
+}
 
 struct SceneDev
 {

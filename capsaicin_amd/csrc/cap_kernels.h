@@ -67,11 +67,11 @@ struct BvhBuildArgs
     uint32_t        tri_count;
     // outputs
     float4*         shade_tris;     // 6 per triangle, global order
-    float4*         tris_sorted;    // 3 per triangle, leaf order
+    float4*         tris_sorted;    // 4 per triangle, leaf order
     float4*         nodes;          // 4 per internal node
     uint32_t*       leaf_tri;       // global triangle id per leaf
     // scratch
-    float4*         tri_raw;        // 3 per triangle, global order
+    float4*         tri_raw;        // 4 per triangle, global order
     float4*         tri_box;        // 2 per triangle (lo, hi), global order
     uint32_t*       keys[2];
     uint32_t*       vals[2];

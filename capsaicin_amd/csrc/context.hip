@@ -44,6 +44,19 @@ struct DevBuf
 {
     T*     p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept
+    {
+        if (this != &o)
+        {
+            release();
+            p = o.p, n = o.n, o.p = nullptr, o.n = 0;
+        }
+        return *this;
+    }
     ~DevBuf() { release(); }
     void release()
     {
@@ -114,6 +127,7 @@ struct CapContext
     bool          camera_ready = false;
     ScreenDev     screen{};
     uint64_t      max_batch_paths = 0;
+    uint32_t      traversal_mode  = CAP_TRAVERSAL_AUTO;
 
     // wavefront state
     DevBuf<float4>     hits, q_org[2], q_dir[2], q_thr[2], s_org, s_dir, s_con, pl_color, pl_direct, pl_albedo, aov_geo, aov_nd,
@@ -168,11 +182,13 @@ int sync_and_collect(CapContext* c)
     for (auto& pc : c->pending)
     {
         const uint32_t D = pc.second;
+        const size_t per = (size_t)kQueueClasses * kCounterStride;
         for (uint32_t b = 0; b <= D; ++b)
-        {
-            c->stats.rays_extension += pc.first[b];
-            c->stats.rays_shadow += pc.first[(D + 1) + b];
-        }
+            for (uint32_t k = 0; k < kQueueClasses; ++k)
+            {
+                c->stats.rays_extension += pc.first[b * per + k * kCounterStride];
+                c->stats.rays_shadow += pc.first[((D + 1) + b) * per + k * kCounterStride];
+            }
         c->pinned_pool.push_back(pc.first);
     }
     c->pending.clear();
@@ -287,7 +303,8 @@ SceneDev scene_dev(const CapContext* c)
 
 int ensure_wavefront(CapContext* c, uint32_t slots, uint32_t bounces)
 {
-    const size_t np = (size_t)slots * c->screen.pixels_padded;
+    const size_t planes_np = (size_t)slots * c->screen.pixels_padded;
+    const size_t np        = planes_np + (size_t)kQueueClasses * 64;  // queue regions round up to whole chunks per class
     HIP_TRY(c->hits.ensure(np));
     for (int k = 0; k < 2; ++k)
     {
@@ -298,12 +315,12 @@ int ensure_wavefront(CapContext* c, uint32_t slots, uint32_t bounces)
     HIP_TRY(c->s_org.ensure(np));
     HIP_TRY(c->s_dir.ensure(np));
     HIP_TRY(c->s_con.ensure(np));
-    HIP_TRY(c->pl_color.ensure(np));
-    HIP_TRY(c->pl_direct.ensure(np));
-    HIP_TRY(c->pl_albedo.ensure(np));
+    HIP_TRY(c->pl_color.ensure(planes_np));
+    HIP_TRY(c->pl_direct.ensure(planes_np));
+    HIP_TRY(c->pl_albedo.ensure(planes_np));
     HIP_TRY(c->aov_geo.ensure(c->screen.pixels_padded));
     HIP_TRY(c->aov_nd.ensure(c->screen.pixels_padded));
-    HIP_TRY(c->counters.ensure(2 * (size_t)(bounces + 1)));
+    HIP_TRY(c->counters.ensure(2 * (size_t)(bounces + 1) * kQueueClasses * kCounterStride));
     if (!c->shaded_counter.p)
     {
         HIP_TRY(c->shaded_counter.ensure(1));
@@ -495,8 +512,8 @@ int cap_bvh_build(CapContext* c)
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t n = c->tri_count;
     HIP_TRY(c->shade_tris.ensure(6 * (size_t)n));
-    HIP_TRY(c->tris_sorted.ensure(3 * (size_t)n));
-    HIP_TRY(c->tri_raw.ensure(3 * (size_t)n));
+    HIP_TRY(c->tris_sorted.ensure(4 * (size_t)n));
+    HIP_TRY(c->tri_raw.ensure(4 * (size_t)n));
     HIP_TRY(c->tri_box.ensure(2 * (size_t)n));
     HIP_TRY(c->nodes.ensure(4 * (size_t)(n > 1 ? n - 1 : 1)));
     HIP_TRY(c->leaf_tri.ensure(n));
@@ -608,6 +625,14 @@ int cap_set_batch_paths(CapContext* c, uint64_t max_paths)
     return CAP_OK;
 }
 
+int cap_set_traversal(CapContext* c, uint32_t mode)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_traversal: ctx is NULL");
+    if (mode > CAP_TRAVERSAL_EXHAUSTIVE) return fail(CAP_ERR_INVALID_ARG, "cap_set_traversal: unknown mode %u", mode);
+    c->traversal_mode = mode;
+    return CAP_OK;
+}
+
 int cap_accum_reset(CapContext* c)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_accum_reset: ctx is NULL");
@@ -630,7 +655,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_render: call cap_bvh_build first");
     if (!c->camera_ready || !c->bluenoise_ready || !c->screen.width) return fail(CAP_ERR_STATE, "cap_render: camera, blue noise and resolution must be set");
     if (flags & CAP_RENDER_EXT_MATERIALS) return fail(CAP_ERR_UNSUPPORTED, "cap_render: EXT materials are not available in this build");
-    if (num_bounces > 1024) return fail(CAP_ERR_INVALID_ARG, "cap_render: num_bounces too large");
+    if (num_bounces > 255) return fail(CAP_ERR_INVALID_ARG, "cap_render: num_bounces %u exceeds 255", num_bounces);
     if (!n_frames) return CAP_OK;
     HIP_TRY(hipSetDevice(c->device));
 
@@ -657,7 +682,15 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         c->textures_dirty = false;
     }
 
-    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, c->bvh_info.stack_entries};
+    uint32_t stack_entries = c->bvh_info.stack_entries;
+    if (c->traversal_mode == CAP_TRAVERSAL_EXHAUSTIVE)
+    {
+        if (c->tri_count > 4096) return fail(CAP_ERR_UNSUPPORTED, "cap_render: exhaustive traversal refused for %u triangles", c->tri_count);
+        stack_entries = 0;
+    }
+    else if (c->traversal_mode == CAP_TRAVERSAL_AUTO && c->tri_count <= kExhaustiveMax)
+        stack_entries = 0;
+    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, stack_entries};
     const BvhDev    bvh   = bvh_dev(c);
     const SceneDev  scene = scene_dev(c);
     const CameraDev cam   = camera_dev(c->camera);
@@ -668,9 +701,13 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     {
         const uint32_t ns = std::min(slots, n_frames - done);
         const FrameConst* frames = c->frames.p + done;
-        HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * 2 * (D + 1), c->stream));
+        const size_t   per_queue     = (size_t)kQueueClasses * kCounterStride;  // counter words of one queue
+        const size_t   counter_words = 2 * (size_t)(D + 1) * per_queue;
+        HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * counter_words, c->stream));
         uint32_t*      ext_count = c->counters.p;
-        uint32_t*      sh_count  = c->counters.p + (D + 1);
+        uint32_t*      sh_count  = c->counters.p + (D + 1) * per_queue;
+        const uint32_t total_chunks   = ns * (Ppad >> 6);
+        const uint32_t class_capacity = ((total_chunks + kQueueClasses - 1) / kQueueClasses) * 64u;
         const bool     last_batch = done + ns >= n_frames;
         const uint32_t aov_slot   = ((flags & CAP_RENDER_AOV) && last_batch) ? ns - 1 : ~0u;
         const uint32_t max_count  = ns * Ppad;
@@ -689,9 +726,9 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         {
             const int pi = (int)(b & 1u), po = pi ^ 1;
             sa.bounce    = b;
-            sa.in        = RayQueue{c->q_org[pi].p, c->q_dir[pi].p, c->q_thr[pi].p, b ? ext_count + (b - 1) : nullptr};
-            sa.out       = RayQueue{c->q_org[po].p, c->q_dir[po].p, c->q_thr[po].p, ext_count + b};
-            sa.shadow    = ShadowQueue{c->s_org.p, c->s_dir.p, c->s_con.p, sh_count + b};
+            sa.in        = RayQueue{c->q_org[pi].p, c->q_dir[pi].p, c->q_thr[pi].p, b ? ext_count + (b - 1) * per_queue : nullptr, class_capacity};
+            sa.out       = RayQueue{c->q_org[po].p, c->q_dir[po].p, c->q_thr[po].p, ext_count + b * per_queue, class_capacity};
+            sa.shadow    = ShadowQueue{c->s_org.p, c->s_dir.p, c->s_con.p, sh_count + b * per_queue, class_capacity};
             {
                 StageTimer t(c, ST_SHADE, st);
                 launch_shade(cfg, sa);
@@ -721,8 +758,8 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             c->pinned_pool.pop_back();
         }
         else
-            HIP_TRY(hipHostMalloc((void**)&pinned, sizeof(uint32_t) * 2 * 1025, hipHostMallocDefault));
-        HIP_TRY(hipMemcpyAsync(pinned, c->counters.p, sizeof(uint32_t) * 2 * (D + 1), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipHostMalloc((void**)&pinned, sizeof(uint32_t) * 2 * 256 * kQueueClasses * kCounterStride, hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(pinned, c->counters.p, sizeof(uint32_t) * counter_words, hipMemcpyDeviceToHost, c->stream));
         c->pending.push_back({pinned, D});
         HIP_TRY(hipGetLastError());
 

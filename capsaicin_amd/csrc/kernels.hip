@@ -40,27 +40,27 @@ __device__ __forceinline__ bool slab(const Ray& r, float lox, float loy, float l
     return tn <= tf * 1.0000004f;
 }
 
-// Two-sided Moller-Trumbore in the determinant-scaled domain; one division per accepted candidate.
-// Hit rule: tmin < t < tmax (DXR triangle rule); barycentrics weight v1, v2 (scene.h:46-49).
+// Ray / triangle test of the intersection contract: two-sided Moller-Trumbore in the determinant-scaled
+// domain, regrouped around the per-triangle plane normal n = e1 x e2 and q = tvec x d:
+//   det = e1.(d x e2) = -d.n    U = tvec.(d x e2) = e2.q    V = d.(tvec x e1) = -e1.q    T = e2.(tvec x e1) = tvec.n
+// Hit rule: det != 0, U, V >= 0, U + V <= |det|, tmin < T/det < tmax (DXR triangle rule); barycentrics weight v1, v2
+// (scene.h:46-49).  Written without branches: on this machine the scalar unit is shared by the four SIMDs of a CU, and the
+// exec-mask bookkeeping of a branchy test costs more scalar issue slots than the vector work it skips.
 __device__ __forceinline__ bool tri_test(const Ray& r, const float4 t0, const float4 t1, const float4 t2, float& t, float& u, float& v)
 {
-    const v3    v0 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x);
-    const v3    pvec = cross3(r.d, e2);
-    float       det  = dot3(e1, pvec);
-    const v3    tvec = r.o - v0;
-    const v3    qvec = cross3(tvec, e1);
-    float       U = dot3(tvec, pvec), V = dot3(r.d, qvec), T = dot3(e2, qvec);
-    if (det < 0.0f)
-    {
-        U = -U, V = -V, T = -T, det = -det;
-    }
-    if (!(det > 0.0f)) return false;
-    if (!(U >= 0.0f && V >= 0.0f && U + V <= det)) return false;
-    const float inv = 1.0f / det;
-    const float tt  = T * inv;
-    if (!(tt > r.tmin && tt < r.tmax)) return false;
+    const v3 v0 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x), n = mk3(t2.y, t2.z, t2.w);
+    const v3 tvec = r.o - v0;
+    const v3 q    = cross3(tvec, r.d);
+    float    det  = -dot3(r.d, n);
+    float    U = dot3(e2, q), V = -dot3(e1, q), T = dot3(tvec, n);
+    // two-sided: when det < 0 every sign flips (exact, so a sign-bit xor)
+    const uint32_t sgn = f2u(det) & 0x80000000u;
+    det = u2f(f2u(det) ^ sgn), U = u2f(f2u(U) ^ sgn), V = u2f(f2u(V) ^ sgn), T = u2f(f2u(T) ^ sgn);
+    const bool  inside = (det > 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= det);
+    const float inv    = 1.0f / det;
+    const float tt     = T * inv;
     t = tt, u = U * inv, v = V * inv;
-    return true;
+    return inside & (tt > r.tmin) & (tt < r.tmax);
 }
 
 // Closest hit: minimum t, equal t resolved towards the lower global triangle id (visit-order independent).
@@ -99,11 +99,11 @@ __device__ __forceinline__ void traverse_closest(const BvhDev& bvh, const Ray& r
         else
         {
             const uint32_t leaf = (uint32_t)~node;
-            const float4   t0 = bvh.tris[3 * leaf + 0], t1 = bvh.tris[3 * leaf + 1], t2 = bvh.tris[3 * leaf + 2];
+            const float4   t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
             float          t, u, v;
             if (tri_test(r, t0, t1, t2, t, u, v))
             {
-                const uint32_t gid = f2u(t2.y);
+                const uint32_t gid = f2u(bvh.tris[4 * leaf + 3].x);
                 if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
             }
         }
@@ -144,7 +144,7 @@ __device__ __forceinline__ bool traverse_any(const BvhDev& bvh, const Ray& r, ui
         else
         {
             const uint32_t leaf = (uint32_t)~node;
-            const float4   t0 = bvh.tris[3 * leaf + 0], t1 = bvh.tris[3 * leaf + 1], t2 = bvh.tris[3 * leaf + 2];
+            const float4   t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
             float          t, u, v;
             if (tri_test(r, t0, t1, t2, t, u, v)) return true;
         }
@@ -152,6 +152,80 @@ __device__ __forceinline__ bool traverse_any(const BvhDev& bvh, const Ray& r, ui
         node = (int)stack[(--sp) * kBlock];
     }
     return false;
+}
+
+// Small scenes (tri_count <= kExhaustiveMax): the hierarchy degenerates to one leaf holding every triangle, tested
+// exhaustively.  The loop counter is wave-uniform, so the triangle records are fetched once per wave through the scalar
+// data cache (s_load) instead of 64 times through the vector path, and no lane ever waits for another lane's traversal:
+// 64-lane SIMD efficiency is 100 % whatever the ray distribution.  Same hit rule, so the same answer as the stack traversal.
+// The triangle array is written once by the BVH build and never during a render, so it may be read through the constant
+// address space: with a wave-uniform index the compiler then emits s_load (scalar data cache, operands in SGPRs).
+struct RawF4
+{
+    float x, y, z, w;
+};
+__device__ __forceinline__ float4 load_const(const float4* base, uint32_t i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const RawF4 ConstF4;
+    const RawF4 v = ((const ConstF4*)base)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return base[i];
+#endif
+}
+
+__device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const Ray& r, float& best_t, float& best_u, float& best_v,
+                                                   uint32_t& best_gid)
+{
+    best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
+    const uint32_t n = bvh.tri_count;
+#pragma unroll 2
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        const float4 t0 = load_const(bvh.tris, 4 * k + 0), t1 = load_const(bvh.tris, 4 * k + 1), t2 = load_const(bvh.tris, 4 * k + 2);
+        const uint32_t gid = f2u(load_const(bvh.tris, 4 * k + 3).x);
+        float        t, u, v;
+        const bool   hit    = tri_test(r, t0, t1, t2, t, u, v);
+        const bool   better = hit & ((t < best_t) | ((t == best_t) & (gid < best_gid)));
+        best_t   = better ? t : best_t;
+        best_u   = better ? u : best_u;
+        best_v   = better ? v : best_v;
+        best_gid = better ? gid : best_gid;
+    }
+}
+
+__device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r)
+{
+    const uint32_t n   = bvh.tri_count;
+    bool           hit = false;
+#pragma unroll 2
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        const float4 t0 = load_const(bvh.tris, 4 * k + 0), t1 = load_const(bvh.tris, 4 * k + 1), t2 = load_const(bvh.tris, 4 * k + 2);
+        float        t, u, v;
+        hit |= tri_test(r, t0, t1, t2, t, u, v);
+    }
+    return hit;
+}
+
+// STACK == 0 selects the exhaustive small-scene path.
+template <int STACK>
+__device__ __forceinline__ void trace_closest_any_size(const BvhDev& bvh, const Ray& r, uint32_t* stack, float& t, float& u, float& v,
+                                                       uint32_t& gid)
+{
+    if constexpr (STACK == 0)
+        exhaustive_closest(bvh, r, t, u, v, gid);
+    else
+        traverse_closest<STACK>(bvh, r, stack, t, u, v, gid);
+}
+template <int STACK>
+__device__ __forceinline__ bool trace_any_any_size(const BvhDev& bvh, const Ray& r, uint32_t* stack)
+{
+    if constexpr (STACK == 0)
+        return exhaustive_any(bvh, r);
+    else
+        return traverse_any<STACK>(bvh, r, stack);
 }
 
 // Work distribution of the queue kernels: the grid is persistent (fixed size, independent of the device-side
@@ -175,7 +249,7 @@ template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_trace_primary(BvhDev bvh, CameraDev cam, ScreenDev screen, const FrameConst* frames,
                                                           float4* hits)
 {
-    __shared__ uint32_t lds_stack[STACK * kBlock];
+    __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
     uint32_t*           stack  = lds_stack + threadIdx.x;
     const uint32_t      slot   = blockIdx.y;
     const FrameConst    fc     = frames[slot];
@@ -190,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(BvhDev bvh, CameraDev 
         {
             const Ray r = make_ray(mk3(cam.position[0], cam.position[1], cam.position[2]), primary_dir(cam, screen, fc, x, y), 0.0f,
                                    kPrimaryFar);
-            traverse_closest<STACK>(bvh, r, stack, t, u, v, gid);
+            trace_closest_any_size<STACK>(bvh, r, stack, t, u, v, gid);
         }
         hits[(size_t)slot * screen.pixels_padded + pl] = make_float4(u, v, u2f(gid), t);
     }
@@ -199,20 +273,19 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(BvhDev bvh, CameraDev 
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_trace_closest(BvhDev bvh, RayQueue q, float4* hits)
 {
-    __shared__ uint32_t lds_stack[STACK * kBlock];
+    __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
     uint32_t*           stack  = lds_stack + threadIdx.x;
-    const uint32_t      count  = *q.count;
-    const uint32_t      chunks = (count + 63u) >> 6;
-    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
+    const uint32_t      slots  = (q.class_capacity >> 6) * kQueueClasses;
+    for (uint32_t cs = wave_global_id(); cs < slots; cs += wave_total())
     {
-        const uint32_t i = chunk * 64 + (threadIdx.x & 63u);
-        if (i < count)
+        uint32_t i, klass;
+        if (queue_chunk(q.count, q.class_capacity, cs, threadIdx.x & 63u, i, klass))
         {
             const float4 a = q.org_tmin[i], b = q.dir_tmax[i];
             const Ray    r = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
             float        t, u, v;
             uint32_t     gid;
-            traverse_closest<STACK>(bvh, r, stack, t, u, v, gid);
+            trace_closest_any_size<STACK>(bvh, r, stack, t, u, v, gid);
             hits[i] = make_float4(u, v, u2f(gid), t);
         }
     }
@@ -221,18 +294,17 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(BvhDev bvh, RayQueue q
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded)
 {
-    __shared__ uint32_t lds_stack[STACK * kBlock];
+    __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
     uint32_t*           stack  = lds_stack + threadIdx.x;
-    const uint32_t      count  = *q.count;
-    const uint32_t      chunks = (count + 63u) >> 6;
-    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
+    const uint32_t      slots  = (q.class_capacity >> 6) * kQueueClasses;
+    for (uint32_t cs = wave_global_id(); cs < slots; cs += wave_total())
     {
-        const uint32_t i = chunk * 64 + (threadIdx.x & 63u);
-        if (i < count)
+        uint32_t i, klass;
+        if (queue_chunk(q.count, q.class_capacity, cs, threadIdx.x & 63u, i, klass))
         {
             const float4 a = q.org_tmin[i], b = q.dir_tmax[i];
             const Ray    r = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
-            if (!traverse_any<STACK>(bvh, r, stack))
+            if (!trace_any_any_size<STACK>(bvh, r, stack))
             {
                 // lighting.h:57-60: unoccluded -> the contribution evaluated at shading time is added.  One shadow ray
                 // per path per bounce, so the read-modify-write needs no atomic.
@@ -255,7 +327,9 @@ void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraD
     if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
     if (gx == 0) gx = 1;
     dim3 grid(gx, n_slots);
-    if (cfg.stack_entries <= 32)
+    if (cfg.stack_entries == 0)
+        hipLaunchKernelGGL(k_trace_primary<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, cam, screen, frames, hits);
+    else if (cfg.stack_entries <= 32)
         hipLaunchKernelGGL(k_trace_primary<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, cam, screen, frames, hits);
     else
         hipLaunchKernelGGL(k_trace_primary<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, cam, screen, frames, hits);
@@ -271,7 +345,9 @@ static uint32_t queue_grid(const LaunchCfg& cfg, uint32_t max_count)
 void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits)
 {
     dim3 grid(queue_grid(cfg, max_count));
-    if (cfg.stack_entries <= 32)
+    if (cfg.stack_entries == 0)
+        hipLaunchKernelGGL(k_trace_closest<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
+    else if (cfg.stack_entries <= 32)
         hipLaunchKernelGGL(k_trace_closest<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
     else
         hipLaunchKernelGGL(k_trace_closest<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
@@ -281,7 +357,9 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
                       uint32_t pixels_padded)
 {
     dim3 grid(queue_grid(cfg, max_count));
-    if (cfg.stack_entries <= 32)
+    if (cfg.stack_entries == 0)
+        hipLaunchKernelGGL(k_trace_any<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded);
+    else if (cfg.stack_entries <= 32)
         hipLaunchKernelGGL(k_trace_any<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded);
     else
         hipLaunchKernelGGL(k_trace_any<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded);
@@ -389,22 +467,21 @@ template <bool FIRST>
 __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
 {
     const uint32_t Ppad = a.screen.pixels_padded;
-    uint32_t       count, chunks;
-    if (FIRST)
-    {
-        count  = Ppad;  // identity queue: item i of slot blockIdx.y is local pixel i
-        chunks = Ppad >> 6;
-    }
-    else
-    {
-        count  = *a.in.count;
-        chunks = (count + 63u) >> 6;
-    }
-    uint32_t n_shaded = 0;
+    // FIRST: identity queue, item i of frame slot blockIdx.y is local pixel i.  Otherwise: chunk slots of the input queue.
+    const uint32_t chunks   = FIRST ? (Ppad >> 6) : (a.in.class_capacity >> 6) * kQueueClasses;
+    uint32_t       n_shaded = 0;
     for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
     {
-        const uint32_t i      = chunk * 64 + (threadIdx.x & 63u);
-        const bool     active = i < count;
+        uint32_t i, klass;
+        bool     active;
+        if (FIRST)
+        {
+            i      = chunk * 64 + (threadIdx.x & 63u);
+            active = true;
+            klass  = (blockIdx.y * (Ppad >> 6) + chunk) % kQueueClasses;  // the path's class for its whole life
+        }
+        else
+            active = queue_chunk(a.in.count, a.in.class_capacity, chunk, threadIdx.x & 63u, i, klass);
         uint32_t       pid = 0, slot = 0, pl = 0;
         float4         hit = make_float4(0.f, 0.f, u2f(kInvalidId), 0.f);
         v3             thr = mk3(1.0f, 1.0f, 1.0f);
@@ -524,7 +601,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
             }
         }
 
-        const uint32_t si = wave_append(emit_shadow, a.shadow.count);
+        const uint32_t si = klass * a.shadow.class_capacity + wave_append(emit_shadow, a.shadow.count + klass * kCounterStride);
         if (emit_shadow)
         {
             const FrameConst& f = fc;
@@ -532,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
             a.shadow.dir_tmax[si]    = make_float4(f.light_dir[0], f.light_dir[1], f.light_dir[2], kRayFar);
             a.shadow.contrib_pid[si] = make_float4(contrib.x, contrib.y, contrib.z, u2f(pid));
         }
-        const uint32_t ei = wave_append(emit_ext, a.out.count);
+        const uint32_t ei = klass * a.out.class_capacity + wave_append(emit_ext, a.out.count + klass * kCounterStride);
         if (emit_ext)
         {
             a.out.org_tmin[ei] = make_float4(p.x, p.y, p.z, kRayEps);

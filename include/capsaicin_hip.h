@@ -157,6 +157,15 @@ int cap_set_resolution(CapContext* ctx, uint32_t width, uint32_t height);
 int cap_set_shard(CapContext* ctx, uint32_t shard_index, uint32_t shard_count);
 /* Upper bound of (frame, pixel) paths kept in flight per batch (0 = default). */
 int cap_set_batch_paths(CapContext* ctx, uint64_t max_paths);
+/* Traversal strategy of the trace kernels (same hits either way): AUTO picks EXHAUSTIVE for scenes of at most 64
+ * triangles (wave-uniform test of every triangle, no stack) and STACK (LBVH + per-lane LDS stack) otherwise. */
+typedef enum CapTraversal
+{
+    CAP_TRAVERSAL_AUTO       = 0,
+    CAP_TRAVERSAL_STACK      = 1,
+    CAP_TRAVERSAL_EXHAUSTIVE = 2 /* refused above 4096 triangles */
+} CapTraversal;
+int cap_set_traversal(CapContext* ctx, uint32_t mode);
 
 /* RaytracingSystem::Run ray passes (raytracing_system.cpp:266-292) for frame_count = frame_begin ..
  * frame_begin + n_frames - 1, each frame's COMBINED added to the accumulation buffer in frame order.

@@ -255,12 +255,13 @@ void oct_encode(f3 n, float out[2])
 
 // ---------------------------------------------------------------------------------------------
 // Ray / triangle intersection (replaces the DXR fixed-function unit; contract in DESIGN.md):
-// two-sided Moller-Trumbore evaluated in the determinant-scaled domain, one division per accepted
-// candidate; a hit needs tmin < t < tmax (DXR triangle rule); barycentrics (u,v) weight v1, v2.
+// two-sided Moller-Trumbore evaluated in the determinant-scaled domain around a per-triangle plane
+// normal, one division per accepted candidate; a hit needs tmin < t < tmax (DXR triangle rule);
+// barycentrics (u,v) weight v1, v2.
 // ---------------------------------------------------------------------------------------------
 struct Tri
 {
-    f3       v0, e1, e2;
+    f3       v0, e1, e2, n;  // n = cross(e1, e2), evaluated once per triangle
     uint32_t inst, prim;
 };
 struct Hit
@@ -271,11 +272,12 @@ struct Hit
 
 inline bool intersect_tri(f3 o, f3 d, const Tri& tr, float tmin, float tmax, float* t, float* u, float* v)
 {
-    f3    pvec = cross(d, tr.e2);
-    float det  = dot(tr.e1, pvec);
+    // scalar triple products of Moller-Trumbore regrouped around the precomputed plane normal n = e1 x e2 and
+    // q = tvec x d:  det = e1.(d x e2) = -d.n,  U = tvec.(d x e2) = e2.q,  V = d.(tvec x e1) = -e1.q,  T = e2.(tvec x e1) = tvec.n
     f3    tvec = o - tr.v0;
-    f3    qvec = cross(tvec, tr.e1);
-    float U = dot(tvec, pvec), V = dot(d, qvec), T = dot(tr.e2, qvec);
+    f3    q    = cross(tvec, d);
+    float det  = -dot(d, tr.n);
+    float U = dot(tr.e2, q), V = -dot(tr.e1, q), T = dot(tvec, tr.n);
     if (det < 0.0f)
     {
         U = -U, V = -V, T = -T, det = -det;
@@ -704,7 +706,8 @@ void* oracle_scene_create(const OracleScene* s)
                 uint32_t vi = mesh.first_vertex_offset + sc->indices[mesh.first_index_offset + k + j];
                 v[j]        = make3(sc->positions[3 * vi], sc->positions[3 * vi + 1], sc->positions[3 * vi + 2]);
             }
-            sc->tris.push_back(Tri{v[0], v[1] - v[0], v[2] - v[0], mesh.index, k / 3});
+            f3 e1 = v[1] - v[0], e2 = v[2] - v[0];
+            sc->tris.push_back(Tri{v[0], e1, e2, cross(e1, e2), mesh.index, k / 3});
         }
     }
     build_bvh(*sc);
@@ -783,7 +786,7 @@ int   oracle_intersect_triangle(const float o[3], const float d[3], float tmin, 
                                 const float v1[3], const float v2[3], float* t, float* u, float* v)
 {
     f3  a = make3(v0[0], v0[1], v0[2]), b = make3(v1[0], v1[1], v1[2]), c = make3(v2[0], v2[1], v2[2]);
-    Tri tr{a, b - a, c - a, 0, 0};
+    Tri tr{a, b - a, c - a, cross(b - a, c - a), 0, 0};
     return intersect_tri(make3(o[0], o[1], o[2]), make3(d[0], d[1], d[2]), tr, tmin, tmax, t, u, v) ? 1 : 0;
 }
 void oracle_sample_texture(const OracleTexture* tex, float u, float v, float out[3]) { sample_texture(*tex, u, v, out); }

@@ -11,6 +11,16 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+def assert_same(got, ref, name):
+    g, r = bits(got), bits(ref)
+    if not np.array_equal(g, r):
+        bad = np.argwhere((g != r).any(-1))
+        msg = ["%s: %d pixels differ" % (name, len(bad))]
+        for b in bad[:6]:
+            msg.append("  (y,x)=%s gpu=%s oracle=%s" % (tuple(b), got[tuple(b)], ref[tuple(b)]))
+        raise AssertionError("\n".join(msg))
+
+
 def soup(seed, ntri, spread=2.0, size=0.8):
     rs = np.random.RandomState(seed)
     c = rs.rand(ntri, 1, 3) * 2 * spread - spread
@@ -125,7 +135,7 @@ def test_triangle_soup_parity(native_lib, bluenoise, seed, ntri, w, h, D):
     for name, kind in (("gbuffer_geo", capi.BUF_GBUFFER_GEO), ("direct", capi.BUF_DIRECT), ("indirect", capi.BUF_INDIRECT),
                        ("normal_depth", capi.BUF_NORMAL_DEPTH), ("combined", capi.BUF_COMBINED)):
         got = r.readback(kind)
-        assert np.array_equal(bits(got), bits(ref[name])), "%s: %d pixels differ" % (name, int((bits(got) != bits(ref[name])).any(-1).sum()))
+        assert_same(got, ref[name], name)
     s = r.stats()
     assert (s.rays_primary, s.rays_extension, s.rays_shadow) == ref["rays"]
     r.close()
@@ -184,9 +194,10 @@ def test_textured_quad_parity(native_lib, bluenoise):
     sc = O.Scene(pos, nrm, uv, idx, meshes, textures=[tex0, tex1])
     ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1], cam.focal_length)
     ref = sc.render_frame(ocam, bluenoise, w, h, 9, D)
-    for name, kind in (("albedo", capi.BUF_ALBEDO), ("direct", capi.BUF_DIRECT), ("indirect", capi.BUF_INDIRECT), ("combined", capi.BUF_COMBINED)):
+    for name, kind in (("gbuffer_geo", capi.BUF_GBUFFER_GEO), ("albedo", capi.BUF_ALBEDO), ("direct", capi.BUF_DIRECT), ("indirect", capi.BUF_INDIRECT),
+                       ("combined", capi.BUF_COMBINED)):
         got = r.readback(kind)
-        assert np.array_equal(bits(got), bits(ref[name])), "%s: %d pixels differ" % (name, int((bits(got) != bits(ref[name])).any(-1).sum()))
+        assert_same(got, ref[name], name)
     # a missing texture is a 1x1 zero texel (texture_system.cpp:47-56): albedo 0 everywhere on that mesh
     r.upload_texture(0, None)
     r.render(9, 1, D, capi.RENDER_AOV)
