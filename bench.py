@@ -139,14 +139,27 @@ def main():
         sp = r.stats()
         roofline = None
         if rank == 0 and sp.launches_trace_closest:
+            fused = sp.launches_shade == 0
             avg_ms = sp.ms_trace_closest / sp.launches_trace_closest
-            bytes_per_launch = BYTES_CLOSEST * sp.rays_extension / sp.launches_trace_closest
+            if fused:
+                # k_trace_shade (bounce >= 1): reads one 48-B queue entry (ray 32 + throughput/path id 16) per extension ray,
+                # writes one 48-B extension entry and one 48-B shadow entry per ray it emits (DESIGN.md "algorithmic bytes")
+                ext_out = sp.rays_extension - sp.rays_extension_bounce0
+                sh_out = sp.rays_shadow - sp.rays_shadow_bounce0
+                kernel_bytes = 48 * sp.rays_extension + 48 * ext_out + 48 * sh_out
+                kernel_name = "k_trace_shade<bounce>=1> (exhaustive closest hit + shading, fused)"
+                all_bytes = kernel_bytes + 48 * (sp.rays_extension_bounce0 + sp.rays_shadow_bounce0) + 48 * sp.rays_primary + \
+                    (48 + 32) * sp.rays_shadow + 48 * sp.rays_primary
+            else:
+                kernel_bytes = BYTES_CLOSEST * sp.rays_extension
+                kernel_name = "k_trace_closest"
+                all_bytes = BYTES_CLOSEST * sp.rays_extension + 16 * sp.rays_primary + BYTES_ANY * sp.rays_shadow + BYTES_VERTEX * sp.shaded_vertices
+            bytes_per_launch = kernel_bytes / sp.launches_trace_closest
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            all_bytes = BYTES_CLOSEST * (sp.rays_extension) + 16 * sp.rays_primary + BYTES_ANY * sp.rays_shadow + BYTES_VERTEX * sp.shaded_vertices
-            roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_ms": avg_ms, "launches": int(sp.launches_trace_closest),
-                        "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_ray": BYTES_CLOSEST,
+                        "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_ray": kernel_bytes / max(1, sp.rays_extension),
                         "rays_per_launch": sp.rays_extension / sp.launches_trace_closest,
                         "kernel_mrays_per_s": sp.rays_extension / (sp.ms_trace_closest * 1e-3) / 1e6,
                         "whole_step_queue_stream_gbs": all_bytes / (sp.ms_total * 1e-3) / 1e9,

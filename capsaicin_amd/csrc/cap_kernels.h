@@ -43,6 +43,8 @@ struct ShadeArgs
     uint64_t*         shaded_counter;
 };
 void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args);
+// small-scene path: exhaustive closest hit fused with the shading of the vertex found (bounce 0 generates the camera rays)
+void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args);
 
 // ---- accumulate / exchange ----
 // accum[pl] += sum over slots (in slot order) of color*albedo + direct; .w counts frames.

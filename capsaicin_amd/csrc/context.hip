@@ -188,6 +188,11 @@ int sync_and_collect(CapContext* c)
             {
                 c->stats.rays_extension += pc.first[b * per + k * kCounterStride];
                 c->stats.rays_shadow += pc.first[((D + 1) + b) * per + k * kCounterStride];
+                if (b == 0)
+                {
+                    c->stats.rays_extension_bounce0 += pc.first[k * kCounterStride];
+                    c->stats.rays_shadow_bounce0 += pc.first[(D + 1) * per + k * kCounterStride];
+                }
             }
         c->pinned_pool.push_back(pc.first);
     }
@@ -712,16 +717,19 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         const uint32_t aov_slot   = ((flags & CAP_RENDER_AOV) && last_batch) ? ns - 1 : ~0u;
         const uint32_t max_count  = ns * Ppad;
 
-        {
-            StageTimer t(c, ST_PRIMARY, st);
-            launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, c->hits.p);
-        }
-        if (aov_slot != ~0u) launch_geo_aov(cfg, scene, c->hits.p + (size_t)aov_slot * Ppad, Ppad, c->aov_geo.p);
-
         ShadeArgs sa{};
         sa.scene = scene, sa.cam = cam, sa.screen = c->screen, sa.frames = frames, sa.hits = c->hits.p;
         sa.planes = Planes{c->pl_color.p, c->pl_direct.p, c->pl_albedo.p, c->aov_geo.p, c->aov_nd.p};
         sa.n_slots = ns, sa.num_bounces = D, sa.max_count = max_count, sa.aov_slot = aov_slot, sa.shaded_counter = c->shaded_counter.p;
+        const bool fused = cfg.stack_entries == 0;  // small-scene path: closest hit and shading in one kernel per bounce
+        if (!fused)
+        {
+            {
+                StageTimer t(c, ST_PRIMARY, st);
+                launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, c->hits.p);
+            }
+            if (aov_slot != ~0u) launch_geo_aov(cfg, scene, c->hits.p + (size_t)aov_slot * Ppad, Ppad, c->aov_geo.p);
+        }
         for (uint32_t b = 0; b <= D; ++b)
         {
             const int pi = (int)(b & 1u), po = pi ^ 1;
@@ -729,6 +737,13 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             sa.in        = RayQueue{c->q_org[pi].p, c->q_dir[pi].p, c->q_thr[pi].p, b ? ext_count + (b - 1) * per_queue : nullptr, class_capacity};
             sa.out       = RayQueue{c->q_org[po].p, c->q_dir[po].p, c->q_thr[po].p, ext_count + b * per_queue, class_capacity};
             sa.shadow    = ShadowQueue{c->s_org.p, c->s_dir.p, c->s_con.p, sh_count + b * per_queue, class_capacity};
+            if (fused)
+            {
+                StageTimer t(c, b == 0 ? ST_PRIMARY : ST_CLOSEST, st);
+                launch_trace_shade(cfg, bvh, sa);
+                if (b) ++c->stats.launches_trace_closest;
+            }
+            else
             {
                 StageTimer t(c, ST_SHADE, st);
                 launch_shade(cfg, sa);
@@ -739,7 +754,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                 launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad);
                 ++c->stats.launches_trace_any;
             }
-            if (b < D)
+            if (!fused && b < D)
             {
                 StageTimer t(c, ST_CLOSEST, st);
                 launch_trace_closest(cfg, bvh, sa.out, max_count, c->hits.p);

@@ -63,6 +63,20 @@ __device__ __forceinline__ bool tri_test(const Ray& r, const float4 t0, const fl
     return inside & (tt > r.tmin) & (tt < r.tmax);
 }
 
+// Occlusion form of the same test (any-hit queries observe only "is there a hit"): the open interval is checked in the scaled
+// domain, tmin*det < T < tmax*det, so the shadow-ray kernels need no division at all.
+__device__ __forceinline__ bool tri_occludes(const Ray& r, const float4 t0, const float4 t1, const float4 t2)
+{
+    const v3 v0 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x), n = mk3(t2.y, t2.z, t2.w);
+    const v3 tvec = r.o - v0;
+    const v3 q    = cross3(tvec, r.d);
+    float    det  = -dot3(r.d, n);
+    float    U = dot3(e2, q), V = -dot3(e1, q), T = dot3(tvec, n);
+    const uint32_t sgn = f2u(det) & 0x80000000u;
+    det = u2f(f2u(det) ^ sgn), U = u2f(f2u(U) ^ sgn), V = u2f(f2u(V) ^ sgn), T = u2f(f2u(T) ^ sgn);
+    return (det > 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= det) & (T > r.tmin * det) & (T < r.tmax * det);
+}
+
 // Closest hit: minimum t, equal t resolved towards the lower global triangle id (visit-order independent).
 // stack: this lane's column of the per-wave LDS stack; entry k lives at stack[k * kBlock].
 template <int STACK>
@@ -145,8 +159,7 @@ __device__ __forceinline__ bool traverse_any(const BvhDev& bvh, const Ray& r, ui
         {
             const uint32_t leaf = (uint32_t)~node;
             const float4   t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
-            float          t, u, v;
-            if (tri_test(r, t0, t1, t2, t, u, v)) return true;
+            if (tri_occludes(r, t0, t1, t2)) return true;
         }
         if (sp == 0) break;
         node = (int)stack[(--sp) * kBlock];
@@ -164,14 +177,22 @@ struct RawF4
 {
     float x, y, z, w;
 };
-__device__ __forceinline__ float4 load_const(const float4* base, uint32_t i)
+struct alignas(64) RawTri
+{
+    RawF4 q[4];
+};
+// One 64-byte triangle record per s_load_dwordx16.
+__device__ __forceinline__ void load_const_tri(const float4* base, uint32_t k, float4& t0, float4& t1, float4& t2, float4& t3)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(4))) const RawF4 ConstF4;
-    const RawF4 v = ((const ConstF4*)base)[i];
-    return make_float4(v.x, v.y, v.z, v.w);
+    typedef __attribute__((address_space(4))) const RawTri ConstTri;
+    const RawTri v = ((const ConstTri*)base)[k];
+    t0 = make_float4(v.q[0].x, v.q[0].y, v.q[0].z, v.q[0].w);
+    t1 = make_float4(v.q[1].x, v.q[1].y, v.q[1].z, v.q[1].w);
+    t2 = make_float4(v.q[2].x, v.q[2].y, v.q[2].z, v.q[2].w);
+    t3 = make_float4(v.q[3].x, v.q[3].y, v.q[3].z, v.q[3].w);
 #else
-    return base[i];
+    t0 = base[4 * k], t1 = base[4 * k + 1], t2 = base[4 * k + 2], t3 = base[4 * k + 3];
 #endif
 }
 
@@ -183,8 +204,9 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const Ray&
 #pragma unroll 2
     for (uint32_t k = 0; k < n; ++k)
     {
-        const float4 t0 = load_const(bvh.tris, 4 * k + 0), t1 = load_const(bvh.tris, 4 * k + 1), t2 = load_const(bvh.tris, 4 * k + 2);
-        const uint32_t gid = f2u(load_const(bvh.tris, 4 * k + 3).x);
+        float4 t0, t1, t2, t3;
+        load_const_tri(bvh.tris, k, t0, t1, t2, t3);
+        const uint32_t gid = f2u(t3.x);
         float        t, u, v;
         const bool   hit    = tri_test(r, t0, t1, t2, t, u, v);
         const bool   better = hit & ((t < best_t) | ((t == best_t) & (gid < best_gid)));
@@ -202,9 +224,9 @@ __device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r)
 #pragma unroll 2
     for (uint32_t k = 0; k < n; ++k)
     {
-        const float4 t0 = load_const(bvh.tris, 4 * k + 0), t1 = load_const(bvh.tris, 4 * k + 1), t2 = load_const(bvh.tris, 4 * k + 2);
-        float        t, u, v;
-        hit |= tri_test(r, t0, t1, t2, t, u, v);
+        float4 t0, t1, t2, t3;
+        load_const_tri(bvh.tris, k, t0, t1, t2, t3);
+        hit |= tri_occludes(r, t0, t1, t2);
     }
     return hit;
 }
@@ -463,42 +485,16 @@ __device__ __forceinline__ uint32_t wave_append(bool emit, uint32_t* counter)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// One path vertex: rt_direct_lighting.hlsl:38-83 (bounce 0) / one iteration of the rt_indirect.hlsl:91-174 loop, followed by
+// the 64-lane compaction of the shadow ray and the extension ray into the class-`klass` sub-queues.  Called wave-uniformly
+// (every lane of the wave, active or not) by the stand-alone shade kernel and by the fused trace+shade kernel.
 template <bool FIRST>
-__global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
+__device__ __forceinline__ void shade_vertex(const ShadeArgs& a, bool active, uint32_t klass, uint32_t pid, float4 hit, v3 thr,
+                                             uint32_t& n_shaded)
 {
     const uint32_t Ppad = a.screen.pixels_padded;
-    // FIRST: identity queue, item i of frame slot blockIdx.y is local pixel i.  Otherwise: chunk slots of the input queue.
-    const uint32_t chunks   = FIRST ? (Ppad >> 6) : (a.in.class_capacity >> 6) * kQueueClasses;
-    uint32_t       n_shaded = 0;
-    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
+    const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
     {
-        uint32_t i, klass;
-        bool     active;
-        if (FIRST)
-        {
-            i      = chunk * 64 + (threadIdx.x & 63u);
-            active = true;
-            klass  = (blockIdx.y * (Ppad >> 6) + chunk) % kQueueClasses;  // the path's class for its whole life
-        }
-        else
-            active = queue_chunk(a.in.count, a.in.class_capacity, chunk, threadIdx.x & 63u, i, klass);
-        uint32_t       pid = 0, slot = 0, pl = 0;
-        float4         hit = make_float4(0.f, 0.f, u2f(kInvalidId), 0.f);
-        v3             thr = mk3(1.0f, 1.0f, 1.0f);
-        if (active)
-        {
-            if (FIRST)
-            {
-                slot = blockIdx.y, pl = i, pid = (slot << kPidShift) | pl;
-                hit  = a.hits[(size_t)slot * Ppad + pl];
-            }
-            else
-            {
-                const float4 tp = a.in.thr_pid[i];
-                thr = mk3(tp.x, tp.y, tp.z), pid = f2u(tp.w), slot = pid >> kPidShift, pl = pid & kPidMask;
-                hit = a.hits[i];
-            }
-        }
         const size_t plane_idx = (size_t)slot * Ppad + pl;
         uint32_t     x = 0, y = 0;
         const bool   valid = active && local_pixel_to_xy(a.screen, pl, x, y);
@@ -617,9 +613,55 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
             a.out.thr_pid[ei]  = make_float4(thr.x, thr.y, thr.z, u2f(pid));
         }
     }
-    // statistics: shaded vertices, one atomic per wave
+}
+
+// statistics: shaded vertices, one atomic per wave
+__device__ __forceinline__ void flush_shaded(uint64_t* counter, uint32_t n_shaded)
+{
     for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
-    if ((threadIdx.x & 63u) == 0 && n_shaded) atomicAdd((unsigned long long*)a.shaded_counter, (unsigned long long)n_shaded);
+    if ((threadIdx.x & 63u) == 0 && n_shaded) atomicAdd((unsigned long long*)counter, (unsigned long long)n_shaded);
+}
+
+// Stand-alone shade stage (used with the LBVH stack traversal): consumes the hit records of the preceding trace kernel.
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
+{
+    const uint32_t Ppad = a.screen.pixels_padded;
+    // FIRST: identity queue, item i of frame slot blockIdx.y is local pixel i.  Otherwise: chunk slots of the input queue.
+    const uint32_t chunks   = FIRST ? (Ppad >> 6) : (a.in.class_capacity >> 6) * kQueueClasses;
+    uint32_t       n_shaded = 0;
+    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
+    {
+        uint32_t i, klass;
+        bool     active;
+        if (FIRST)
+        {
+            i      = chunk * 64 + (threadIdx.x & 63u);
+            active = true;
+            klass  = (blockIdx.y * (Ppad >> 6) + chunk) % kQueueClasses;  // the path's class for its whole life
+        }
+        else
+            active = queue_chunk(a.in.count, a.in.class_capacity, chunk, threadIdx.x & 63u, i, klass);
+        uint32_t pid = 0;
+        float4   hit = make_float4(0.f, 0.f, u2f(kInvalidId), 0.f);
+        v3       thr = mk3(1.0f, 1.0f, 1.0f);
+        if (active)
+        {
+            if (FIRST)
+            {
+                pid = (blockIdx.y << kPidShift) | i;
+                hit = a.hits[(size_t)blockIdx.y * Ppad + i];
+            }
+            else
+            {
+                const float4 tp = a.in.thr_pid[i];
+                thr = mk3(tp.x, tp.y, tp.z), pid = f2u(tp.w);
+                hit = a.hits[i];
+            }
+        }
+        shade_vertex<FIRST>(a, active, klass, pid, hit, thr, n_shaded);
+    }
+    flush_shaded(a.shaded_counter, n_shaded);
 }
 
 void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args)
@@ -635,6 +677,78 @@ void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args)
     else
     {
         hipLaunchKernelGGL(k_shade<false>, dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
+    }
+}
+
+// Fused stage of the small-scene path: closest-hit (exhaustive, wave-uniform) + shading of the vertex it finds, in one pass over
+// the ray queue.  The hit record never travels through HBM and the shading stage's memory latency hides under the ALU-bound
+// triangle loop of the other waves.  FIRST generates the camera ray instead of reading a queue entry (rt_primary_visibility).
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_trace_shade(BvhDev bvh, ShadeArgs a)
+{
+    const uint32_t Ppad     = a.screen.pixels_padded;
+    const uint32_t chunks   = FIRST ? (Ppad >> 6) : (a.in.class_capacity >> 6) * kQueueClasses;
+    uint32_t       n_shaded = 0;
+    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
+    {
+        uint32_t i, klass, pid = 0;
+        bool     active;
+        v3       thr = mk3(1.0f, 1.0f, 1.0f);
+        Ray      r   = make_ray(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 1.f), 0.0f, 0.0f);  // empty interval: hits nothing
+        if (FIRST)
+        {
+            i      = chunk * 64 + (threadIdx.x & 63u);
+            active = true;
+            klass  = (blockIdx.y * (Ppad >> 6) + chunk) % kQueueClasses;
+            pid    = (blockIdx.y << kPidShift) | i;
+            uint32_t x, y;
+            if (local_pixel_to_xy(a.screen, i, x, y))
+                r = make_ray(mk3(a.cam.position[0], a.cam.position[1], a.cam.position[2]),
+                             primary_dir(a.cam, a.screen, a.frames[blockIdx.y], x, y), 0.0f, kPrimaryFar);
+        }
+        else
+        {
+            active = queue_chunk(a.in.count, a.in.class_capacity, chunk, threadIdx.x & 63u, i, klass);
+            if (__ballot(active) == 0ull) continue;  // unoccupied chunk slot of this class: nothing to trace (wave-uniform)
+            if (active)
+            {
+                const float4 o = a.in.org_tmin[i], d = a.in.dir_tmax[i], tp = a.in.thr_pid[i];
+                r   = make_ray(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w);
+                thr = mk3(tp.x, tp.y, tp.z), pid = f2u(tp.w);
+            }
+        }
+        float    t, u, v;
+        uint32_t gid;
+        exhaustive_closest(bvh, r, t, u, v, gid);
+        if (FIRST && blockIdx.y == a.aov_slot)
+        {
+            // rt_primary_visibility.hlsl:46: (uv, asfloat(InstanceID), asfloat(PrimitiveIndex)); a miss keeps uv = 0, ids = ~0u
+            float4 g = make_float4(0.f, 0.f, u2f(kInvalidId), u2f(kInvalidId));
+            if (gid != kInvalidId)
+            {
+                const uint2 id = a.scene.tri_ids[gid];
+                g              = make_float4(u, v, u2f(id.x), u2f(id.y));
+            }
+            a.planes.aov_geo[i] = g;
+        }
+        shade_vertex<FIRST>(a, active, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded);
+    }
+    flush_shaded(a.shaded_counter, n_shaded);
+}
+
+void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args)
+{
+    if (args.bounce == 0)
+    {
+        const uint32_t chunks = args.screen.pixels_padded >> 6;
+        uint32_t       gx     = (chunks + 3) / 4;
+        if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
+        if (gx == 0) gx = 1;
+        hipLaunchKernelGGL(k_trace_shade<true>, dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, bvh, args);
+    }
+    else
+    {
+        hipLaunchKernelGGL(k_trace_shade<false>, dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh, args);
     }
 }
 

@@ -98,14 +98,16 @@ typedef struct CapStats
     uint64_t shaded_vertices;
     uint64_t frames;
     double   ms_total;          /* GPU time of cap_render calls (hipEvent, context stream) */
-    double   ms_primary;        /* "RaytracePrimaryVisibility" */
-    double   ms_trace_closest;  /* extension-ray traversal ("RT Indirect diffuse", trace part) */
+    double   ms_primary;        /* "RaytracePrimaryVisibility" (fused small-scene path: + shading of the camera vertex) */
+    double   ms_trace_closest;  /* extension-ray traversal ("RT Indirect diffuse"; fused small-scene path: + shading) */
     double   ms_trace_any;      /* shadow-ray traversal */
     double   ms_shade;          /* shading / BSDF sampling / compaction */
     double   ms_resolve;        /* radiance accumulate */
     uint64_t launches_trace_closest;
     uint64_t launches_trace_any;
-    uint64_t launches_shade;
+    uint64_t launches_shade;   /* 0 when the small-scene path fuses shading into the closest-hit kernel */
+    uint64_t rays_extension_bounce0; /* extension / shadow rays emitted by the bounce-0 (camera-vertex) kernel */
+    uint64_t rays_shadow_bounce0;
 } CapStats;
 
 typedef struct CapBvhInfo

@@ -291,6 +291,24 @@ inline bool intersect_tri(f3 o, f3 d, const Tri& tr, float tmin, float tmax, flo
     return true;
 }
 
+// Occlusion query (lighting.h:48-55, ACCEPT_FIRST_HIT_AND_END_SEARCH: only "is there a hit" is observable).  Same
+// determinant-scaled quantities; the open interval test is made in the scaled domain, tmin*det < T < tmax*det, which
+// needs no division (the two forms differ only when T/det rounds across an interval end).
+inline bool occludes_tri(f3 o, f3 d, const Tri& tr, float tmin, float tmax)
+{
+    f3    tvec = o - tr.v0;
+    f3    q    = cross(tvec, d);
+    float det  = -dot(d, tr.n);
+    float U = dot(tr.e2, q), V = -dot(tr.e1, q), T = dot(tvec, tr.n);
+    if (det < 0.0f)
+    {
+        U = -U, V = -V, T = -T, det = -det;
+    }
+    if (!(det > 0.0f)) return false;
+    if (!(U >= 0.0f && V >= 0.0f && U + V <= det)) return false;
+    return T > tmin * det && T < tmax * det;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Scene: pooled geometry (asset_load_system.cpp:162-255) flattened to one triangle list.  The
 // reference's TLAS has one identity-transform instance per mesh with InstanceID = mesh.index
@@ -439,7 +457,7 @@ bool trace_any(const Scene& sc, f3 o, f3 d, float tmin, float tmax, bool use_bvh
     if (!use_bvh || sc.nodes.empty())
     {
         for (uint32_t i = 0; i < sc.tris.size(); ++i)
-            if (intersect_tri(o, d, sc.tris[i], tmin, tmax, &t, &u, &v)) return true;
+            if (occludes_tri(o, d, sc.tris[i], tmin, tmax)) return true;
         return false;
     }
     f3       inv = make3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -454,7 +472,7 @@ bool trace_any(const Scene& sc, f3 o, f3 d, float tmin, float tmax, bool use_bvh
         {
             uint32_t cnt = nd.right & 0x7fffffffu;
             for (uint32_t i = 0; i < cnt; ++i)
-                if (intersect_tri(o, d, sc.tris[sc.bvh_order[nd.left + i]], tmin, tmax, &t, &u, &v)) return true;
+                if (occludes_tri(o, d, sc.tris[sc.bvh_order[nd.left + i]], tmin, tmax)) return true;
         }
         else
         {
