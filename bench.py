@@ -121,6 +121,8 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         st = r.stats()
+        if st.guard_shade or st.guard_trace_any:
+            raise SystemExit("kernel bounds guards fired: shade=%d trace_any=%d last=0x%x" % (st.guard_shade, st.guard_trace_any, st.guard_last))
 
         # whole-job numbers: MAX time over ranks, SUM of rays over ranks
         red = torch.tensor([dt], dtype=torch.float64, device="cuda")

@@ -20,8 +20,9 @@ void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraD
 // Closest hit for the extension-ray queue (rt_indirect.hlsl:173).
 void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits);
 // Any hit for the shadow-ray queue (lighting.h:48-61); unoccluded rays add contrib to target[plane index].
+// guard: 4 x uint64 {shaded vertices, malformed path ids seen by shade, by trace_any, last offender}
 void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target,
-                      uint32_t pixels_padded);
+                      uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard);
 
 // ---- shade ----
 struct ShadeArgs

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -187,11 +188,11 @@ int sync_and_collect(CapContext* c)
             for (uint32_t k = 0; k < kQueueClasses; ++k)
             {
                 c->stats.rays_extension += pc.first[b * per + k * kCounterStride];
-                c->stats.rays_shadow += pc.first[((D + 1) + b) * per + k * kCounterStride];
+                c->stats.rays_shadow += pc.first[b * per + k * kCounterStride + 1];
                 if (b == 0)
                 {
                     c->stats.rays_extension_bounce0 += pc.first[k * kCounterStride];
-                    c->stats.rays_shadow_bounce0 += pc.first[(D + 1) * per + k * kCounterStride];
+                    c->stats.rays_shadow_bounce0 += pc.first[k * kCounterStride + 1];
                 }
             }
         c->pinned_pool.push_back(pc.first);
@@ -199,8 +200,11 @@ int sync_and_collect(CapContext* c)
     c->pending.clear();
     if (c->pinned_shaded && c->shaded_counter.p)
     {
-        HIP_TRY(hipMemcpy(c->pinned_shaded, c->shaded_counter.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
-        c->stats.shaded_vertices = *c->pinned_shaded;
+        HIP_TRY(hipMemcpy(c->pinned_shaded, c->shaded_counter.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        c->stats.shaded_vertices = c->pinned_shaded[0];
+        c->stats.guard_shade     = c->pinned_shaded[1];
+        c->stats.guard_trace_any = c->pinned_shaded[2];
+        c->stats.guard_last      = c->pinned_shaded[3];
     }
     return CAP_OK;
 }
@@ -328,8 +332,8 @@ int ensure_wavefront(CapContext* c, uint32_t slots, uint32_t bounces)
     HIP_TRY(c->counters.ensure(2 * (size_t)(bounces + 1) * kQueueClasses * kCounterStride));
     if (!c->shaded_counter.p)
     {
-        HIP_TRY(c->shaded_counter.ensure(1));
-        HIP_TRY(hipMemsetAsync(c->shaded_counter.p, 0, sizeof(uint64_t), c->stream));
+        HIP_TRY(c->shaded_counter.ensure(4));
+        HIP_TRY(hipMemsetAsync(c->shaded_counter.p, 0, 4 * sizeof(uint64_t), c->stream));
     }
     if (!c->accum.p || c->accum.n < c->screen.pixels_padded)
     {
@@ -378,7 +382,7 @@ int cap_ctx_create(int device_id, void* hip_stream, CapContext** out_ctx)
         }
         c->own_stream = true;
     }
-    (void)hipHostMalloc((void**)&c->pinned_shaded, sizeof(uint64_t), hipHostMallocDefault);
+    (void)hipHostMalloc((void**)&c->pinned_shaded, 4 * sizeof(uint64_t), hipHostMallocDefault);
     update_screen(c, 0, 0, 0, 1);
     *out_ctx = c;
     return CAP_OK;
@@ -517,7 +521,10 @@ int cap_bvh_build(CapContext* c)
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t n = c->tri_count;
     HIP_TRY(c->shade_tris.ensure(6 * (size_t)n));
-    HIP_TRY(c->tris_sorted.ensure(4 * (size_t)n));
+    // + 4 zero records: the exhaustive kernels test triangles in pairs and fetch one pair ahead (kernels.hip); a zero record
+    // has det == 0 and is never hit
+    HIP_TRY(c->tris_sorted.ensure(4 * ((size_t)n + 4)));
+    HIP_TRY(hipMemsetAsync(c->tris_sorted.p, 0, sizeof(float4) * 4 * ((size_t)n + 4), c->stream));
     HIP_TRY(c->tri_raw.ensure(4 * (size_t)n));
     HIP_TRY(c->tri_box.ensure(2 * (size_t)n));
     HIP_TRY(c->nodes.ensure(4 * (size_t)(n > 1 ? n - 1 : 1)));
@@ -695,7 +702,12 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     }
     else if (c->traversal_mode == CAP_TRAVERSAL_AUTO && c->tri_count <= kExhaustiveMax)
         stack_entries = 0;
-    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, stack_entries};
+    // Persistent grids must be fully resident: a workgroup that cannot be co-scheduled runs as a second round after the first
+    // waves retire and doubles the kernel's tail.  blocks_per_cu is therefore the residency the kernels are built for
+    // (launch bounds in kernels.hip), not the 8 a register-light kernel could reach.
+    uint32_t blocks_per_cu = stack_entries == 0 ? 6u : (stack_entries <= 32 ? 5u : 2u);  // measured: 4..8 within 4 %, 6 best
+    if (const char* e = getenv("CAP_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)std::max(1, atoi(e));
+    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * blocks_per_cu, stack_entries};
     const BvhDev    bvh   = bvh_dev(c);
     const SceneDev  scene = scene_dev(c);
     const CameraDev cam   = camera_dev(c->camera);
@@ -707,10 +719,11 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         const uint32_t ns = std::min(slots, n_frames - done);
         const FrameConst* frames = c->frames.p + done;
         const size_t   per_queue     = (size_t)kQueueClasses * kCounterStride;  // counter words of one queue
-        const size_t   counter_words = 2 * (size_t)(D + 1) * per_queue;
+        // per bounce and class one 64-bit word: low half = extension entries, high half = shadow entries (one atomic serves both)
+        const size_t   counter_words = (size_t)(D + 1) * per_queue;
         HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * counter_words, c->stream));
         uint32_t*      ext_count = c->counters.p;
-        uint32_t*      sh_count  = c->counters.p + (D + 1) * per_queue;
+        uint32_t*      sh_count  = c->counters.p + 1;
         const uint32_t total_chunks   = ns * (Ppad >> 6);
         const uint32_t class_capacity = ((total_chunks + kQueueClasses - 1) / kQueueClasses) * 64u;
         const bool     last_batch = done + ns >= n_frames;
@@ -722,6 +735,17 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         sa.planes = Planes{c->pl_color.p, c->pl_direct.p, c->pl_albedo.p, c->aov_geo.p, c->aov_nd.p};
         sa.n_slots = ns, sa.num_bounces = D, sa.max_count = max_count, sa.aov_slot = aov_slot, sa.shaded_counter = c->shaded_counter.p;
         const bool fused = cfg.stack_entries == 0;  // small-scene path: closest hit and shading in one kernel per bounce
+        // CAP_TRACE_LAUNCHES=1: name every launch on stderr and drain the stream after it (fault localisation only)
+        static const bool trace_launches = getenv("CAP_TRACE_LAUNCHES") != nullptr;
+        auto              traced         = [&](const char* what, uint32_t b) -> int {
+            if (!trace_launches) return CAP_OK;
+            fprintf(stderr, "[cap] %s bounce %u batch %u ... ", what, b, done / slots);
+            fflush(stderr);
+            hipError_t e = hipStreamSynchronize(c->stream);
+            fprintf(stderr, "%s\n", hipGetErrorString(e));
+            fflush(stderr);
+            return e == hipSuccess ? CAP_OK : CAP_ERR_HIP;
+        };
         if (!fused)
         {
             {
@@ -742,6 +766,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                 StageTimer t(c, b == 0 ? ST_PRIMARY : ST_CLOSEST, st);
                 launch_trace_shade(cfg, bvh, sa);
                 if (b) ++c->stats.launches_trace_closest;
+                if (traced("trace_shade", b)) return fail(CAP_ERR_HIP, "trace_shade failed");
             }
             else
             {
@@ -751,8 +776,9 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             }
             {
                 StageTimer t(c, ST_ANY, st);
-                launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad);
+                launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p);
                 ++c->stats.launches_trace_any;
+                if (traced("trace_any", b)) return fail(CAP_ERR_HIP, "trace_any failed");
             }
             if (!fused && b < D)
             {
@@ -855,7 +881,7 @@ int cap_stats_reset(CapContext* c)
     HIP_TRY(hipSetDevice(c->device));
     if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
     c->stats = CapStats{};
-    if (c->shaded_counter.p) HIP_TRY(hipMemset(c->shaded_counter.p, 0, sizeof(uint64_t)));
+    if (c->shaded_counter.p) HIP_TRY(hipMemset(c->shaded_counter.p, 0, 4 * sizeof(uint64_t)));
     return CAP_OK;
 }
 

@@ -314,7 +314,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(BvhDev bvh, RayQueue q
 }
 
 template <int STACK>
-__global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded)
+__global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded, uint32_t n_slots,
+                                                      uint64_t* guard)
 {
     __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
     uint32_t*           stack  = lds_stack + threadIdx.x;
@@ -332,10 +333,18 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q,
                 // per path per bounce, so the read-modify-write needs no atomic.
                 const float4   c   = q.contrib_pid[i];
                 const uint32_t pid = f2u(c.w);
+                if ((pid >> kPidShift) >= n_slots || (pid & kPidMask) >= pixels_padded)
+                {
+                    // never true for a well-formed queue; reported through CapStats::guard_* instead of faulting
+                    atomicAdd((unsigned long long*)guard + 2, 1ull);
+                    guard[3] = ((uint64_t)i << 32) | pid;
+                    continue;
+                }
                 const size_t   idx = (size_t)(pid >> kPidShift) * pixels_padded + (pid & kPidMask);
-                float4         tv  = target[idx];
-                tv.x = tv.x + c.x, tv.y = tv.y + c.y, tv.z = tv.z + c.z;
-                target[idx] = tv;
+                float*         tv  = reinterpret_cast<float*>(target + idx);
+                atomicAdd(tv + 0, c.x);  // sole writer of this path: IEEE adds in program order, no wait for the old value
+                atomicAdd(tv + 1, c.y);
+                atomicAdd(tv + 2, c.z);
             }
         }
     }
@@ -376,15 +385,15 @@ void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueu
 }
 
 void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target,
-                      uint32_t pixels_padded)
+                      uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard)
 {
     dim3 grid(queue_grid(cfg, max_count));
     if (cfg.stack_entries == 0)
-        hipLaunchKernelGGL(k_trace_any<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded);
+        hipLaunchKernelGGL(k_trace_any<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard);
     else if (cfg.stack_entries <= 32)
-        hipLaunchKernelGGL(k_trace_any<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded);
+        hipLaunchKernelGGL(k_trace_any<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard);
     else
-        hipLaunchKernelGGL(k_trace_any<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded);
+        hipLaunchKernelGGL(k_trace_any<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,24 +497,79 @@ __device__ __forceinline__ uint32_t wave_append(bool emit, uint32_t* counter)
 // One path vertex: rt_direct_lighting.hlsl:38-83 (bounce 0) / one iteration of the rt_indirect.hlsl:91-174 loop, followed by
 // the 64-lane compaction of the shadow ray and the extension ray into the class-`klass` sub-queues.  Called wave-uniformly
 // (every lane of the wave, active or not) by the stand-alone shade kernel and by the fused trace+shade kernel.
+//
+// Everything the vertex needs that does not depend on the hit (pixel coordinates, the frame's light, the blue-noise sample) is
+// fetched by shade_prefetch(); the fused kernel calls it BEFORE the triangle loop so that these dependent loads land under
+// the loop's ALU work instead of in the latency-bound tail.
+struct ShadePre
+{
+    bool  valid;
+    v3    L, I;    // lighting.h:20-33 of this path's frame
+    float r1, r2;  // sampling.h:13-23 sample of (pixel, frame * 25 + bounce)
+};
+
+__device__ __forceinline__ ShadePre shade_prefetch(const ShadeArgs& a, bool active, uint32_t pid)
+{
+    ShadePre       s;
+    const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
+    uint32_t       x = 0, y = 0;
+    s.valid = active && local_pixel_to_xy(a.screen, pl, x, y);
+    s.L = mk3(0, 0, 0), s.I = mk3(0, 0, 0), s.r1 = 0.f, s.r2 = 0.f;
+    if (s.valid)
+    {
+        const FrameConst fc = a.frames[slot];
+        s.L = mk3(fc.light_dir[0], fc.light_dir[1], fc.light_dir[2]);
+        s.I = mk3(fc.light_intensity[0], fc.light_intensity[1], fc.light_intensity[2]);
+        bluenoise4x4(a.scene.bluenoise, x, y, fc.frame_count * 25u + a.bounce, s.r1, s.r2);  // rt_indirect.hlsl:149
+    }
+    return s;
+}
+
+// Both queue appends of a wave with ONE device atomic: the extension and the shadow counter of a class sit in one 64-bit word
+// (low half = extension entries, high half = shadow entries).
+__device__ __forceinline__ void wave_append2(bool emit_ext, bool emit_shadow, uint32_t* counter_pair, uint32_t& ext_slot,
+                                             uint32_t& shadow_slot)
+{
+    const unsigned long long me = __ballot(emit_ext), ms = __ballot(emit_shadow);
+    ext_slot = shadow_slot = 0;
+    if ((me | ms) == 0ull) return;
+    const uint32_t lane   = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)(me | ms)) - 1u;
+    uint32_t       lo = 0, hi = 0;
+    if (lane == leader)
+    {
+        const unsigned long long add = ((unsigned long long)__popcll(ms) << 32) | (unsigned long long)__popcll(me);
+        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(counter_pair), add);
+        lo = (uint32_t)old, hi = (uint32_t)(old >> 32);
+    }
+    lo = __shfl(lo, (int)leader), hi = __shfl(hi, (int)leader);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    ext_slot    = lo + (uint32_t)__popcll(me & below);
+    shadow_slot = hi + (uint32_t)__popcll(ms & below);
+}
+
 template <bool FIRST>
-__device__ __forceinline__ void shade_vertex(const ShadeArgs& a, bool active, uint32_t klass, uint32_t pid, float4 hit, v3 thr,
+__device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const ShadePre& pre, uint32_t klass, uint32_t pid, float4 hit, v3 thr,
                                              uint32_t& n_shaded)
 {
     const uint32_t Ppad = a.screen.pixels_padded;
     const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
     {
         const size_t plane_idx = (size_t)slot * Ppad + pl;
-        uint32_t     x = 0, y = 0;
-        const bool   valid = active && local_pixel_to_xy(a.screen, pl, x, y);
+        bool         valid = pre.valid;
+        if (valid && (slot >= a.n_slots || pl >= Ppad))
+        {
+            // never true for a well-formed queue; reported through CapStats::guard_* instead of faulting
+            atomicAdd((unsigned long long*)a.shaded_counter + 1, 1ull);
+            a.shaded_counter[3] = ((uint64_t)a.bounce << 32) | pid;
+            valid = false;
+        }
         const uint32_t gid = f2u(hit.z);
 
         bool   emit_shadow = false, emit_ext = false;
         v3     p = mk3(0, 0, 0), dir = mk3(0, 0, 0), contrib = mk3(0, 0, 0);
-        FrameConst fc;
-        if (valid) fc = a.frames[slot];
 
-        if (FIRST && active && !valid)
+        if (FIRST && !valid)
         {
             // padding lane of a partial / absent tile: define the planes so the resolve adds exact zeros
             a.planes.color[plane_idx]  = make_float4(0, 0, 0, 0);
@@ -524,10 +588,13 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, bool active, ui
             }
             else
             {
-                // rt_indirect.hlsl:94-99  color += throughput * sky
-                float4 c = a.planes.color[plane_idx];
-                c.x = c.x + thr.x * 0.7f, c.y = c.y + thr.y * 0.7f, c.z = c.z + thr.z * 0.85f;
-                a.planes.color[plane_idx] = c;
+                // rt_indirect.hlsl:94-99  color += throughput * sky.  Exactly one lane in the whole grid owns this path, so the
+                // three no-return float atomics are plain IEEE adds in program order; unlike a load-add-store they do not make
+                // the wave wait for the old value.
+                float* c = reinterpret_cast<float*>(a.planes.color + plane_idx);
+                atomicAdd(c + 0, thr.x * 0.7f);
+                atomicAdd(c + 1, thr.y * 0.7f);
+                atomicAdd(c + 2, thr.z * 0.85f);
             }
         }
         else if (valid)
@@ -541,14 +608,18 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, bool active, ui
             const v3      n = normalize3(mk3(mix(s3.x, s4.x, s5.x), mix(s3.y, s4.y, s5.y), mix(s3.z, s4.z, s5.z)));
             p = mk3(mix(s0.x, s1.x, s2.x), mix(s0.y, s1.y, s2.y), mix(s0.z, s1.z, s2.z));
             // scene.h:52-61 GetMaterial
-            v3             kd   = mk3(a.scene.kd_untextured, a.scene.kd_untextured, a.scene.kd_untextured);
-            const uint32_t inst = a.scene.tri_ids[gid].x;
-            const uint32_t tex  = a.scene.mesh_texture[inst];
-            if (tex != kInvalidId && tex < a.scene.texture_count)
+            v3       kd   = mk3(a.scene.kd_untextured, a.scene.kd_untextured, a.scene.kd_untextured);
+            uint32_t inst = 0;
+            if (a.scene.texture_count != 0 || (FIRST && slot == a.aov_slot))  // wave-uniform: untextured scenes skip two dependent loads
             {
-                const float tu = mix(s0.w, s2.w, s4.w), tv = mix(s1.w, s3.w, s5.w);
-                const v3    c  = sample_texture(a.scene.textures[tex], tu, 1.0f - tv);
-                kd             = mk3(pow22_c(c.x), pow22_c(c.y), pow22_c(c.z));
+                inst               = a.scene.tri_ids[gid].x;
+                const uint32_t tex = a.scene.mesh_texture[inst];
+                if (tex != kInvalidId && tex < a.scene.texture_count)
+                {
+                    const float tu = mix(s0.w, s2.w, s4.w), tv = mix(s1.w, s3.w, s5.w);
+                    const v3    c  = sample_texture(a.scene.textures[tex], tu, 1.0f - tv);
+                    kd             = mk3(pow22_c(c.x), pow22_c(c.y), pow22_c(c.z));
+                }
             }
             const bool black = kd.x < 1e-5f && kd.y < 1e-5f && kd.z < 1e-5f;  // rt_direct_lighting.hlsl:68, rt_indirect.hlsl:108
             if (FIRST)
@@ -571,19 +642,15 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, bool active, ui
             if (!black)
             {
                 // lighting.h:35-61: unshadowed direct term; the visibility ray is queued for the any-hit kernel
-                const v3    L   = mk3(fc.light_dir[0], fc.light_dir[1], fc.light_dir[2]);
-                const float ndl = fmaxf(0.0f, dot3(n, L));
-                v3          c   = mk3(((fc.light_intensity[0] * kd.x) * kInvPi) * ndl, ((fc.light_intensity[1] * kd.y) * kInvPi) * ndl,
-                                      ((fc.light_intensity[2] * kd.z) * kInvPi) * ndl);
+                const float ndl = fmaxf(0.0f, dot3(n, pre.L));
+                v3          c   = mk3(((pre.I.x * kd.x) * kInvPi) * ndl, ((pre.I.y * kd.y) * kInvPi) * ndl, ((pre.I.z * kd.z) * kInvPi) * ndl);
                 if (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f)
                 {
                     emit_shadow = true;
                     contrib     = FIRST ? c : thr * c;  // rt_direct_lighting.hlsl:77 / rt_indirect.hlsl:136
                 }
                 // rt_indirect.hlsl:149-170
-                float r1, r2;
-                bluenoise4x4(a.scene.bluenoise, x, y, fc.frame_count * 25u + a.bounce, r1, r2);
-                dir             = map_to_hemisphere(r1, r2, n);
+                dir             = map_to_hemisphere(pre.r1, pre.r2, n);
                 const float ndd = dot3(n, dir);
                 const float pdf = fmaxf(0.0f, ndd) / kPi;  // shading.h:19-22
                 if (!(pdf < 1e-5f))
@@ -597,15 +664,17 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, bool active, ui
             }
         }
 
-        const uint32_t si = klass * a.shadow.class_capacity + wave_append(emit_shadow, a.shadow.count + klass * kCounterStride);
+        // a.shadow.count == a.out.count + 1: both counters of a class share one 64-bit word (one atomic per wave for both queues)
+        uint32_t ei, si;
+        wave_append2(emit_ext, emit_shadow, a.out.count + klass * kCounterStride, ei, si);
+        ei += klass * a.out.class_capacity;
+        si += klass * a.shadow.class_capacity;
         if (emit_shadow)
         {
-            const FrameConst& f = fc;
             a.shadow.org_tmin[si]    = make_float4(p.x, p.y, p.z, kRayEps);
-            a.shadow.dir_tmax[si]    = make_float4(f.light_dir[0], f.light_dir[1], f.light_dir[2], kRayFar);
+            a.shadow.dir_tmax[si]    = make_float4(pre.L.x, pre.L.y, pre.L.z, kRayFar);
             a.shadow.contrib_pid[si] = make_float4(contrib.x, contrib.y, contrib.z, u2f(pid));
         }
-        const uint32_t ei = klass * a.out.class_capacity + wave_append(emit_ext, a.out.count + klass * kCounterStride);
         if (emit_ext)
         {
             a.out.org_tmin[ei] = make_float4(p.x, p.y, p.z, kRayEps);
@@ -659,7 +728,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
                 hit = a.hits[i];
             }
         }
-        shade_vertex<FIRST>(a, active, klass, pid, hit, thr, n_shaded);
+        const ShadePre pre = shade_prefetch(a, active, pid);
+        shade_vertex<FIRST>(a, pre, klass, pid, hit, thr, n_shaded);
     }
     flush_shaded(a.shaded_counter, n_shaded);
 }
@@ -717,8 +787,9 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_trace_shade(BvhDev bv
                 thr = mk3(tp.x, tp.y, tp.z), pid = f2u(tp.w);
             }
         }
-        float    t, u, v;
-        uint32_t gid;
+        const ShadePre pre = shade_prefetch(a, active, pid);  // issued before the triangle loop: lands under its ALU work
+        float          t, u, v;
+        uint32_t       gid;
         exhaustive_closest(bvh, r, t, u, v, gid);
         if (FIRST && blockIdx.y == a.aov_slot)
         {
@@ -731,7 +802,7 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_trace_shade(BvhDev bv
             }
             a.planes.aov_geo[i] = g;
         }
-        shade_vertex<FIRST>(a, active, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded);
+        shade_vertex<FIRST>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded);
     }
     flush_shaded(a.shaded_counter, n_shaded);
 }

@@ -108,6 +108,9 @@ typedef struct CapStats
     uint64_t launches_shade;   /* 0 when the small-scene path fuses shading into the closest-hit kernel */
     uint64_t rays_extension_bounce0; /* extension / shadow rays emitted by the bounce-0 (camera-vertex) kernel */
     uint64_t rays_shadow_bounce0;
+    uint64_t guard_shade;     /* malformed queue entries caught by the kernels' bounds guards: always 0 in a correct run */
+    uint64_t guard_trace_any;
+    uint64_t guard_last;      /* (queue index or bounce) << 32 | path id of the last offender */
 } CapStats;
 
 typedef struct CapBvhInfo
