@@ -73,14 +73,22 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the renderer has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # CAP_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices, the gather goes
+    # through host memory); the contract run uses nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("CAP_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    comm_device = "cuda" if backend == "nccl" else "cpu"
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        r = capi.Renderer(local_rank, stream.cuda_stream)
+        r = capi.Renderer(device_index, stream.cuda_stream)
         r.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
         r.upload_bluenoise(capi.load_bluenoise())
         bvh = r.build_bvh()
@@ -101,7 +109,15 @@ def main():
             r.resolve_tiles(tile_buf.data_ptr())
             if world > 1:
                 # the single data-path collective: tile radiance -> rank 0 over xGMI
-                dist.gather(tile_buf, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+                if backend == "nccl":
+                    dist.gather(tile_buf, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+                else:
+                    r.sync()
+                    host = tile_buf.cpu()
+                    parts = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+                    dist.gather(host, parts, dst=0)
+                    if rank == 0:
+                        gathered.copy_(torch.cat(parts))
             if rank == 0:
                 r.assemble_tiles((gathered if world > 1 else tile_buf).data_ptr(), world, image.data_ptr())
 
@@ -125,8 +141,8 @@ def main():
             raise SystemExit("kernel bounds guards fired: shade=%d trace_any=%d last=0x%x" % (st.guard_shade, st.guard_trace_any, st.guard_last))
 
         # whole-job numbers: MAX time over ranks, SUM of rays over ranks
-        red = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        cnt = torch.tensor([st.rays_primary, st.rays_extension, st.rays_shadow, st.shaded_vertices], dtype=torch.float64, device="cuda")
+        red = torch.tensor([dt], dtype=torch.float64, device=comm_device)
+        cnt = torch.tensor([st.rays_primary, st.rays_extension, st.rays_shadow, st.shaded_vertices], dtype=torch.float64, device=comm_device)
         if world > 1:
             dist.all_reduce(red, op=dist.ReduceOp.MAX)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)

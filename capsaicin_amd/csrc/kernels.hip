@@ -56,8 +56,10 @@ __device__ __forceinline__ bool tri_test(const Ray& r, const float4 t0, const fl
     // two-sided: when det < 0 every sign flips (exact, so a sign-bit xor)
     const uint32_t sgn = f2u(det) & 0x80000000u;
     det = u2f(f2u(det) ^ sgn), U = u2f(f2u(U) ^ sgn), V = u2f(f2u(V) ^ sgn), T = u2f(f2u(T) ^ sgn);
-    const bool  inside = (det > 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= det);
-    const float inv    = 1.0f / det;
+    // det == 0 needs no test of its own: then inv overflows and tt is +-inf or NaN, which the interval test rejects
+    // (det NaN fails every comparison), exactly where the contract's explicit det > 0 rejects.
+    const bool  inside = (U >= 0.0f) & (V >= 0.0f) & (U + V <= det);
+    const float inv    = rcp_c(det);
     const float tt     = T * inv;
     t = tt, u = U * inv, v = V * inv;
     return inside & (tt > r.tmin) & (tt < r.tmax);

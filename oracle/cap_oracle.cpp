@@ -270,6 +270,18 @@ struct Hit
     uint32_t gid;  // global triangle index; ~0u = miss
 };
 
+// Reciprocal of the intersection contract: bit-trick seed + three Newton-Raphson steps, each x <- x * fma(-a, x, 2).
+// Relative error <= 1e-7 for normal a > 0; fully specified by IEEE operations, so host and device agree bit for bit
+// (a hardware reciprocal estimate would not be reproducible on the CPU).
+inline float rcp_contract(float a)
+{
+    float x = as_float(0x7EF311C7u - as_uint(a));
+    x       = x * fmaf(-a, x, 2.0f);
+    x       = x * fmaf(-a, x, 2.0f);
+    x       = x * fmaf(-a, x, 2.0f);
+    return x;
+}
+
 inline bool intersect_tri(f3 o, f3 d, const Tri& tr, float tmin, float tmax, float* t, float* u, float* v)
 {
     // scalar triple products of Moller-Trumbore regrouped around the precomputed plane normal n = e1 x e2 and
@@ -284,7 +296,7 @@ inline bool intersect_tri(f3 o, f3 d, const Tri& tr, float tmin, float tmax, flo
     }
     if (!(det > 0.0f)) return false;
     if (!(U >= 0.0f && V >= 0.0f && U + V <= det)) return false;
-    float inv = 1.0f / det;
+    float inv = rcp_contract(det);
     float tt  = T * inv;
     if (!(tt > tmin && tt < tmax)) return false;
     *t = tt, *u = U * inv, *v = V * inv;
