@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--batch-paths", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--traversal", type=int, default=0, help=argparse.SUPPRESS)  # 0 auto (contract run), 1 stack, 2 exhaustive
+    ap.add_argument("--scene", default="cornell", help=argparse.SUPPRESS)  # "sponza": extra line on the procedural 262 k-triangle scene
     args = ap.parse_args()
 
     import numpy as np
@@ -89,12 +90,42 @@ def main():
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         r = capi.Renderer(device_index, stream.cuda_stream)
-        r.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
+        scene_name = "cornell_box.obj"
+        camera = capi.cornell_camera(WIDTH, HEIGHT)
+        if args.scene == "sponza":
+            # not the contract workload: BASELINE configs[3] stand-in (tools/make_sponza_class.py), LBVH + LDS-stack kernels
+            import tempfile
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import make_sponza_class as gen
+            tmp = tempfile.mkdtemp(prefix="sponza_class_r%d_" % rank)
+            gen.write(tmp, 1.0, 256)
+            geo = capi.Geometry(os.path.join(tmp, "sponza_class.obj"))
+            r.upload_geometry(geo)
+            for i, name in enumerate(geo.texture_names):
+                raw = open(os.path.join(tmp, "textures", name), "rb").read().split(b"\n", 3)
+                tw, th = (int(x) for x in raw[1].split())
+                rgb = np.frombuffer(raw[3], np.uint8).reshape(th, tw, 3)
+                r.upload_texture(i, np.concatenate([rgb, np.full((th, tw, 1), 255, np.uint8)], -1))
+            c = gen.camera()
+            f = np.float64(c["forward"]) / np.linalg.norm(c["forward"])
+            right = -np.cross(f, (0, 1, 0))
+            right /= np.linalg.norm(right)
+            camera = capi.CameraData()
+            camera.position[:] = c["position"]
+            camera.forward[:] = f
+            camera.right[:] = right
+            camera.up[:] = np.cross(f, right)
+            camera.focal_length = c["focal_length"]
+            camera.sensor_size[0] = 0.036
+            camera.sensor_size[1] = np.float32(0.036) * (np.float32(HEIGHT) / np.float32(WIDTH))
+            scene_name = "sponza_class.obj (procedural, textured)"
+        else:
+            r.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
         r.upload_bluenoise(capi.load_bluenoise())
         bvh = r.build_bvh()
         r.set_resolution(WIDTH, HEIGHT)
         r.set_shard(rank, world)
-        r.set_camera(capi.cornell_camera(WIDTH, HEIGHT))
+        r.set_camera(camera)
         if args.batch_paths:
             r.set_batch_paths(args.batch_paths)
         r.set_traversal(args.traversal)
@@ -191,7 +222,7 @@ def main():
             out = {"metric": "Mrays/sec (primary+secondary), cornell_box 1080p 64spp", "value": rays / dt / 1e6, "unit": "Mrays/s",
                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                   "config": {"workload": "cornell_box.obj %dx%d %dspp depth=%d (reference shading: Lambert + directional light + sky), "
+                   "config": {"workload": scene_name + " %dx%d %dspp depth=%d (reference shading: Lambert + directional light + sky), "
                                           "tile-sharded over %d GPU(s)" % (WIDTH, HEIGHT, args.spp, DEPTH, world),
                               "triangles": int(bvh.triangle_count), "bvh_depth": int(bvh.max_depth),
                               "rays_per_step": {"primary": rays_p / args.steps, "extension": rays_e / args.steps, "shadow": rays_s / args.steps},
