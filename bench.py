@@ -215,6 +215,36 @@ def main():
                         "stage_ms": {"primary": sp.ms_primary, "trace_closest": sp.ms_trace_closest, "trace_any": sp.ms_trace_any,
                                      "shade": sp.ms_shade, "resolve": sp.ms_resolve, "total": sp.ms_total}}
 
+        # Informational second line of the same workload with the EXT shading model (no reference counterpart): the Cornell box
+        # with its MTL colours, GGX on the two boxes and the back wall, the emissive lamp sampled by next-event estimation.
+        ext_variant = None
+        if args.scene == "cornell" and world == 1:
+            import shutil
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="cornell_mtl_")
+            txt = open(os.path.join(ROOT, "assets", "cornell_box.obj")).read().replace("mtllib cornellbox.mtl", "mtllib cornell_box.mtl")
+            open(os.path.join(tmp, "c.obj"), "w").write(txt)
+            shutil.copy(os.path.join(ROOT, "assets", "cornell_box.mtl"), os.path.join(tmp, "cornell_box.mtl"))
+            mats = capi.Geometry(os.path.join(tmp, "c.obj")).materials()
+            for m, (rough, ks) in {1: (0.25, 0.6), 6: (0.45, 0.4), 3: (0.15, 0.8)}.items():
+                mats[m, 3], mats[m, 4:7] = rough, ks
+            r.upload_materials(mats)
+            step(capi.RENDER_EXT_MATERIALS)
+            fence()
+            r.stats_reset()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(capi.RENDER_EXT_MATERIALS)
+            fence()
+            edt = time.perf_counter() - t0
+            es = r.stats()
+            erays = es.rays_primary + es.rays_extension + es.rays_shadow
+            ext_variant = {"workload": "cornell_box.obj + cornell_box.mtl %dx%d %dspp depth=%d, Lambert+GGX, emissive lamp + NEE (EXT model)" %
+                                       (WIDTH, HEIGHT, args.spp, DEPTH),
+                           "value": erays / edt / 1e6, "unit": "Mrays/s", "ms_per_step": edt / args.steps * 1e3,
+                           "rays_per_step": {"primary": es.rays_primary / args.steps, "extension": es.rays_extension / args.steps,
+                                             "shadow": es.rays_shadow / args.steps}}
+
         if rank == 0:
             # sanity of the product of the timed region: finite image, every pixel accumulated spp frames
             img = image.cpu().numpy().reshape(HEIGHT, WIDTH, 4)
@@ -227,7 +257,7 @@ def main():
                               "triangles": int(bvh.triangle_count), "bvh_depth": int(bvh.max_depth),
                               "rays_per_step": {"primary": rays_p / args.steps, "extension": rays_e / args.steps, "shadow": rays_s / args.steps},
                               "parallelism": "tiles%d" % world},
-                   "roofline": roofline}
+                   "roofline": roofline, "ext_variant": ext_variant}
             out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()  # rank 0, N = 1 only
             print(json.dumps(out), flush=True)
         r.close()

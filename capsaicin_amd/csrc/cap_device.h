@@ -118,6 +118,14 @@ __device__ __forceinline__ bool queue_chunk(const uint32_t* count, uint32_t clas
     return local < n;
 }
 
+// CapMaterial as uploaded (include/capsaicin_hip.h), 48 bytes
+struct MaterialDev
+{
+    float kd[3], roughness;
+    float ks[3], pad0;
+    float ke[3], pad1;
+};
+
 struct SceneDev
 {
     const float4*     shade_tris;  // 6 per triangle
@@ -127,6 +135,13 @@ struct SceneDev
     uint32_t          texture_count;
     const float2*     bluenoise;   // 256*256 (R,G)/255
     float             kd_untextured;  // pow(0.75, 2.2), scene.h:55-58
+    // EXT shading model (no reference counterpart; DESIGN.md "EXT shading model")
+    const float2*      bluenoise_ba;  // 256*256 (B,A)/255
+    const MaterialDev* materials;     // one per mesh
+    const uint32_t*    light_tris;    // emissive triangles (global ids) in triangle order
+    const float*       light_cdf;     // float prefix sums of their areas
+    uint32_t           light_count;
+    float              light_area;
 };
 
 struct Planes

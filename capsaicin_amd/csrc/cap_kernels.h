@@ -43,9 +43,9 @@ struct ShadeArgs
     uint32_t          aov_slot;    // frame slot whose AOVs are kept, or ~0u
     uint64_t*         shaded_counter;
 };
-void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args);
+void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext);
 // small-scene path: exhaustive closest hit fused with the shading of the vertex found (bounce 0 generates the camera rays)
-void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args);
+void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, bool ext);
 
 // ---- accumulate / exchange ----
 // accum[pl] += sum over slots (in slot order) of color*albedo + direct; .w counts frames.

@@ -116,6 +116,16 @@ struct CapContext
     bool                         bluenoise_ready = false;
     std::vector<CapMaterial>     materials_host;
     DevBuf<CapMaterial>          materials;
+    // EXT: host copies needed to build the light table, the table itself, the B/A blue-noise channels
+    std::vector<float>           positions_host;
+    std::vector<uint32_t>        indices_host;
+    std::vector<CapMeshDesc>     meshes_host;
+    DevBuf<uint32_t>             light_tris;
+    DevBuf<float>                light_cdf;
+    DevBuf<float2>               bluenoise_ba;
+    uint32_t                     light_count = 0;
+    float                        light_area  = 0.0f;
+    bool                         materials_ready = false;
 
     // BVH
     DevBuf<float4>   shade_tris, tris_sorted, nodes, tri_raw, tri_box;
@@ -307,6 +317,12 @@ SceneDev scene_dev(const CapContext* c)
     s.texture_count = (uint32_t)c->texture_host.size();
     s.bluenoise     = c->bluenoise.p;
     s.kd_untextured = pow22_c(0.75f);
+    s.bluenoise_ba  = c->bluenoise_ba.p;
+    s.materials     = reinterpret_cast<const MaterialDev*>(c->materials.p);
+    s.light_tris    = c->light_tris.p;
+    s.light_cdf     = c->light_cdf.p;
+    s.light_count   = c->light_count;
+    s.light_area    = c->light_area;
     return s;
 }
 
@@ -453,6 +469,11 @@ int cap_scene_upload(CapContext* c, const float* positions, const float* normals
         HIP_TRY(hipMemcpy(c->mesh_offsets.p, mesh_offsets.data(), sizeof(uint4) * mesh_count, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->mesh_texture.p, mesh_texture.data(), sizeof(uint32_t) * mesh_count, hipMemcpyHostToDevice));
     }
+    c->positions_host.assign(positions, positions + 3 * (size_t)vertex_count);
+    c->indices_host.assign(indices, indices + index_count);
+    c->meshes_host.assign(meshes, meshes + mesh_count);
+    c->materials_ready = false;  // per-mesh materials belong to the previous scene
+    c->light_count     = 0;
     c->vertex_count = vertex_count, c->index_count = index_count, c->mesh_count = mesh_count, c->tri_count = (uint32_t)tri_ids.size();
     c->scene_ready = true;
     c->bvh_ready   = false;
@@ -499,6 +520,10 @@ int cap_bluenoise_upload(CapContext* c, const uint8_t* rgba8)
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(c->bluenoise.ensure(lut.size()));
     HIP_TRY(hipMemcpy(c->bluenoise.p, lut.data(), sizeof(float2) * lut.size(), hipMemcpyHostToDevice));
+    // EXT: the B and A channels feed the extra random numbers of the EXT shading model (lobe choice, light triangle)
+    for (size_t i = 0; i < lut.size(); ++i) lut[i] = make_float2((float)rgba8[4 * i + 2] / 255.0f, (float)rgba8[4 * i + 3] / 255.0f);
+    HIP_TRY(c->bluenoise_ba.ensure(lut.size()));
+    HIP_TRY(hipMemcpy(c->bluenoise_ba.p, lut.data(), sizeof(float2) * lut.size(), hipMemcpyHostToDevice));
     c->bluenoise_ready = true;
     return CAP_OK;
 }
@@ -508,9 +533,45 @@ int cap_materials_upload(CapContext* c, const CapMaterial* materials, uint32_t m
     if (!c || (!materials && mesh_count)) return fail(CAP_ERR_INVALID_ARG, "cap_materials_upload: NULL argument");
     if (!c->scene_ready || mesh_count != c->mesh_count) return fail(CAP_ERR_STATE, "cap_materials_upload: expected %u materials (one per mesh)", c->mesh_count);
     c->materials_host.assign(materials, materials + mesh_count);
+    // Light table of the EXT model: emissive triangles in global triangle order with float prefix sums of their areas
+    // (area = |e1 x e2| / 2 with the arithmetic of cap_math.h, so the table is the one the oracle builds).
+    std::vector<uint32_t> light_tris;
+    std::vector<float>    light_cdf;
+    float                 area = 0.0f;
+    uint32_t              g    = 0;
+    for (uint32_t m = 0; m < c->mesh_count; ++m)
+    {
+        const CapMeshDesc& d  = c->meshes_host[m];
+        const CapMaterial& mt = materials[m];
+        const bool         emissive = mt.ke[0] > 0.0f || mt.ke[1] > 0.0f || mt.ke[2] > 0.0f;
+        for (uint32_t k = 0; k + 2 < d.index_count; k += 3, ++g)
+        {
+            if (!emissive) continue;
+            v3 p[3];
+            for (int j = 0; j < 3; ++j)
+            {
+                const uint32_t vi = d.first_vertex_offset + c->indices_host[d.first_index_offset + k + j];
+                p[j]              = mk3(c->positions_host[3 * vi], c->positions_host[3 * vi + 1], c->positions_host[3 * vi + 2]);
+            }
+            area = area + 0.5f * length3(cross3(p[1] - p[0], p[2] - p[0]));
+            light_tris.push_back(g);
+            light_cdf.push_back(area);
+        }
+    }
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(c->materials.ensure(mesh_count));
     if (mesh_count) HIP_TRY(hipMemcpy(c->materials.p, materials, sizeof(CapMaterial) * mesh_count, hipMemcpyHostToDevice));
+    HIP_TRY(c->light_tris.ensure(light_tris.size()));
+    HIP_TRY(c->light_cdf.ensure(light_cdf.size()));
+    if (!light_tris.empty())
+    {
+        HIP_TRY(hipMemcpy(c->light_tris.p, light_tris.data(), sizeof(uint32_t) * light_tris.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->light_cdf.p, light_cdf.data(), sizeof(float) * light_cdf.size(), hipMemcpyHostToDevice));
+    }
+    c->light_count     = (uint32_t)light_tris.size();
+    c->light_area      = area;
+    c->materials_ready = true;
     return CAP_OK;
 }
 
@@ -666,7 +727,9 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_render: ctx is NULL");
     if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_render: call cap_bvh_build first");
     if (!c->camera_ready || !c->bluenoise_ready || !c->screen.width) return fail(CAP_ERR_STATE, "cap_render: camera, blue noise and resolution must be set");
-    if (flags & CAP_RENDER_EXT_MATERIALS) return fail(CAP_ERR_UNSUPPORTED, "cap_render: EXT materials are not available in this build");
+    const bool ext = (flags & CAP_RENDER_EXT_MATERIALS) != 0;
+    if (ext && !c->materials_ready) return fail(CAP_ERR_STATE, "cap_render: CAP_RENDER_EXT_MATERIALS needs cap_materials_upload (one material per mesh)");
+    static_assert(sizeof(MaterialDev) == sizeof(CapMaterial), "material layouts must match");
     if (num_bounces > 255) return fail(CAP_ERR_INVALID_ARG, "cap_render: num_bounces %u exceeds 255", num_bounces);
     if (!n_frames) return CAP_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -764,14 +827,14 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             if (fused)
             {
                 StageTimer t(c, b == 0 ? ST_PRIMARY : ST_CLOSEST, st);
-                launch_trace_shade(cfg, bvh, sa);
+                launch_trace_shade(cfg, bvh, sa, ext);
                 if (b) ++c->stats.launches_trace_closest;
                 if (traced("trace_shade", b)) return fail(CAP_ERR_HIP, "trace_shade failed");
             }
             else
             {
                 StageTimer t(c, ST_SHADE, st);
-                launch_shade(cfg, sa);
+                launch_shade(cfg, sa, ext);
                 ++c->stats.launches_shade;
             }
             {

@@ -756,8 +756,10 @@ struct ShadePre
     bool  valid;
     v3    L, I;    // lighting.h:20-33 of this path's frame
     float r1, r2;  // sampling.h:13-23 sample of (pixel, frame * 25 + bounce)
+    float r3, r4, r5, r6;  // EXT only: B, A of the same texel; R, G of the texel of count + 7
 };
 
+template <bool EXT = false>
 __device__ __forceinline__ ShadePre shade_prefetch(const ShadeArgs& a, bool active, uint32_t pid)
 {
     ShadePre       s;
@@ -765,12 +767,19 @@ __device__ __forceinline__ ShadePre shade_prefetch(const ShadeArgs& a, bool acti
     uint32_t       x = 0, y = 0;
     s.valid = active && local_pixel_to_xy(a.screen, pl, x, y);
     s.L = mk3(0, 0, 0), s.I = mk3(0, 0, 0), s.r1 = 0.f, s.r2 = 0.f;
+    s.r3 = s.r4 = s.r5 = s.r6 = 0.f;
     if (s.valid)
     {
         const FrameConst fc = a.frames[slot];
         s.L = mk3(fc.light_dir[0], fc.light_dir[1], fc.light_dir[2]);
         s.I = mk3(fc.light_intensity[0], fc.light_intensity[1], fc.light_intensity[2]);
-        bluenoise4x4(a.scene.bluenoise, x, y, fc.frame_count * 25u + a.bounce, s.r1, s.r2);  // rt_indirect.hlsl:149
+        const uint32_t count = fc.frame_count * 25u + a.bounce;
+        bluenoise4x4(a.scene.bluenoise, x, y, count, s.r1, s.r2);  // rt_indirect.hlsl:149
+        if (EXT)
+        {
+            bluenoise4x4(a.scene.bluenoise_ba, x, y, count, s.r3, s.r4);
+            bluenoise4x4(a.scene.bluenoise, x, y, count + 7u, s.r5, s.r6);
+        }
     }
     return s;
 }
@@ -934,6 +943,191 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const ShadePre&
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXT shading model (no reference counterpart, specification in DESIGN.md "EXT shading model"):
+// Lambert + GGX microfacet BSDF, emissive triangles sampled by area with one shadow ray per vertex (next-event estimation),
+// emission seen directly only from the camera, black environment.  Same queues and kernels as the reference model.
+// ------------------------------------------------------------------------------------------------
+struct ExtBsdf
+{
+    v3    f;
+    float pdf_spec, pdf_diff;
+};
+
+__device__ __forceinline__ float lum3(v3 c) { return fmaf(c.z, 0.114f, fmaf(c.y, 0.587f, c.x * 0.299f)); }
+
+__device__ __forceinline__ ExtBsdf ext_bsdf(v3 kd, v3 ks, float a2, v3 nf, v3 wo, v3 wi)
+{
+    const float cos_o = dot3(nf, wo), cos_i = dot3(nf, wi);
+    const v3    h     = normalize3(wo + wi);
+    const float cos_h = dot3(nf, h), woh = dot3(wo, h);
+    const float dd    = fmaf(cos_h * cos_h, a2 - 1.0f, 1.0f);
+    const float D     = a2 / (kPi * dd * dd);
+    const float g_o   = (2.0f * cos_o) / (cos_o + sqrtf(fmaf(1.0f - a2, cos_o * cos_o, a2)));
+    const float g_i   = (2.0f * cos_i) / (cos_i + sqrtf(fmaf(1.0f - a2, cos_i * cos_i, a2)));
+    const float spec  = (D * (g_o * g_i)) / (4.0f * cos_o * cos_i);
+    ExtBsdf     r;
+    r.f        = mk3(kd.x * kInvPi + ks.x * spec, kd.y * kInvPi + ks.y * spec, kd.z * kInvPi + ks.z * spec);
+    r.pdf_spec = (D * cos_h) / (4.0f * woh);
+    r.pdf_diff = cos_i * kInvPi;
+    return r;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const ShadePre& pre, uint32_t klass, uint32_t pid, float4 hit, v3 thr,
+                                                 v3 d, uint32_t& n_shaded)
+{
+    const uint32_t Ppad = a.screen.pixels_padded;
+    const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
+    const size_t   plane_idx = (size_t)slot * Ppad + pl;
+    bool           valid = pre.valid;
+    if (valid && (slot >= a.n_slots || pl >= Ppad))
+    {
+        atomicAdd((unsigned long long*)a.shaded_counter + 1, 1ull);
+        a.shaded_counter[3] = ((uint64_t)a.bounce << 32) | pid;
+        valid = false;
+    }
+    const uint32_t gid = f2u(hit.z);
+    bool  emit_shadow = false, emit_ext = false;
+    v3    p = mk3(0, 0, 0), dir = mk3(0, 0, 0), contrib = mk3(0, 0, 0), sdir = mk3(0, 0, 1);
+    float stmax = 0.0f;
+
+    if (FIRST && !valid)
+    {
+        a.planes.color[plane_idx]  = make_float4(0, 0, 0, 0);
+        a.planes.direct[plane_idx] = make_float4(0, 0, 0, 0);
+        a.planes.albedo[plane_idx] = make_float4(0, 0, 0, 0);
+    }
+    if (valid && gid == kInvalidId)
+    {
+        if (FIRST)
+        {
+            // black environment: the camera ray that leaves the scene carries nothing
+            a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
+            a.planes.direct[plane_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
+            a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (slot == a.aov_slot) a.planes.aov_normal_depth[pl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    else if (valid)
+    {
+        ++n_shaded;
+        const float4* st = a.scene.shade_tris + 6 * (size_t)gid;
+        const float4  s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3], s4 = st[4], s5 = st[5];
+        const float   u = hit.x, v = hit.y, w = (1.0f - u) - v;
+        auto          mix = [&](float c0, float c1, float c2) { return fmaf(c2, v, fmaf(c1, u, c0 * w)); };
+        const v3      n = normalize3(mk3(mix(s3.x, s4.x, s5.x), mix(s3.y, s4.y, s5.y), mix(s3.z, s4.z, s5.z)));
+        p = mk3(mix(s0.x, s1.x, s2.x), mix(s0.y, s1.y, s2.y), mix(s0.z, s1.z, s2.z));
+        const uint32_t    inst = a.scene.tri_ids[gid].x;
+        const MaterialDev m    = a.scene.materials[inst];
+        const v3    kd = mk3(m.kd[0], m.kd[1], m.kd[2]), ks = mk3(m.ks[0], m.ks[1], m.ks[2]), ke = mk3(m.ke[0], m.ke[1], m.ke[2]);
+        const float alpha = fmaxf(m.roughness * m.roughness, 1e-3f), a2 = alpha * alpha;
+        const v3    wo = mk3(-d.x, -d.y, -d.z);
+        const v3    nf = dot3(n, wo) < 0.0f ? mk3(-n.x, -n.y, -n.z) : n;
+        if (FIRST)
+        {
+            a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
+            a.planes.direct[plane_idx] = make_float4(ke.x, ke.y, ke.z, 1.f);
+            a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (slot == a.aov_slot)
+            {
+                float4 nd;
+                oct_encode(n, nd.x, nd.y);
+                nd.z = (float)inst;
+                nd.w = length3(mk3(a.cam.position[0], a.cam.position[1], a.cam.position[2]) - p);
+                a.planes.aov_normal_depth[pl] = nd;
+            }
+        }
+        // ---- next-event estimation: one point on the emissive triangles, uniform by area ----
+        if (a.scene.light_count != 0)
+        {
+            const float target = pre.r4 * a.scene.light_area;
+            uint32_t    lo = 0, hi = a.scene.light_count - 1;
+            while (lo < hi)  // first entry whose prefix sum exceeds target, else the last
+            {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a.scene.light_cdf[mid] > target) hi = mid; else lo = mid + 1;
+            }
+            const uint32_t lg = a.scene.light_tris[lo];
+            const float4*  lt = a.scene.shade_tris + 6 * (size_t)lg;
+            const float4   l0 = lt[0], l1 = lt[1], l2 = lt[2];
+            const v3       q0 = mk3(l0.x, l0.y, l0.z), q1 = mk3(l1.x, l1.y, l1.z), q2 = mk3(l2.x, l2.y, l2.z);
+            const float    su = sqrtf(pre.r5), b0 = 1.0f - su, b1 = su * (1.0f - pre.r6), b2 = su * pre.r6;
+            const v3 lp = mk3(fmaf(q2.x, b2, fmaf(q1.x, b1, q0.x * b0)), fmaf(q2.y, b2, fmaf(q1.y, b1, q0.y * b0)),
+                              fmaf(q2.z, b2, fmaf(q1.z, b1, q0.z * b0)));
+            const v3    nl = normalize3(cross3(q1 - q0, q2 - q0));
+            const v3    Lv = lp - p;
+            const float d2 = dot3(Lv, Lv), dist = sqrtf(d2);
+            const v3    wi = Lv * (1.0f / dist);
+            const float cos_s = dot3(nf, wi), cos_l = fabsf(dot3(nl, wi));
+            if (cos_s > 0.0f && cos_l > 0.0f && d2 > 0.0f)
+            {
+                const MaterialDev lm  = a.scene.materials[a.scene.tri_ids[lg].x];
+                const ExtBsdf     bs  = ext_bsdf(kd, ks, a2, nf, wo, wi);
+                const float       wgt = ((cos_s * cos_l) * a.scene.light_area) / d2;
+                const v3 c = mk3((thr.x * bs.f.x) * (lm.ke[0] * wgt), (thr.y * bs.f.y) * (lm.ke[1] * wgt), (thr.z * bs.f.z) * (lm.ke[2] * wgt));
+                if (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f)
+                {
+                    emit_shadow = true, contrib = c, sdir = wi, stmax = dist * 0.999f;
+                }
+            }
+        }
+        // ---- BSDF sampling: GGX half vector or cosine hemisphere, chosen by luminance ----
+        const float ls = lum3(ks), sum = lum3(kd) + ls;
+        if (sum > 0.0f)
+        {
+            const float ps = ls / sum;
+            v3          wi;
+            if (pre.r3 < ps)
+            {
+                const float c2 = (1.0f - pre.r2) / fmaf(a2 - 1.0f, pre.r2, 1.0f);
+                const float ct = sqrtf(c2), stt = sqrtf(fmaxf(0.0f, 1.0f - c2));
+                float       sp, cp;
+                sincos_c((2.0f * kPi) * pre.r1, sp, cp);
+                v3       uu = ortho_vector(nf);
+                const v3 vv = cross3(uu, nf);
+                uu          = cross3(nf, vv);
+                const float ca = stt * cp, cb = stt * sp;
+                const v3    hh = normalize3(mk3(fmaf(nf.x, ct, fmaf(vv.x, cb, uu.x * ca)), fmaf(nf.y, ct, fmaf(vv.y, cb, uu.y * ca)),
+                                                fmaf(nf.z, ct, fmaf(vv.z, cb, uu.z * ca))));
+                const float k2 = 2.0f * dot3(wo, hh);
+                wi = mk3(fmaf(hh.x, k2, -wo.x), fmaf(hh.y, k2, -wo.y), fmaf(hh.z, k2, -wo.z));
+            }
+            else
+                wi = map_to_hemisphere(pre.r1, pre.r2, nf);
+            const float cos_i = dot3(nf, wi);
+            if (cos_i > 0.0f)
+            {
+                const ExtBsdf bs  = ext_bsdf(kd, ks, a2, nf, wo, wi);
+                const float   pdf = ps * bs.pdf_spec + (1.0f - ps) * bs.pdf_diff;
+                if (pdf > 1e-8f)
+                {
+                    const float wgt = cos_i / pdf;
+                    thr      = mk3(thr.x * (bs.f.x * wgt), thr.y * (bs.f.y * wgt), thr.z * (bs.f.z * wgt));
+                    dir      = wi;
+                    emit_ext = a.bounce < a.num_bounces;
+                }
+            }
+        }
+    }
+    uint32_t ei, si;
+    wave_append2(emit_ext, emit_shadow, a.out.count + klass * kCounterStride, ei, si);
+    ei += klass * a.out.class_capacity;
+    si += klass * a.shadow.class_capacity;
+    if (emit_shadow)
+    {
+        a.shadow.org_tmin[si]    = make_float4(p.x, p.y, p.z, kRayEps);
+        a.shadow.dir_tmax[si]    = make_float4(sdir.x, sdir.y, sdir.z, stmax);
+        a.shadow.contrib_pid[si] = make_float4(contrib.x, contrib.y, contrib.z, u2f(pid));
+    }
+    if (emit_ext)
+    {
+        a.out.org_tmin[ei] = make_float4(p.x, p.y, p.z, kRayEps);
+        a.out.dir_tmax[ei] = make_float4(dir.x, dir.y, dir.z, kRayFar);
+        a.out.thr_pid[ei]  = make_float4(thr.x, thr.y, thr.z, u2f(pid));
+    }
+}
+
 // statistics: shaded vertices, one atomic per wave
 __device__ __forceinline__ void flush_shaded(uint64_t* counter, uint32_t n_shaded)
 {
@@ -942,7 +1136,7 @@ __device__ __forceinline__ void flush_shaded(uint64_t* counter, uint32_t n_shade
 }
 
 // Stand-alone shade stage (used with the LBVH stack traversal): consumes the hit records of the preceding trace kernel.
-template <bool FIRST>
+template <bool FIRST, bool EXT>
 __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
 {
     const uint32_t Ppad = a.screen.pixels_padded;
@@ -978,13 +1172,33 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
                 hit = a.hits[i];
             }
         }
-        const ShadePre pre = shade_prefetch(a, active, pid);
-        shade_vertex<FIRST>(a, pre, klass, pid, hit, thr, n_shaded);
+        const ShadePre pre = shade_prefetch<EXT>(a, active, pid);
+        if constexpr (EXT)
+        {
+            // the EXT BSDF depends on the incoming direction: the camera ray (bounce 0) or the queue entry's direction
+            v3 d = mk3(0.f, 0.f, 1.f);
+            if (active)
+            {
+                if (FIRST)
+                {
+                    uint32_t x, y;
+                    if (local_pixel_to_xy(a.screen, i, x, y)) d = primary_dir(a.cam, a.screen, a.frames[blockIdx.y], x, y);
+                }
+                else
+                {
+                    const float4 dq = a.in.dir_tmax[i];
+                    d               = mk3(dq.x, dq.y, dq.z);
+                }
+            }
+            shade_vertex_ext<FIRST>(a, pre, klass, pid, hit, thr, d, n_shaded);
+        }
+        else
+            shade_vertex<FIRST>(a, pre, klass, pid, hit, thr, n_shaded);
     }
     flush_shaded(a.shaded_counter, n_shaded);
 }
 
-void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args)
+void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext)
 {
     if (args.bounce == 0)
     {
@@ -992,19 +1206,22 @@ void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args)
         uint32_t       gx     = (chunks + 3) / 4;
         if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
         if (gx == 0) gx = 1;
-        hipLaunchKernelGGL(k_shade<true>, dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, args);
+        if (ext)
+            hipLaunchKernelGGL((k_shade<true, true>), dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, args);
+        else
+            hipLaunchKernelGGL((k_shade<true, false>), dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, args);
     }
+    else if (ext)
+        hipLaunchKernelGGL((k_shade<false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
     else
-    {
-        hipLaunchKernelGGL(k_shade<false>, dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
-    }
+        hipLaunchKernelGGL((k_shade<false, false>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
 }
 
 // Fused stage of the small-scene path: closest-hit (exhaustive, wave-uniform) + shading of the vertex it finds, in one pass over
 // the ray queue.  The hit record never travels through HBM and the shading stage's memory latency hides under the ALU-bound
 // triangle loop of the other waves.  FIRST generates the camera ray instead of reading a queue entry (rt_primary_visibility).
-template <bool FIRST>
-__global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_trace_shade(BvhDev bvh, ShadeArgs a)
+template <bool FIRST, bool EXT>
+__global__ __launch_bounds__(kBlock, EXT ? 4 : (FIRST ? 5 : 6)) void k_trace_shade(BvhDev bvh, ShadeArgs a)
 {
     const uint32_t Ppad     = a.screen.pixels_padded;
     const uint32_t chunks   = FIRST ? (Ppad >> 6) : (a.in.class_capacity >> 6) * kQueueClasses;
@@ -1037,7 +1254,7 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_trace_shade(BvhDev bv
                 thr = mk3(tp.x, tp.y, tp.z), pid = f2u(tp.w);
             }
         }
-        const ShadePre pre = shade_prefetch(a, active, pid);  // issued before the triangle loop: lands under its ALU work
+        const ShadePre pre = shade_prefetch<EXT>(a, active, pid);  // issued before the triangle loop: lands under its ALU work
         float          t, u, v;
         uint32_t       gid;
         exhaustive_closest(bvh, r, t, u, v, gid);
@@ -1052,12 +1269,15 @@ __global__ __launch_bounds__(kBlock, FIRST ? 5 : 6) void k_trace_shade(BvhDev bv
             }
             a.planes.aov_geo[i] = g;
         }
-        shade_vertex<FIRST>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded);
+        if constexpr (EXT)
+            shade_vertex_ext<FIRST>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
+        else
+            shade_vertex<FIRST>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded);
     }
     flush_shaded(a.shaded_counter, n_shaded);
 }
 
-void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args)
+void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, bool ext)
 {
     if (args.bounce == 0)
     {
@@ -1065,12 +1285,15 @@ void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs
         uint32_t       gx     = (chunks + 3) / 4;
         if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
         if (gx == 0) gx = 1;
-        hipLaunchKernelGGL(k_trace_shade<true>, dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, bvh, args);
+        if (ext)
+            hipLaunchKernelGGL((k_trace_shade<true, true>), dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, bvh, args);
+        else
+            hipLaunchKernelGGL((k_trace_shade<true, false>), dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, bvh, args);
     }
+    else if (ext)
+        hipLaunchKernelGGL((k_trace_shade<false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh, args);
     else
-    {
-        hipLaunchKernelGGL(k_trace_shade<false>, dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh, args);
-    }
+        hipLaunchKernelGGL((k_trace_shade<false, false>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh, args);
 }
 
 // ------------------------------------------------------------------------------------------------

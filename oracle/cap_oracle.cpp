@@ -343,6 +343,10 @@ struct Scene
     std::vector<Tri>            tris;       // global triangle order = mesh order, then primitive order
     std::vector<uint32_t>       bvh_order;  // triangle ids in leaf order
     std::vector<BvhNode>        nodes;
+    // EXT: emissive triangles in global triangle order, float prefix sums of their areas, total emissive area
+    std::vector<uint32_t>       light_tris;
+    std::vector<float>          light_cdf;
+    float                       light_area = 0.0f;
 };
 
 void build_bvh(Scene& sc)
@@ -686,14 +690,187 @@ void shade_pixel(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, ui
     set4(o->indirect, color.x, color.y, color.z, 1.0f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// EXT shading model (GGX, emissive triangles, next-event estimation).  No reference counterpart:
+// the specification is this code (DESIGN.md "EXT shading model"); the HIP path implements it independently.
+//   BSDF  f = kd/pi + ks * D_ggx(h) * G_smith(wo, wi) / (4 (n.wo)(n.wi)),  alpha = max(roughness^2, 1e-3), shading normal
+//         flipped towards wo;  lobe choice by luminance;  pdf = ps * D (n.h) / (4 wo.h) + (1 - ps) * (n.wi)/pi
+//   light emissive triangles sampled uniformly by area (float prefix sums in triangle order), one shadow ray per vertex;
+//         emission is seen directly only from the camera (bounce 0), every other vertex gets it through NEE
+//   rng   blue-noise texel of (pixel, frame*25+bounce): R,G -> BSDF direction, B -> lobe, A -> light triangle;
+//         texel of count+7: R,G -> point on the light.  Sky and the reference's directional light are off.
+// ---------------------------------------------------------------------------------------------
+void bluenoise4x4_rgba(const uint8_t* tex, uint32_t x, uint32_t y, uint32_t count, float out[4])
+{
+    uint32_t       px = (count % 16) % 4, py = (count % 16) / 4;
+    uint32_t       sx = (x * 4 + px) % 256, sy = (y * 4 + py) % 256;
+    const uint8_t* t  = tex + 4 * (sy * 256 + sx);
+    float          k  = 0.61803398875f * (float)(count / 16);
+    for (int c = 0; c < 4; ++c) out[c] = frac((float)t[c] / 255.0f + k);
+}
+
+inline float lum(f3 c) { return fmaf(c.z, 0.114f, fmaf(c.y, 0.587f, c.x * 0.299f)); }  // math_functions.h:25-28 weights
+
+struct ExtBsdf
+{
+    f3    f;
+    float pdf_spec, pdf_diff;
+};
+ExtBsdf ext_bsdf(f3 kd, f3 ks, float a2, f3 nf, f3 wo, f3 wi)
+{
+    float cos_o = dot(nf, wo), cos_i = dot(nf, wi);
+    f3    h     = normalize(wo + wi);
+    float cos_h = dot(nf, h), woh = dot(wo, h);
+    float dd    = fmaf(cos_h * cos_h, a2 - 1.0f, 1.0f);
+    float D     = a2 / (kPi * dd * dd);
+    float g_o   = (2.0f * cos_o) / (cos_o + sqrtf(fmaf(1.0f - a2, cos_o * cos_o, a2)));
+    float g_i   = (2.0f * cos_i) / (cos_i + sqrtf(fmaf(1.0f - a2, cos_i * cos_i, a2)));
+    float spec  = (D * (g_o * g_i)) / (4.0f * cos_o * cos_i);
+    ExtBsdf r;
+    r.f        = make3(kd.x * kInvPi + ks.x * spec, kd.y * kInvPi + ks.y * spec, kd.z * kInvPi + ks.z * spec);
+    r.pdf_spec = (D * cos_h) / (4.0f * woh);
+    r.pdf_diff = cos_i * kInvPi;
+    return r;
+}
+
+void tri_positions(const Scene& sc, uint32_t gid, f3* p0, f3* p1, f3* p2)
+{
+    const Tri&        tr   = sc.tris[gid];
+    const OracleMesh& mesh = sc.meshes[tr.inst];
+    const uint32_t*   ix   = &sc.indices[mesh.first_index_offset + 3 * tr.prim];
+    auto              P    = [&](uint32_t i) {
+        uint32_t v = mesh.first_vertex_offset + i;
+        return make3(sc.positions[3 * v], sc.positions[3 * v + 1], sc.positions[3 * v + 2]);
+    };
+    *p0 = P(ix[0]), *p1 = P(ix[1]), *p2 = P(ix[2]);
+}
+
+void shade_pixel_ext(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
+                     uint32_t frame_count, uint32_t num_bounces, bool use_bvh, PixelOut* o, uint64_t rays[3])
+{
+    f3 org, dir;
+    create_primary_ray(cam, x, y, w, h, frame_count, &org, &dir);
+    Hit hit = trace_closest(sc, org, dir, 0.0f, 1e6f, use_bvh);
+    ++rays[0];
+    auto set4 = [](float* d, float a, float b, float c, float e) { d[0] = a, d[1] = b, d[2] = c, d[3] = e; };
+    uint32_t inst = kInvalidId, prim = kInvalidId;
+    float    bu = 0.0f, bv = 0.0f;
+    if (hit.gid != kInvalidId) inst = sc.tris[hit.gid].inst, prim = sc.tris[hit.gid].prim, bu = hit.u, bv = hit.v;
+    o->geo[0] = bu, o->geo[1] = bv, o->geo[2] = as_float(inst), o->geo[3] = as_float(prim);
+    set4(o->albedo, 1, 1, 1, 1);
+    set4(o->nd, 0, 0, 0, 0);
+    f3 direct = make3(0, 0, 0), color = make3(0, 0, 0), thr = make3(1, 1, 1);
+    for (uint32_t bounce = 0; bounce <= num_bounces; ++bounce)
+    {
+        if (inst == kInvalidId) break;  // environment is black in the EXT model
+        f3    p, n;
+        float tx[2];
+        interpolate_attributes(sc, inst, prim, bu, bv, &p, &n, tx);
+        const OracleMaterial& m = sc.materials[inst];
+        f3    kd = make3(m.kd[0], m.kd[1], m.kd[2]), ks = make3(m.ks[0], m.ks[1], m.ks[2]), ke = make3(m.ke[0], m.ke[1], m.ke[2]);
+        float alpha = hmax(m.roughness * m.roughness, 1e-3f), a2 = alpha * alpha;
+        f3    wo = make3(-dir.x, -dir.y, -dir.z);
+        f3    nf = dot(n, wo) < 0.0f ? make3(-n.x, -n.y, -n.z) : n;
+        if (bounce == 0)
+        {
+            direct = ke;
+            float oct[2];
+            oct_encode(n, oct);
+            f3 cp = make3(cam.position[0], cam.position[1], cam.position[2]) - p;
+            set4(o->nd, oct[0], oct[1], (float)inst, length(cp));
+        }
+        float ra[4], rb[4];
+        bluenoise4x4_rgba(bn, x, y, frame_count * 25 + bounce, ra);
+        bluenoise4x4_rgba(bn, x, y, frame_count * 25 + bounce + 7, rb);
+        // ---- next-event estimation ----
+        if (!sc.light_tris.empty())
+        {
+            float  target = ra[3] * sc.light_area;
+            size_t j      = 0;
+            while (j + 1 < sc.light_tris.size() && !(sc.light_cdf[j] > target)) ++j;
+            uint32_t lg = sc.light_tris[j];
+            f3       q0, q1, q2;
+            tri_positions(sc, lg, &q0, &q1, &q2);
+            float su = sqrtf(rb[0]), b0 = 1.0f - su, b1 = su * (1.0f - rb[1]), b2 = su * rb[1];
+            f3    pl = make3(fmaf(q2.x, b2, fmaf(q1.x, b1, q0.x * b0)), fmaf(q2.y, b2, fmaf(q1.y, b1, q0.y * b0)),
+                             fmaf(q2.z, b2, fmaf(q1.z, b1, q0.z * b0)));
+            f3    nl = normalize(cross(q1 - q0, q2 - q0));
+            f3    Lv = pl - p;
+            float d2 = dot(Lv, Lv), dist = sqrtf(d2);
+            f3    wi = Lv * (1.0f / dist);
+            float cos_s = dot(nf, wi), cos_l = fabsf(dot(nl, wi));
+            if (cos_s > 0.0f && cos_l > 0.0f && d2 > 0.0f)
+            {
+                const OracleMaterial& lm = sc.materials[sc.tris[lg].inst];
+                ExtBsdf bs = ext_bsdf(kd, ks, a2, nf, wo, wi);
+                float   wgt = ((cos_s * cos_l) * sc.light_area) / d2;
+                f3      c = make3((thr.x * bs.f.x) * (lm.ke[0] * wgt), (thr.y * bs.f.y) * (lm.ke[1] * wgt), (thr.z * bs.f.z) * (lm.ke[2] * wgt));
+                if (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f)
+                {
+                    ++rays[2];
+                    if (!trace_any(sc, p, wi, 0.0001f, dist * 0.999f, use_bvh))
+                    {
+                        if (bounce == 0) direct = direct + c; else color = color + c;
+                    }
+                }
+            }
+        }
+        // ---- BSDF sampling ----
+        float ls = lum(ks), sum = lum(kd) + ls;
+        if (!(sum > 0.0f)) break;
+        float ps = ls / sum;
+        f3    wi;
+        if (ra[2] < ps)
+        {
+            float c2 = (1.0f - ra[1]) / fmaf(a2 - 1.0f, ra[1], 1.0f);
+            float ct = sqrtf(c2), st = sqrtf(hmax(0.0f, 1.0f - c2));
+            float sp, cp;
+            sincos_contract((2.0f * kPi) * ra[0], &sp, &cp);
+            f3 uu = ortho_vector(nf);
+            f3 vv = cross(uu, nf);
+            uu    = cross(nf, vv);
+            float a = st * cp, b = st * sp;
+            f3 hh = normalize(make3(fmaf(nf.x, ct, fmaf(vv.x, b, uu.x * a)), fmaf(nf.y, ct, fmaf(vv.y, b, uu.y * a)),
+                                    fmaf(nf.z, ct, fmaf(vv.z, b, uu.z * a))));
+            float k2 = 2.0f * dot(wo, hh);
+            wi = make3(fmaf(hh.x, k2, -wo.x), fmaf(hh.y, k2, -wo.y), fmaf(hh.z, k2, -wo.z));
+        }
+        else
+        {
+            float s2[2] = {ra[0], ra[1]};
+            wi = map_to_hemisphere(s2, nf);
+        }
+        float cos_i = dot(nf, wi);
+        if (!(cos_i > 0.0f)) break;
+        ExtBsdf bs  = ext_bsdf(kd, ks, a2, nf, wo, wi);
+        float   pdf = ps * bs.pdf_spec + (1.0f - ps) * bs.pdf_diff;
+        if (!(pdf > 1e-8f)) break;
+        float wgt = cos_i / pdf;
+        thr = make3(thr.x * (bs.f.x * wgt), thr.y * (bs.f.y * wgt), thr.z * (bs.f.z * wgt));
+        if (bounce == num_bounces) break;
+        dir = wi;
+        hit = trace_closest(sc, p, wi, 0.0001f, 100000.0f, use_bvh);
+        ++rays[1];
+        if (hit.gid != kInvalidId)
+            inst = sc.tris[hit.gid].inst, prim = sc.tris[hit.gid].prim, bu = hit.u, bv = hit.v;
+        else
+            inst = prim = kInvalidId;
+    }
+    set4(o->direct, direct.x, direct.y, direct.z, 1.0f);
+    set4(o->indirect, color.x, color.y, color.z, 1.0f);
+}
+
 void render_rows(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, uint32_t w, uint32_t h, uint32_t frame,
-                 uint32_t bounces, bool use_bvh, uint32_t row0, uint32_t row_step, OracleFrameOutputs* out, uint64_t rays[3])
+                 uint32_t bounces, bool use_bvh, bool ext, uint32_t row0, uint32_t row_step, OracleFrameOutputs* out, uint64_t rays[3])
 {
     for (uint32_t y = row0; y < h; y += row_step)
         for (uint32_t x = 0; x < w; ++x)
         {
             PixelOut po;
-            shade_pixel(sc, cam, bn, x, y, w, h, frame, bounces, use_bvh, &po, rays);
+            if (ext)
+                shade_pixel_ext(sc, cam, bn, x, y, w, h, frame, bounces, use_bvh, &po, rays);
+            else
+                shade_pixel(sc, cam, bn, x, y, w, h, frame, bounces, use_bvh, &po, rays);
             size_t i = 4 * ((size_t)y * w + x);
             if (out->gbuffer_geo) memcpy(out->gbuffer_geo + i, po.geo, 16);
             if (out->direct) memcpy(out->direct + i, po.direct, 16);
@@ -740,6 +917,17 @@ void* oracle_scene_create(const OracleScene* s)
             sc->tris.push_back(Tri{v[0], e1, e2, cross(e1, e2), mesh.index, k / 3});
         }
     }
+    if (!sc->materials.empty())
+        for (uint32_t g = 0; g < sc->tris.size(); ++g)
+        {
+            const OracleMaterial& m = sc->materials[sc->tris[g].inst];
+            if (m.ke[0] > 0.0f || m.ke[1] > 0.0f || m.ke[2] > 0.0f)
+            {
+                sc->light_area = sc->light_area + 0.5f * length(sc->tris[g].n);
+                sc->light_tris.push_back(g);
+                sc->light_cdf.push_back(sc->light_area);
+            }
+        }
     build_bvh(*sc);
     return sc;
 }
@@ -751,16 +939,17 @@ int oracle_render_frame(void* scene, const OracleCamera* cam, const uint8_t* bn,
                         OracleFrameOutputs* out)
 {
     if (!scene || !cam || !bn || !out || !w || !h) return 1;
-    if (flags & ORACLE_FLAG_EXT_MATERIALS) return 2;  // not implemented in this round
     const Scene& sc = *(const Scene*)scene;
     bool     bvh = (flags & ORACLE_FLAG_USE_BVH) != 0;
+    bool     ext = (flags & ORACLE_FLAG_EXT_MATERIALS) != 0;
+    if (ext && sc.materials.size() != sc.meshes.size()) return 2;  // EXT needs one material per mesh
     uint32_t nt  = std::max(1u, std::min(num_threads, h));
     std::vector<uint64_t> rays(3 * (size_t)nt, 0);
     std::vector<std::thread> th;
     for (uint32_t t = 1; t < nt; ++t)
-        th.emplace_back(render_rows, std::cref(sc), std::cref(*cam), bn, w, h, frame_count, num_bounces, bvh, t, nt, out,
+        th.emplace_back(render_rows, std::cref(sc), std::cref(*cam), bn, w, h, frame_count, num_bounces, bvh, ext, t, nt, out,
                         rays.data() + 3 * t);
-    render_rows(sc, *cam, bn, w, h, frame_count, num_bounces, bvh, 0, nt, out, rays.data());
+    render_rows(sc, *cam, bn, w, h, frame_count, num_bounces, bvh, ext, 0, nt, out, rays.data());
     for (auto& t : th) t.join();
     out->rays[0] = out->rays[1] = out->rays[2] = 0;
     for (uint32_t t = 0; t < nt; ++t)
