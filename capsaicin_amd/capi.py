@@ -49,6 +49,19 @@ class BvhInfo(C.Structure):
                 ("build_ms", C.c_double)]
 
 
+class PostSettings(C.Structure):
+    """SettingsComponent fields read by the reconstruction chain, reference src/systems/gui_system.h:20-37 (defaults below)."""
+    _fields_ = [("gather", C.c_int32), ("denoise", C.c_int32), ("eaw5", C.c_int32), ("eaw_normal_sigma", C.c_float),
+                ("eaw_depth_sigma", C.c_float), ("eaw_luma_sigma", C.c_float), ("gather_normal_sigma", C.c_float),
+                ("gather_depth_sigma", C.c_float), ("gather_luma_sigma", C.c_float), ("temporal_upscale_feedback", C.c_float),
+                ("taa_feedback", C.c_float)]
+
+    def __init__(self, **kw):
+        super().__init__(1, 1, 1, 128.0, 3.0, 3.0, 64.0, 2.0, 3.0, 0.975, 0.9)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
 class GeometryView(C.Structure):
     _fields_ = [("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)), ("texcoords", C.POINTER(C.c_float)),
                 ("indices", C.POINTER(C.c_uint32)), ("meshes", C.POINTER(C.c_uint32)), ("vertex_count", C.c_uint32),
@@ -84,6 +97,9 @@ SYMBOLS = {
     "cap_tile_buffer_floats": (_i, [_vp, C.POINTER(C.c_size_t)]),
     "cap_resolve_tiles": (_i, [_vp, _vp]),
     "cap_assemble_tiles": (_i, [_vp, _vp, _u32, _vp]),
+    "cap_post_frame": (_i, [_vp, C.POINTER(PostSettings), _u32, C.POINTER(CameraData)]),
+    "cap_post_reset": (_i, [_vp]),
+    "cap_post_readback": (_i, [_vp, _vp]),
     "cap_obj_load": (_i, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
     "cap_geometry_free": (None, [_vp]),
     "cap_geometry_view": (_i, [_vp, C.POINTER(GeometryView)]),
@@ -287,6 +303,19 @@ class Renderer:
 
     def stats_reset(self):
         _check(lib().cap_stats_reset(self.ctx), "cap_stats_reset")
+
+    # ---- reconstruction chain ----
+    def post_frame(self, settings, frame_count, prev_camera):
+        """Gather -> Accumulate -> Denoise -> Combine -> TAA on the last CAP_RENDER_AOV frame (raytracing_system.cpp:294-317)."""
+        _check(lib().cap_post_frame(self.ctx, C.byref(settings), frame_count, C.byref(prev_camera)), "cap_post_frame")
+
+    def post_reset(self):
+        _check(lib().cap_post_reset(self.ctx), "cap_post_reset")
+
+    def post_readback(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        _check(lib().cap_post_readback(self.ctx, _p(out)), "cap_post_readback")
+        return out
 
     # ---- multi-GPU tile exchange ----
     def tile_buffer_floats(self):

@@ -86,4 +86,27 @@ struct BvhBuildArgs
 };
 size_t bvh_radix_blocks(uint32_t n);
 void   launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a);
+
+// ---- reconstruction chain (post.hip): Gather -> Accumulate -> BlurDisocclusion -> Blur -> Combine -> TAA ----
+struct PostSettingsDev  // SettingsComponent subset, gui_system.h:20-37
+{
+    int   gather, denoise, eaw5;
+    float eaw_normal_sigma, eaw_depth_sigma, eaw_luma_sigma;
+    float gather_normal_sigma, gather_depth_sigma, gather_luma_sigma;
+    float temporal_upscale_feedback, taa_feedback;
+};
+struct PostChainArgs
+{
+    PostSettingsDev settings;
+    uint32_t        width, height, frame_count;
+    CameraDev       camera, prev_camera;
+    // this frame's ray-pass outputs, row-major W*H
+    const float4 *indirect, *direct, *albedo, *normal_depth;
+    // persistent state (raytracing_system.cpp:262-317)
+    float4 *indirect_history[2], *moments_history[2], *combined_history[2], *prev_normal_depth;
+    // scratch
+    float4 *indirect_temp, *temp[2];
+};
+// The frame's output is combined_history[frame_count % 2] (raytracing_system.cpp:320-324).
+void launch_post_chain(hipStream_t stream, const PostChainArgs& a);
 }  // namespace cap

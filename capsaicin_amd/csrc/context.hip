@@ -151,6 +151,12 @@ struct CapContext
     bool               aov_valid = false;
     uint64_t           frames_accumulated = 0;
 
+    // reconstruction chain (row-major W*H images)
+    DevBuf<float4> post_in[4];  // indirect, direct, albedo, normal_depth of the frame
+    DevBuf<float4> post_ihist[2], post_mhist[2], post_chist[2], post_prev_nd, post_itemp, post_temp[2];
+    uint32_t       post_w = 0, post_h = 0;
+    int            post_last_dst = -1;
+
     // statistics
     CapStats               stats{};
     std::vector<TimedSpan> spans;
@@ -677,6 +683,8 @@ int cap_set_resolution(CapContext* c, uint32_t width, uint32_t height)
     update_screen(c, width, height, c->screen.shard_index, c->screen.shard_count);
     if ((uint64_t)c->screen.pixels_padded > kPidMask) return fail(CAP_ERR_UNSUPPORTED, "too many pixels per shard");
     c->accum.release();
+    c->post_w = c->post_h = 0;  // histories restart at the next cap_post_frame
+    c->post_last_dst = -1;
     return CAP_OK;
 }
 
@@ -975,6 +983,68 @@ int cap_assemble_tiles(CapContext* c, const float* device_src, uint32_t shard_co
     LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
     launch_assemble(cfg, c->screen, reinterpret_cast<const float4*>(device_src), shard_count, reinterpret_cast<float4*>(device_image));
     HIP_TRY(hipGetLastError());
+    return CAP_OK;
+}
+
+int cap_post_reset(CapContext* c)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_post_reset: ctx is NULL");
+    if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_post_reset: resolution not set");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)c->screen.width * c->screen.height;
+    DevBuf<float4>* all[] = {&c->post_in[0],   &c->post_in[1],   &c->post_in[2],   &c->post_in[3],  &c->post_ihist[0], &c->post_ihist[1],
+                             &c->post_mhist[0], &c->post_mhist[1], &c->post_chist[0], &c->post_chist[1], &c->post_prev_nd, &c->post_itemp,
+                             &c->post_temp[0],  &c->post_temp[1]};
+    for (DevBuf<float4>* b : all)
+    {
+        HIP_TRY(b->ensure(npix));
+        HIP_TRY(hipMemsetAsync(b->p, 0, sizeof(float4) * npix, c->stream));  // the reference's textures start cleared
+    }
+    c->post_w = c->screen.width, c->post_h = c->screen.height;
+    c->post_last_dst = -1;
+    return CAP_OK;
+}
+
+int cap_post_frame(CapContext* c, const CapPostSettings* s, uint32_t frame_count, const CapCameraData* prev_camera)
+{
+    if (!c || !s || !prev_camera) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame: NULL argument");
+    if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_post_frame: resolution not set");
+    if (c->screen.shard_count != 1) return fail(CAP_ERR_UNSUPPORTED, "cap_post_frame: needs an unsharded context (shard_count is %u)", c->screen.shard_count);
+    if (!c->aov_valid) return fail(CAP_ERR_STATE, "cap_post_frame: no frame rendered with CAP_RENDER_AOV");
+    if (!(s->eaw_luma_sigma > 0.0f) || !(s->gather_luma_sigma > 0.0f)) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame: luma sigmas must be > 0");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->post_w != c->screen.width || c->post_h != c->screen.height)
+        if (int e = cap_post_reset(c)) return e;
+    const uint32_t Ppad = c->screen.pixels_padded;
+    const size_t   off  = (size_t)(c->last_slots ? c->last_slots - 1 : 0) * Ppad;
+    LaunchCfg      cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
+    launch_untile(cfg, c->screen, c->pl_color.p + off, nullptr, nullptr, 0, c->post_in[0].p);
+    launch_untile(cfg, c->screen, c->pl_direct.p + off, nullptr, nullptr, 0, c->post_in[1].p);
+    launch_untile(cfg, c->screen, c->pl_albedo.p + off, nullptr, nullptr, 0, c->post_in[2].p);
+    launch_untile(cfg, c->screen, c->aov_nd.p, nullptr, nullptr, 0, c->post_in[3].p);
+    PostChainArgs a{};
+    a.settings = PostSettingsDev{s->gather, s->denoise, s->eaw5, s->eaw_normal_sigma, s->eaw_depth_sigma, s->eaw_luma_sigma, s->gather_normal_sigma,
+                                 s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback};
+    a.width = c->screen.width, a.height = c->screen.height, a.frame_count = frame_count;
+    a.camera = camera_dev(c->camera), a.prev_camera = camera_dev(*prev_camera);
+    a.indirect = c->post_in[0].p, a.direct = c->post_in[1].p, a.albedo = c->post_in[2].p, a.normal_depth = c->post_in[3].p;
+    for (int k = 0; k < 2; ++k)
+        a.indirect_history[k] = c->post_ihist[k].p, a.moments_history[k] = c->post_mhist[k].p, a.combined_history[k] = c->post_chist[k].p,
+        a.temp[k] = c->post_temp[k].p;
+    a.prev_normal_depth = c->post_prev_nd.p, a.indirect_temp = c->post_itemp.p;
+    launch_post_chain(c->stream, a);
+    HIP_TRY(hipGetLastError());
+    c->post_last_dst = (int)(frame_count % 2);
+    return CAP_OK;
+}
+
+int cap_post_readback(CapContext* c, float* dst)
+{
+    if (!c || !dst) return fail(CAP_ERR_INVALID_ARG, "cap_post_readback: NULL argument");
+    if (c->post_last_dst < 0) return fail(CAP_ERR_STATE, "cap_post_readback: cap_post_frame has not run");
+    HIP_TRY(hipSetDevice(c->device));
+    if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
+    HIP_TRY(hipMemcpy(dst, c->post_chist[c->post_last_dst].p, sizeof(float4) * (size_t)c->post_w * c->post_h, hipMemcpyDeviceToHost));
     return CAP_OK;
 }
 }

@@ -194,6 +194,36 @@ int cap_resolve_tiles(CapContext* ctx, float* device_dst);
 /* device_src: shard_count tile buffers back to back (the gather result); device_image: width*height*4 floats */
 int cap_assemble_tiles(CapContext* ctx, const float* device_src, uint32_t shard_count, float* device_image);
 
+/* ---- reconstruction chain ----
+ * The passes RaytracingSystem::Run records after the ray passes (raytracing_system.cpp:294-317):
+ * SpatialGather (cpp:1541-1604) -> IntegrateTemporally (cpp:1283-1342) -> Denoise = BlurDisocclusion + 2|4 a-trous blurs
+ * (cpp:1437-1538) -> CombineIllumination (cpp:1400-1435) -> ApplyTAA (cpp:1344-1398), full-resolution configuration.
+ * Settings = the SettingsComponent fields those passes read (gui_system.h:20-37, defaults in comments). */
+typedef struct CapPostSettings
+{
+    int32_t gather;                    /* true  */
+    int32_t denoise;                   /* true  */
+    int32_t eaw5;                      /* true  */
+    float   eaw_normal_sigma;          /* 128   */
+    float   eaw_depth_sigma;           /* 3     */
+    float   eaw_luma_sigma;            /* 3     */
+    float   gather_normal_sigma;       /* 64    */
+    float   gather_depth_sigma;        /* 2     */
+    float   gather_luma_sigma;         /* 3     */
+    float   temporal_upscale_feedback; /* 0.975 */
+    float   taa_feedback;              /* 0.9   */
+} CapPostSettings;
+/* Runs the chain on the planes of the last frame rendered with CAP_RENDER_AOV (frame_count = that frame's index; the
+ * camera is the one set for it; prev_camera = the previous frame's, CameraComponent/prev_camera of
+ * temporal_accumulation.hlsl:10-11) and keeps the histories for the next call.  Needs an unsharded context: the stencils read
+ * across tile borders.  Asynchronous on the context stream.  The result (current_frame_output(), cpp:320-324) is read with
+ * cap_post_readback. */
+int cap_post_frame(CapContext* ctx, const CapPostSettings* settings, uint32_t frame_count, const CapCameraData* prev_camera);
+/* zero-fills the histories (a new sequence; also implied by cap_set_resolution) */
+int cap_post_reset(CapContext* ctx);
+/* dst: width*height*4 floats (host) */
+int cap_post_readback(CapContext* ctx, float* dst);
+
 #ifdef __cplusplus
 }
 #endif

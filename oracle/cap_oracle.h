@@ -118,6 +118,31 @@ int oracle_render_accumulate(void* scene, const OracleCamera* cam, const uint8_t
                              uint32_t height, uint32_t frame_begin, uint32_t n_frames, uint32_t num_bounces,
                              uint32_t flags, uint32_t num_threads, float* accum, uint64_t rays[3]);
 
+/* ---- reconstruction chain, cap_oracle_post.cpp ---- */
+/* SettingsComponent subset, gui_system.h:20-37 (defaults in comments) */
+typedef struct OraclePostSettings
+{
+    int   gather;                    /* true  */
+    int   denoise;                   /* true  */
+    int   eaw5;                      /* true  */
+    float eaw_normal_sigma;          /* 128   */
+    float eaw_depth_sigma;           /* 3     */
+    float eaw_luma_sigma;            /* 3     */
+    float gather_normal_sigma;       /* 64    */
+    float gather_depth_sigma;        /* 2     */
+    float gather_luma_sigma;         /* 3     */
+    float temporal_upscale_feedback; /* 0.975 */
+    float taa_feedback;              /* 0.9   */
+} OraclePostSettings;
+
+void* oracle_post_create(uint32_t width, uint32_t height);
+void  oracle_post_destroy(void* chain);
+/* One frame of Gather -> Accumulate -> BlurDisocclusion -> Blur x2|x4 -> Combine -> TAA on this frame's ray-pass outputs
+ * (all W*H*4 floats); writes current_frame_output() (raytracing_system.cpp:320-324) to out and keeps the histories. */
+int oracle_post_frame(void* chain, const OraclePostSettings* settings, uint32_t frame_count, const OracleCamera* camera,
+                      const OracleCamera* prev_camera, const float* indirect, const float* direct, const float* albedo,
+                      const float* normal_depth, float* out);
+
 /* ---- pure functions (known-answer tests) ---- */
 void     oracle_halton23(uint32_t frame_count, float out[2]);                                   /* sampling.h:143-155 */
 uint32_t oracle_wang_hash(uint32_t x, uint32_t y);                                              /* sampling.h:37-46 */

@@ -29,13 +29,26 @@ class FrameOutputs(C.Structure):
                 ("indirect", C.c_void_p), ("combined", C.c_void_p), ("rays", C.c_uint64 * 3)]
 
 
+class PostSettings(C.Structure):
+    """SettingsComponent subset with the reference defaults (gui_system.h:20-37)."""
+    _fields_ = [("gather", C.c_int), ("denoise", C.c_int), ("eaw5", C.c_int), ("eaw_normal_sigma", C.c_float),
+                ("eaw_depth_sigma", C.c_float), ("eaw_luma_sigma", C.c_float), ("gather_normal_sigma", C.c_float),
+                ("gather_depth_sigma", C.c_float), ("gather_luma_sigma", C.c_float), ("temporal_upscale_feedback", C.c_float),
+                ("taa_feedback", C.c_float)]
+
+    def __init__(self, **kw):
+        super().__init__(1, 1, 1, 128.0, 3.0, 3.0, 64.0, 2.0, 3.0, 0.975, 0.9)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
 FLAG_USE_BVH = 1
 FLAG_EXT_MATERIALS = 2
 
 
 def build(force=False):
     so = os.path.join(_HERE, "libcap_oracle.so")
-    src = [os.path.join(_HERE, f) for f in ("cap_oracle.cpp", "cap_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("cap_oracle.cpp", "cap_oracle_post.cpp", "cap_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libcap_oracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -50,6 +63,10 @@ def lib():
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
         L.oracle_render_frame.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_uint32] * 6 + [C.POINTER(FrameOutputs)]
         L.oracle_render_accumulate.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p, C.c_void_p]
+        L.oracle_post_create.restype = C.c_void_p
+        L.oracle_post_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.oracle_post_destroy.argtypes = [C.c_void_p]
+        L.oracle_post_frame.argtypes = [C.c_void_p, C.POINTER(PostSettings), C.c_uint32, C.POINTER(Camera), C.POINTER(Camera)] + [C.c_void_p] * 5
         L.oracle_wang_hash.restype = C.c_uint32
         L.oracle_wang_hash.argtypes = [C.c_uint32, C.c_uint32]
         L.oracle_pow22.restype = C.c_float
@@ -136,6 +153,28 @@ class Scene:
         if rc:
             raise RuntimeError("oracle_render_accumulate rc=%d" % rc)
         return acc, tuple(int(x) for x in rays)
+
+
+class PostChain:
+    """History-carrying reconstruction chain (Gather .. TAA) of the oracle."""
+
+    def __init__(self, width, height):
+        self.w, self.h = width, height
+        self.handle = lib().oracle_post_create(width, height)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().oracle_post_destroy(self.handle)
+            self.handle = None
+
+    def frame(self, settings, frame_count, cam, prev_cam, planes):
+        a = [np.ascontiguousarray(planes[k], np.float32) for k in ("indirect", "direct", "albedo", "normal_depth")]
+        out = np.zeros((self.h, self.w, 4), np.float32)
+        rc = lib().oracle_post_frame(self.handle, C.byref(settings), frame_count, C.byref(cam), C.byref(prev_cam), _p(a[0]), _p(a[1]),
+                                     _p(a[2]), _p(a[3]), _p(out))
+        if rc:
+            raise RuntimeError("oracle_post_frame rc=%d" % rc)
+        return out
 
 
 # ---- pure functions ----

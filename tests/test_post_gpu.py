@@ -1,0 +1,94 @@
+"""Reconstruction chain (Gather -> Accumulate -> BlurDisocclusion -> Blur -> Combine -> TAA) on the GPU against
+the oracle's chain (oracle/cap_oracle_post.cpp), bit for bit, frame after frame with the histories carried along."""
+import numpy as np
+import pytest
+
+from capsaicin_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def ocam_of(O, cam):
+    return O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1],
+                         cam.focal_length)
+
+
+def moved(cam, dx, dy, dz):
+    c = capi.CameraData.from_buffer_copy(bytes(cam))
+    c.position[0] += dx
+    c.position[1] += dy
+    c.position[2] += dz
+    return c
+
+
+@pytest.mark.parametrize("settings", [dict(), dict(gather=0, eaw5=0), dict(denoise=0), dict(eaw_luma_sigma=1.5, gather_normal_sigma=16.0)])
+def test_post_chain_parity_cornell(native_lib, bluenoise, cornell_path, settings):
+    from oracle import cap_oracle as O
+    w, h, D = 150, 101, 2  # not multiples of the 32x8 workgroup footprint or the 8x8 render tiles
+    geo = capi.Geometry(cornell_path)
+    r = capi.Renderer(0)
+    r.upload_geometry(geo)
+    r.upload_bluenoise(bluenoise)
+    r.build_bvh()
+    r.set_resolution(w, h)
+    sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes)
+    chain = O.PostChain(w, h)
+    base = capi.cornell_camera(w, h)
+    # static for four frames, then a dolly/strafe (reprojection, disocclusion at the box edges, the non-static TAA branch)
+    cams = [base] * 4 + [moved(base, 0.02 * k, 0.01 * k, -0.03 * k) for k in range(1, 4)] + [moved(base, 0.06, 0.03, -0.09)] * 2
+    gs, os_ = capi.PostSettings(**settings), O.PostSettings(**settings)
+    prev = cams[0]
+    for f, cam in enumerate(cams):
+        r.set_camera(cam)
+        r.render(f, 1, D, capi.RENDER_AOV)
+        r.post_frame(gs, f, prev)
+        got = r.post_readback()
+        ref = sc.render_frame(ocam_of(O, cam), bluenoise, w, h, f, D, threads=8)
+        want = chain.frame(os_, f, ocam_of(O, cam), ocam_of(O, prev), ref)
+        assert np.all(np.isfinite(got))
+        nbad = int((bits(got) != bits(want)).any(-1).sum())
+        assert nbad == 0, "frame %d (%s): %d pixels differ, max abs %g" % (f, settings, nbad, float(np.abs(got - want).max()))
+        prev = cam
+    # the denoised image is smoother than the raw one-sample frame but keeps its mean
+    raw = ref["combined"][..., :3]
+    assert abs(float(got[..., :3].mean()) - float(raw.mean())) < 0.1 * float(raw.mean()) + 0.02
+    r.close()
+
+
+def test_post_chain_reset_and_errors(native_lib, bluenoise, cornell_path):
+    w, h = 64, 48
+    r = capi.Renderer(0)
+    r.upload_geometry(capi.Geometry(cornell_path))
+    r.upload_bluenoise(bluenoise)
+    r.build_bvh()
+    r.set_resolution(w, h)
+    cam = capi.cornell_camera(w, h)
+    r.set_camera(cam)
+    s = capi.PostSettings()
+    with pytest.raises(capi.CapError, match="CAP_RENDER_AOV"):
+        r.post_frame(s, 0, cam)
+    with pytest.raises(capi.CapError, match="has not run"):
+        r.post_readback()
+    r.render(0, 1, 1, capi.RENDER_AOV)
+    with pytest.raises(capi.CapError, match="luma"):
+        r.post_frame(capi.PostSettings(eaw_luma_sigma=0.0), 0, cam)
+    r.post_frame(s, 0, cam)
+    first = r.post_readback()
+    r.render(1, 1, 1, capi.RENDER_AOV)
+    r.post_frame(s, 1, cam)
+    second = r.post_readback()
+    assert not np.array_equal(first, second)
+    # a reset sequence reproduces the first frame exactly
+    r.post_reset()
+    r.render(0, 1, 1, capi.RENDER_AOV)
+    r.post_frame(s, 0, cam)
+    assert np.array_equal(bits(r.post_readback()), bits(first))
+    r.set_shard(0, 2)
+    r.render(0, 1, 1, capi.RENDER_AOV)
+    with pytest.raises(capi.CapError, match="unsharded"):
+        r.post_frame(s, 0, cam)
+    r.close()
