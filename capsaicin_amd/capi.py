@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_PKG, "libcapsaicin_hip.so")
 RENDER_AOV = 1
 RENDER_EXT_MATERIALS = 2
 RENDER_STAGE_TIMERS = 4
+RENDER_GBUFFER_FEEDBACK = 8
 
 BUF_GBUFFER_GEO, BUF_DIRECT, BUF_ALBEDO, BUF_NORMAL_DEPTH, BUF_INDIRECT, BUF_COMBINED, BUF_ACCUM_SUM, BUF_ACCUM_MEAN = range(8)
 
@@ -84,6 +85,7 @@ SYMBOLS = {
     "cap_bvh_info": (_i, [_vp, C.POINTER(BvhInfo)]),
     "cap_bvh_readback": (_i, [_vp, _vp, _vp]),
     "cap_camera_set": (_i, [_vp, C.POINTER(CameraData)]),
+    "cap_prev_camera_set": (_i, [_vp, C.POINTER(CameraData)]),
     "cap_set_resolution": (_i, [_vp, _u32, _u32]),
     "cap_set_shard": (_i, [_vp, _u32, _u32]),
     "cap_set_batch_paths": (_i, [_vp, _u64]),
@@ -266,6 +268,9 @@ class Renderer:
     # ---- view ----
     def set_camera(self, cam):
         _check(lib().cap_camera_set(self.ctx, C.byref(cam)), "cap_camera_set")
+
+    def set_prev_camera(self, cam):
+        _check(lib().cap_prev_camera_set(self.ctx, C.byref(cam)), "cap_prev_camera_set")
 
     def set_resolution(self, width, height):
         _check(lib().cap_set_resolution(self.ctx, width, height), "cap_set_resolution")

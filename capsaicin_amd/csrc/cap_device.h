@@ -64,6 +64,15 @@ struct CameraDev
     float up[3], pad;
 };
 
+// Inputs of the G-buffer feedback branch (rt_indirect.hlsl:116-145): the previous frame's camera, normal/depth G-buffer and
+// TAA'd output, row-major width*height images owned by the reconstruction chain.
+struct FeedbackDev
+{
+    CameraDev     prev_cam;
+    const float4* prev_normal_depth;
+    const float4* color_history;
+};
+
 // Screen decomposition of one context (shard): local pixel index pl = local_tile * 64 + (y_in_tile * 8 + x_in_tile),
 // global tile = local_tile * shard_count + shard_index, tiles are numbered row-major over the 8x8 tile grid.
 struct ScreenDev

@@ -42,10 +42,13 @@ struct ShadeArgs
     uint32_t          max_count;   // upper bound of the input queue length
     uint32_t          aov_slot;    // frame slot whose AOVs are kept, or ~0u
     uint64_t*         shaded_counter;
+    FeedbackDev       fb;          // read only by the feedback variants
 };
-void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext);
+// feedback: vertices of bounce >= 1 that the previous frame saw take its shaded colour and end the path (rt_indirect.hlsl:116-145;
+// reference shading model only)
+void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext, bool feedback = false);
 // small-scene path: exhaustive closest hit fused with the shading of the vertex found (bounce 0 generates the camera rays)
-void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, bool ext);
+void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, bool ext, bool feedback = false);
 
 // ---- accumulate / exchange ----
 // accum[pl] += sum over slots (in slot order) of color*albedo + direct; .w counts frames.

@@ -134,8 +134,8 @@ struct CapContext
     bool             bvh_ready = false;
 
     // camera / screen
-    CapCameraData camera{};
-    bool          camera_ready = false;
+    CapCameraData camera{}, prev_camera{};
+    bool          camera_ready = false, prev_camera_ready = false;
     ScreenDev     screen{};
     uint64_t      max_batch_paths = 0;
     uint32_t      traversal_mode  = CAP_TRAVERSAL_AUTO;
@@ -674,6 +674,14 @@ int cap_camera_set(CapContext* c, const CapCameraData* camera)
     return CAP_OK;
 }
 
+int cap_prev_camera_set(CapContext* c, const CapCameraData* camera)
+{
+    if (!c || !camera) return fail(CAP_ERR_INVALID_ARG, "cap_prev_camera_set: NULL argument");
+    c->prev_camera       = *camera;
+    c->prev_camera_ready = true;
+    return CAP_OK;
+}
+
 int cap_set_resolution(CapContext* c, uint32_t width, uint32_t height)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_resolution: ctx is NULL");
@@ -741,6 +749,17 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     if (num_bounces > 255) return fail(CAP_ERR_INVALID_ARG, "cap_render: num_bounces %u exceeds 255", num_bounces);
     if (!n_frames) return CAP_OK;
     HIP_TRY(hipSetDevice(c->device));
+    const bool feedback = (flags & CAP_RENDER_GBUFFER_FEEDBACK) != 0;
+    if (feedback)
+    {
+        // the branch reads the previous frame's reconstruction output: one frame per call, the whole image on this context
+        if (ext) return fail(CAP_ERR_UNSUPPORTED, "cap_render: CAP_RENDER_GBUFFER_FEEDBACK is defined for the reference shading model only");
+        if (n_frames != 1) return fail(CAP_ERR_INVALID_ARG, "cap_render: CAP_RENDER_GBUFFER_FEEDBACK renders one frame per call (n_frames is %u)", n_frames);
+        if (c->screen.shard_count != 1) return fail(CAP_ERR_UNSUPPORTED, "cap_render: CAP_RENDER_GBUFFER_FEEDBACK needs an unsharded context");
+        if (!c->prev_camera_ready) return fail(CAP_ERR_STATE, "cap_render: CAP_RENDER_GBUFFER_FEEDBACK needs cap_prev_camera_set");
+        if (c->post_w != c->screen.width || c->post_h != c->screen.height)
+            if (int e = cap_post_reset(c)) return e;  // first frame: cleared histories, every vertex is a disocclusion
+    }
 
     const uint32_t Ppad = c->screen.pixels_padded;
     uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)8 << 20;
@@ -805,6 +824,8 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         sa.scene = scene, sa.cam = cam, sa.screen = c->screen, sa.frames = frames, sa.hits = c->hits.p;
         sa.planes = Planes{c->pl_color.p, c->pl_direct.p, c->pl_albedo.p, c->aov_geo.p, c->aov_nd.p};
         sa.n_slots = ns, sa.num_bounces = D, sa.max_count = max_count, sa.aov_slot = aov_slot, sa.shaded_counter = c->shaded_counter.p;
+        if (feedback)  // g_color_history = combined_history[(frame_count + 1) % 2], raytracing_system.cpp:1754-1759
+            sa.fb = FeedbackDev{camera_dev(c->prev_camera), c->post_prev_nd.p, c->post_chist[(frame_begin + 1) % 2].p};
         const bool fused = cfg.stack_entries == 0;  // small-scene path: closest hit and shading in one kernel per bounce
         // CAP_TRACE_LAUNCHES=1: name every launch on stderr and drain the stream after it (fault localisation only)
         static const bool trace_launches = getenv("CAP_TRACE_LAUNCHES") != nullptr;
@@ -835,14 +856,14 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             if (fused)
             {
                 StageTimer t(c, b == 0 ? ST_PRIMARY : ST_CLOSEST, st);
-                launch_trace_shade(cfg, bvh, sa, ext);
+                launch_trace_shade(cfg, bvh, sa, ext, feedback);
                 if (b) ++c->stats.launches_trace_closest;
                 if (traced("trace_shade", b)) return fail(CAP_ERR_HIP, "trace_shade failed");
             }
             else
             {
                 StageTimer t(c, ST_SHADE, st);
-                launch_shade(cfg, sa, ext);
+                launch_shade(cfg, sa, ext, feedback);
                 ++c->stats.launches_shade;
             }
             {

@@ -6,6 +6,7 @@
 // The DXR TraceRay / acceleration structure (driver code in the reference) is replaced by the explicit
 // traversal below.  No MFMA: nothing here is a dense contraction.
 #include "cap_kernels.h"
+#include "cap_reproject.h"
 
 namespace cap
 {
@@ -807,7 +808,7 @@ __device__ __forceinline__ void wave_append2(bool emit_ext, bool emit_shadow, ui
     shadow_slot = hi + (uint32_t)__popcll(ms & below);
 }
 
-template <bool FIRST>
+template <bool FIRST, bool FB = false>
 __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const ShadePre& pre, uint32_t klass, uint32_t pid, float4 hit, v3 thr,
                                              uint32_t& n_shaded)
 {
@@ -898,7 +899,32 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const ShadePre&
                     a.planes.aov_normal_depth[pl] = nd;
                 }
             }
-            if (!black)
+            bool reused = false;
+            if (FB && !FIRST && !black)
+            {
+                // rt_indirect.hlsl:116-145 GBUFFER_FEEDBACK: a vertex the previous frame saw (inside its image, depth within 5 %)
+                // takes that frame's shaded, TAA'd colour and ends the path.  A NaN uv counts as disocclusion (stated choice:
+                // HLSL's any(uv < 0) || any(uv > 1) would let it through to an undefined texel address).
+                const uint32_t W = a.screen.width, H = a.screen.height;
+                const f2       puv = image_plane_uv(a.fb.prev_cam, p);
+                if (puv.x >= 0.0f && puv.y >= 0.0f && puv.x <= 1.0f && puv.y <= 1.0f)
+                {
+                    const f2    pxy        = uv_to_xy(puv, W, H);
+                    const float prev_depth = ldi(Img{a.fb.prev_normal_depth, W, H}, (int)pxy.x, (int)pxy.y).w;
+                    const float cur_depth =
+                        length3(p - mk3(a.fb.prev_cam.position[0], a.fb.prev_cam.position[1], a.fb.prev_cam.position[2]));
+                    if (!(fabsf(prev_depth - cur_depth) / cur_depth > 0.05f))
+                    {
+                        reused        = true;
+                        const v3 hc   = sample_bilinear(Img{a.fb.color_history, W, H}, puv);
+                        float*   c    = reinterpret_cast<float*>(a.planes.color + plane_idx);
+                        atomicAdd(c + 0, thr.x * hc.x);
+                        atomicAdd(c + 1, thr.y * hc.y);
+                        atomicAdd(c + 2, thr.z * hc.z);
+                    }
+                }
+            }
+            if (!black && !reused)
             {
                 // lighting.h:35-61: unshadowed direct term; the visibility ray is queued for the any-hit kernel
                 const float ndl = fmaxf(0.0f, dot3(n, pre.L));
@@ -1136,7 +1162,7 @@ __device__ __forceinline__ void flush_shaded(uint64_t* counter, uint32_t n_shade
 }
 
 // Stand-alone shade stage (used with the LBVH stack traversal): consumes the hit records of the preceding trace kernel.
-template <bool FIRST, bool EXT>
+template <bool FIRST, bool EXT, bool FB = false>
 __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
 {
     const uint32_t Ppad = a.screen.pixels_padded;
@@ -1193,12 +1219,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
             shade_vertex_ext<FIRST>(a, pre, klass, pid, hit, thr, d, n_shaded);
         }
         else
-            shade_vertex<FIRST>(a, pre, klass, pid, hit, thr, n_shaded);
+            shade_vertex<FIRST, FB>(a, pre, klass, pid, hit, thr, n_shaded);
     }
     flush_shaded(a.shaded_counter, n_shaded);
 }
 
-void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext)
+void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext, bool feedback)
 {
     if (args.bounce == 0)
     {
@@ -1213,6 +1239,8 @@ void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext)
     }
     else if (ext)
         hipLaunchKernelGGL((k_shade<false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
+    else if (feedback)
+        hipLaunchKernelGGL((k_shade<false, false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
     else
         hipLaunchKernelGGL((k_shade<false, false>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
 }
@@ -1220,8 +1248,8 @@ void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext)
 // Fused stage of the small-scene path: closest-hit (exhaustive, wave-uniform) + shading of the vertex it finds, in one pass over
 // the ray queue.  The hit record never travels through HBM and the shading stage's memory latency hides under the ALU-bound
 // triangle loop of the other waves.  FIRST generates the camera ray instead of reading a queue entry (rt_primary_visibility).
-template <bool FIRST, bool EXT>
-__global__ __launch_bounds__(kBlock, EXT ? 4 : (FIRST ? 5 : 6)) void k_trace_shade(BvhDev bvh, ShadeArgs a)
+template <bool FIRST, bool EXT, bool FB = false>
+__global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? 5 : 6)) void k_trace_shade(BvhDev bvh, ShadeArgs a)
 {
     const uint32_t Ppad     = a.screen.pixels_padded;
     const uint32_t chunks   = FIRST ? (Ppad >> 6) : (a.in.class_capacity >> 6) * kQueueClasses;
@@ -1272,12 +1300,12 @@ __global__ __launch_bounds__(kBlock, EXT ? 4 : (FIRST ? 5 : 6)) void k_trace_sha
         if constexpr (EXT)
             shade_vertex_ext<FIRST>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
         else
-            shade_vertex<FIRST>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded);
+            shade_vertex<FIRST, FB>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded);
     }
     flush_shaded(a.shaded_counter, n_shaded);
 }
 
-void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, bool ext)
+void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, bool ext, bool feedback)
 {
     if (args.bounce == 0)
     {
@@ -1292,6 +1320,9 @@ void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs
     }
     else if (ext)
         hipLaunchKernelGGL((k_trace_shade<false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh, args);
+    else if (feedback)
+        hipLaunchKernelGGL((k_trace_shade<false, false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh,
+                           args);
     else
         hipLaunchKernelGGL((k_trace_shade<false, false>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh, args);
 }

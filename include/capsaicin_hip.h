@@ -73,7 +73,11 @@ enum
 {
     CAP_RENDER_AOV           = 1u << 0, /* keep the per-frame planes of the LAST frame for cap_readback */
     CAP_RENDER_EXT_MATERIALS = 1u << 1, /* EXT shading model (materials uploaded with cap_materials_upload) */
-    CAP_RENDER_STAGE_TIMERS  = 1u << 2  /* bracket every kernel with hipEvents (fills CapStats::ms_<stage>) */
+    CAP_RENDER_STAGE_TIMERS  = 1u << 2, /* bracket every kernel with hipEvents (fills CapStats::ms_<stage>) */
+    /* RaytracingOptions::gbuffer_feedback (raytracing_system.h:26, rt_indirect.hlsl:116-145): a path vertex of bounce >= 1
+     * that the previous frame saw takes that frame's cap_post_frame output and ends the path.  One frame per call, unsharded
+     * context, reference shading model; needs cap_prev_camera_set and cap_post_frame after every frame. */
+    CAP_RENDER_GBUFFER_FEEDBACK = 1u << 3
 };
 
 /* cap_readback kinds: the reference's RaytracingSystem outputs (raytracing_system.h, cpp:466-575). */
@@ -156,6 +160,8 @@ int cap_bvh_readback(CapContext* ctx, float* nodes, uint32_t* leaf_triangles);
 /* CameraSystem::Run upload (camera_system.cpp:89-131). sensor_size is used as given (the caller applies
  * AdjustCameraAspectBasedOnWindow, camera_system.cpp:10-17). */
 int cap_camera_set(CapContext* ctx, const CapCameraData* camera);
+/* CameraComponent::prev_camera_buffer (camera_system.cpp:89-131; bound as g_prev_camera, raytracing_system.cpp:1227-1228) */
+int cap_prev_camera_set(CapContext* ctx, const CapCameraData* camera);
 /* RenderSystem::window_width/height (render_system.h) */
 int cap_set_resolution(CapContext* ctx, uint32_t width, uint32_t height);
 /* Screen-tile sharding: this context renders the 8x8 tiles t with t % shard_count == shard_index. */

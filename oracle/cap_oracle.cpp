@@ -606,8 +606,56 @@ f3 direct_illumination(const Scene& sc, const LightSample& ls, f3 p, f3 n, f3 kd
     return c;
 }
 
+// ---- G-buffer feedback inputs (rt_indirect.hlsl:23, 34-35, 116-145) and the helpers the branch calls ----
+struct Feedback
+{
+    OracleCamera prev_cam;
+    const float* prev_normal_depth;  // W*H*4, the previous frame's gbuffer_normal_depth (CopyGBuffer, raytracing_system.cpp:955-1009)
+    const float* color_history;      // W*H*4, combined_history[(frame_count + 1) % 2] = the previous frame's TAA output
+};
+struct f2
+{
+    float x, y;
+};
+// camera.h:8-37 CalculateImagePlaneUV
+f2 image_plane_uv(const OracleCamera& cam, f3 position)
+{
+    f3    o = make3(cam.position[0], cam.position[1], cam.position[2]);
+    f3    d = normalize(position - o);
+    f3    n = normalize(make3(cam.forward[0], cam.forward[1], cam.forward[2]));
+    f3    p = o + n * cam.focal_length;
+    float t = dot(n, p - o) / dot(n, d);
+    f3    ip = o + d * t;
+    f3    ipd = ip - p;
+    float u = dot(make3(cam.right[0], cam.right[1], cam.right[2]), ipd) / (0.5f * cam.sensor_size[0]);
+    float v = dot(make3(cam.up[0], cam.up[1], cam.up[2]), ipd) / (0.5f * cam.sensor_size[1]);
+    return f2{0.5f * u + 0.5f, 0.5f * v + 0.5f};
+}
+// utils.h:6-10
+f2 uv_to_xy(f2 uv, uint32_t w, uint32_t h) { return f2{hmin(uv.x * (float)w, (float)(w - 1)), hmin(uv.y * (float)h, (float)(h - 1))}; }
+f3 image_load3(const float* img, uint32_t w, uint32_t h, uint32_t x, uint32_t y)  // out-of-bounds reads return 0
+{
+    if (x >= w || y >= h) return make3(0, 0, 0);
+    const float* p = img + 4 * ((size_t)y * w + x);
+    return make3(p[0], p[1], p[2]);
+}
+// utils.h:20-35 SampleBilinear; uint(x) of a negative float saturates to 0, lerp(a,b,t) = a + t*(b - a)
+f3 sample_bilinear(const float* img, uint32_t w, uint32_t h, f2 uv)
+{
+    f2       xy = uv_to_xy(uv, w, h);
+    float    fx = xy.x - 0.5f, fy = xy.y - 0.5f;
+    float    flx = floorf(fx), fly = floorf(fy);
+    uint32_t ux = flx > 0.0f ? (uint32_t)flx : 0u, uy = fly > 0.0f ? (uint32_t)fly : 0u;
+    float    wx = frac(fx), wy = frac(fy);
+    f3 v00 = image_load3(img, w, h, ux, uy), v01 = image_load3(img, w, h, ux, uy + 1), v10 = image_load3(img, w, h, ux + 1, uy),
+       v11 = image_load3(img, w, h, ux + 1, uy + 1);
+    auto lerp3 = [](f3 a, f3 b, float t) { return make3(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z)); };
+    return lerp3(lerp3(v00, v10, wx), lerp3(v01, v11, wx), wy);
+}
+
 void shade_pixel(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, uint32_t x, uint32_t y, uint32_t w,
-                 uint32_t h, uint32_t frame_count, uint32_t num_bounces, bool use_bvh, PixelOut* o, uint64_t rays[3])
+                 uint32_t h, uint32_t frame_count, uint32_t num_bounces, bool use_bvh, PixelOut* o, uint64_t rays[3],
+                 const Feedback* fb = nullptr)
 {
     f3 org, dir;
     create_primary_ray(cam, x, y, w, h, frame_count, &org, &dir);
@@ -669,6 +717,29 @@ void shade_pixel(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, ui
             kd = get_material(sc, inst, tx);
         }
         if (kd.x < 1e-5f && kd.y < 1e-5f && kd.z < 1e-5f) break;  // :108
+        if (bounce != 0 && fb)
+        {
+            // :116-145 GBUFFER_FEEDBACK: a vertex the previous frame saw returns that frame's shaded result and ends the path.
+            // Stated choice: a NaN uv counts as disocclusion (any(uv < 0) || any(uv > 1) is false for NaN in HLSL and would
+            // reach an undefined texel address).
+            f2   puv          = image_plane_uv(fb->prev_cam, p);
+            bool disocclusion = !(puv.x >= 0.0f && puv.y >= 0.0f && puv.x <= 1.0f && puv.y <= 1.0f);
+            if (!disocclusion)
+            {
+                f2    pxy = uv_to_xy(puv, w, h);
+                int   ix = (int)pxy.x, iy = (int)pxy.y;  // Load(int3(prev_frame_xy, 0))
+                float prev_depth = (ix >= 0 && iy >= 0 && (uint32_t)ix < w && (uint32_t)iy < h)
+                                       ? fb->prev_normal_depth[4 * ((size_t)iy * w + ix) + 3]
+                                       : 0.0f;
+                float cur_depth = length(p - make3(fb->prev_cam.position[0], fb->prev_cam.position[1], fb->prev_cam.position[2]));
+                disocclusion    = fabsf(prev_depth - cur_depth) / cur_depth > 0.05f;
+            }
+            if (!disocclusion)
+            {
+                color = color + thr * sample_bilinear(fb->color_history, w, h, puv);  // :142
+                break;
+            }
+        }
         if (bounce != 0) color = color + thr * direct_illumination(sc, ls, p, n, kd, use_bvh, &rays[2]);  // :136
         float s[2];
         bluenoise4x4(bn, x, y, frame_count * 25 + bounce, s);  // :149
@@ -861,7 +932,8 @@ void shade_pixel_ext(const Scene& sc, const OracleCamera& cam, const uint8_t* bn
 }
 
 void render_rows(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, uint32_t w, uint32_t h, uint32_t frame,
-                 uint32_t bounces, bool use_bvh, bool ext, uint32_t row0, uint32_t row_step, OracleFrameOutputs* out, uint64_t rays[3])
+                 uint32_t bounces, bool use_bvh, bool ext, uint32_t row0, uint32_t row_step, OracleFrameOutputs* out, uint64_t rays[3],
+                 const Feedback* fb)
 {
     for (uint32_t y = row0; y < h; y += row_step)
         for (uint32_t x = 0; x < w; ++x)
@@ -870,7 +942,7 @@ void render_rows(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, ui
             if (ext)
                 shade_pixel_ext(sc, cam, bn, x, y, w, h, frame, bounces, use_bvh, &po, rays);
             else
-                shade_pixel(sc, cam, bn, x, y, w, h, frame, bounces, use_bvh, &po, rays);
+                shade_pixel(sc, cam, bn, x, y, w, h, frame, bounces, use_bvh, &po, rays, fb);
             size_t i = 4 * ((size_t)y * w + x);
             if (out->gbuffer_geo) memcpy(out->gbuffer_geo + i, po.geo, 16);
             if (out->direct) memcpy(out->direct + i, po.direct, 16);
@@ -934,27 +1006,42 @@ void* oracle_scene_create(const OracleScene* s)
 
 void oracle_scene_destroy(void* h) { delete (Scene*)h; }
 
-int oracle_render_frame(void* scene, const OracleCamera* cam, const uint8_t* bn, uint32_t w, uint32_t h,
-                        uint32_t frame_count, uint32_t num_bounces, uint32_t flags, uint32_t num_threads,
-                        OracleFrameOutputs* out)
+static int render_frame_impl(void* scene, const OracleCamera* cam, const uint8_t* bn, uint32_t w, uint32_t h, uint32_t frame_count,
+                             uint32_t num_bounces, uint32_t flags, uint32_t num_threads, OracleFrameOutputs* out, const Feedback* fb)
 {
     if (!scene || !cam || !bn || !out || !w || !h) return 1;
     const Scene& sc = *(const Scene*)scene;
     bool     bvh = (flags & ORACLE_FLAG_USE_BVH) != 0;
     bool     ext = (flags & ORACLE_FLAG_EXT_MATERIALS) != 0;
     if (ext && sc.materials.size() != sc.meshes.size()) return 2;  // EXT needs one material per mesh
+    if (ext && fb) return 3;                                        // the feedback branch belongs to the reference model
     uint32_t nt  = std::max(1u, std::min(num_threads, h));
     std::vector<uint64_t> rays(3 * (size_t)nt, 0);
     std::vector<std::thread> th;
     for (uint32_t t = 1; t < nt; ++t)
         th.emplace_back(render_rows, std::cref(sc), std::cref(*cam), bn, w, h, frame_count, num_bounces, bvh, ext, t, nt, out,
-                        rays.data() + 3 * t);
-    render_rows(sc, *cam, bn, w, h, frame_count, num_bounces, bvh, ext, 0, nt, out, rays.data());
+                        rays.data() + 3 * t, fb);
+    render_rows(sc, *cam, bn, w, h, frame_count, num_bounces, bvh, ext, 0, nt, out, rays.data(), fb);
     for (auto& t : th) t.join();
     out->rays[0] = out->rays[1] = out->rays[2] = 0;
     for (uint32_t t = 0; t < nt; ++t)
         for (int k = 0; k < 3; ++k) out->rays[k] += rays[3 * t + k];
     return 0;
+}
+
+int oracle_render_frame(void* scene, const OracleCamera* cam, const uint8_t* bn, uint32_t w, uint32_t h, uint32_t frame_count,
+                        uint32_t num_bounces, uint32_t flags, uint32_t num_threads, OracleFrameOutputs* out)
+{
+    return render_frame_impl(scene, cam, bn, w, h, frame_count, num_bounces, flags, num_threads, out, nullptr);
+}
+
+int oracle_render_frame_feedback(void* scene, const OracleCamera* cam, const OracleCamera* prev_cam, const uint8_t* bn, uint32_t w,
+                                 uint32_t h, uint32_t frame_count, uint32_t num_bounces, uint32_t flags, uint32_t num_threads,
+                                 const float* prev_normal_depth, const float* color_history, OracleFrameOutputs* out)
+{
+    if (!prev_cam || !prev_normal_depth || !color_history) return 1;
+    Feedback fb{*prev_cam, prev_normal_depth, color_history};
+    return render_frame_impl(scene, cam, bn, w, h, frame_count, num_bounces, flags, num_threads, out, &fb);
 }
 
 int oracle_render_accumulate(void* scene, const OracleCamera* cam, const uint8_t* bn, uint32_t w, uint32_t h,

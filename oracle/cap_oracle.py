@@ -62,6 +62,8 @@ def lib():
         L.oracle_scene_create.argtypes = [C.POINTER(SceneDesc)]
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
         L.oracle_render_frame.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_uint32] * 6 + [C.POINTER(FrameOutputs)]
+        L.oracle_render_frame_feedback.argtypes = ([C.c_void_p, C.POINTER(Camera), C.POINTER(Camera), C.c_void_p] + [C.c_uint32] * 6 +
+                                                   [C.c_void_p, C.c_void_p, C.POINTER(FrameOutputs)])
         L.oracle_render_accumulate.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p, C.c_void_p]
         L.oracle_post_create.restype = C.c_void_p
         L.oracle_post_create.argtypes = [C.c_uint32, C.c_uint32]
@@ -131,14 +133,22 @@ class Scene:
             lib().oracle_scene_destroy(self.h)
             self.h = None
 
-    def render_frame(self, cam, bluenoise, width, height, frame_count, num_bounces, flags=0, threads=1):
+    def render_frame(self, cam, bluenoise, width, height, frame_count, num_bounces, flags=0, threads=1, feedback=None):
+        """feedback = (prev_cam, prev_normal_depth, color_history) turns the G-buffer feedback branch on (rt_indirect.hlsl:116-145)."""
         names = ("gbuffer_geo", "direct", "albedo", "normal_depth", "indirect", "combined")
         bufs = {n: np.zeros((height, width, 4), np.float32) for n in names}
         out = FrameOutputs()
         for n in names:
             setattr(out, n, _p(bufs[n]))
         bn = np.ascontiguousarray(bluenoise, np.uint8)
-        rc = lib().oracle_render_frame(self.h, C.byref(cam), _p(bn), width, height, frame_count, num_bounces, flags, threads, C.byref(out))
+        if feedback is not None:
+            prev_cam, pnd, hist = feedback
+            pnd, hist = np.ascontiguousarray(pnd, np.float32), np.ascontiguousarray(hist, np.float32)
+            assert pnd.shape == hist.shape == (height, width, 4)
+            rc = lib().oracle_render_frame_feedback(self.h, C.byref(cam), C.byref(prev_cam), _p(bn), width, height, frame_count, num_bounces,
+                                                    flags, threads, _p(pnd), _p(hist), C.byref(out))
+        else:
+            rc = lib().oracle_render_frame(self.h, C.byref(cam), _p(bn), width, height, frame_count, num_bounces, flags, threads, C.byref(out))
         if rc:
             raise RuntimeError("oracle_render_frame rc=%d" % rc)
         bufs["rays"] = tuple(int(x) for x in out.rays)

@@ -59,6 +59,60 @@ def test_post_chain_parity_cornell(native_lib, bluenoise, cornell_path, settings
     r.close()
 
 
+@pytest.mark.parametrize("traversal", [1, 2])
+def test_gbuffer_feedback_parity(native_lib, bluenoise, cornell_path, traversal):
+    """The reference's default configuration (RaytracingOptions::gbuffer_feedback = true, raytracing_system.h:26): the indirect
+    pass reads the previous frame's reconstruction output (rt_indirect.hlsl:116-145), so render and chain feed each other frame
+    after frame.  Ray passes and chain output are compared bit for bit with the oracle running the same loop."""
+    from oracle import cap_oracle as O
+    w, h, D = 120, 90, 3
+    geo = capi.Geometry(cornell_path)
+    r = capi.Renderer(0)
+    r.upload_geometry(geo)
+    r.upload_bluenoise(bluenoise)
+    r.build_bvh()
+    r.set_traversal(traversal)  # 1: LBVH kernels + stand-alone shade, 2: fused exhaustive kernels
+    r.set_resolution(w, h)
+    sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes)
+    chain = O.PostChain(w, h)
+    base = capi.cornell_camera(w, h)
+    cams = [base] * 3 + [moved(base, 0.03 * k, 0.0, -0.05 * k) for k in range(1, 3)] + [moved(base, 0.06, 0.0, -0.1)]
+    gs, os_ = capi.PostSettings(), O.PostSettings()
+    prev = cams[0]
+    prev_nd = np.zeros((h, w, 4), np.float32)
+    hist = np.zeros((h, w, 4), np.float32)
+    reused_any = False
+    for f, cam in enumerate(cams):
+        r.set_camera(cam)
+        r.set_prev_camera(prev)
+        r.stats_reset()
+        r.render(f, 1, D, capi.RENDER_AOV | capi.RENDER_GBUFFER_FEEDBACK)
+        ref = sc.render_frame(ocam_of(O, cam), bluenoise, w, h, f, D, threads=8, feedback=(ocam_of(O, prev), prev_nd, hist))
+        plain = sc.render_frame(ocam_of(O, cam), bluenoise, w, h, f, D, threads=8)
+        for name, kind in (("direct", capi.BUF_DIRECT), ("albedo", capi.BUF_ALBEDO), ("normal_depth", capi.BUF_NORMAL_DEPTH),
+                           ("indirect", capi.BUF_INDIRECT)):
+            got = r.readback(kind)
+            nbad = int((bits(got) != bits(ref[name])).any(-1).sum())
+            assert nbad == 0, "frame %d %s: %d pixels differ" % (f, name, nbad)
+        s = r.stats()
+        assert (s.rays_primary, s.rays_extension, s.rays_shadow) == ref["rays"]
+        if f == 0:  # cleared histories: every vertex is a disocclusion, the frame equals the plain path tracer's
+            assert ref["rays"] == plain["rays"] and np.array_equal(bits(ref["indirect"]), bits(plain["indirect"]))
+        else:
+            reused_any |= ref["rays"][1] < plain["rays"][1]  # paths end early at vertices the last frame saw
+        r.post_frame(gs, f, prev)
+        got = r.post_readback()
+        want = chain.frame(os_, f, ocam_of(O, cam), ocam_of(O, prev), ref)
+        nbad = int((bits(got) != bits(want)).any(-1).sum())
+        assert nbad == 0, "frame %d chain output: %d pixels differ" % (f, nbad)
+        prev, prev_nd, hist = cam, ref["normal_depth"], want
+    assert reused_any
+    # misuse
+    with pytest.raises(capi.CapError, match="one frame per call"):
+        r.render(0, 2, D, capi.RENDER_GBUFFER_FEEDBACK)
+    r.close()
+
+
 def test_post_chain_reset_and_errors(native_lib, bluenoise, cornell_path):
     w, h = 64, 48
     r = capi.Renderer(0)
