@@ -108,7 +108,7 @@ struct PostChainArgs
     // persistent state (raytracing_system.cpp:262-317)
     float4 *indirect_history[2], *moments_history[2], *combined_history[2], *prev_normal_depth;
     // scratch
-    float4 *indirect_temp, *temp[2];
+    float4 *indirect_temp, *temp[2], *normals;  // normals: decoded (n.xyz, depth) of this frame
 };
 // The frame's output is combined_history[frame_count % 2] (raytracing_system.cpp:320-324).
 void launch_post_chain(hipStream_t stream, const PostChainArgs& a);

@@ -95,7 +95,8 @@ struct World
 {
     // components
     std::vector<AssetComponent> assets;
-    CameraData                  camera;
+    CameraData                  camera, prev_camera;  // CameraComponent::camera_data / prev_camera_data
+    bool                        prev_camera_valid = false;
     Settings                    settings;
     // RenderSystem state
     RenderSessionParams session;
@@ -178,12 +179,31 @@ void run_camera(World& w)
     static_assert(sizeof(cd) == sizeof(CameraData), "layout");
     std::memcpy(&cd, &w.camera, sizeof(cd));
     check(cap_camera_set(w.ctx, &cd), "CameraSystem");
+    // the first frame has no predecessor: prev = current (camera_system.cpp:104-118 uploads the stored previous data)
+    if (!w.prev_camera_valid) w.prev_camera = w.camera, w.prev_camera_valid = true;
+    w.prev_camera.sensor_size[1] = w.prev_camera.sensor_size[0] * aspect;
+    std::memcpy(&cd, &w.prev_camera, sizeof(cd));
+    check(cap_prev_camera_set(w.ctx, &cd), "CameraSystem");
 }
 
 // RaytracingSystem::Run, ray passes (raytracing_system.cpp:266-292)
 void run_raytracing(World& w)
 {
     if (!w.tlas_built) return;  // nothing to trace yet, as in the reference's first frames
+    if (w.settings.reconstruct)
+    {
+        // ray passes + SpatialGather .. ApplyTAA of one frame (raytracing_system.cpp:262-317)
+        const Settings& s = w.settings;
+        if (s.frames_per_render != 1) error_throw("RaytracingSystem: the reconstruction pipeline renders one frame per Render()");
+        const uint32_t flags = CAP_RENDER_STAGE_TIMERS | CAP_RENDER_AOV | (s.gbuffer_feedback ? (uint32_t)CAP_RENDER_GBUFFER_FEEDBACK : 0u);
+        check(cap_render(w.ctx, w.frame_count, 1, (uint32_t)std::max(0, s.num_diffuse_bounces), flags), "RaytracingSystem");
+        CapPostSettings ps{s.gather, s.denoise, s.eaw5, s.eaw_normal_sigma, s.eaw_depth_sigma, s.eaw_luma_sigma, s.gather_normal_sigma,
+                           s.gather_depth_sigma, s.gather_luma_sigma, s.temporal_upscale_feedback, s.taa_feedback};
+        CapCameraData   prev;
+        std::memcpy(&prev, &w.prev_camera, sizeof(prev));
+        check(cap_post_frame(w.ctx, &ps, w.frame_count, &prev), "RaytracingSystem");
+        return;
+    }
     if (!w.settings.accumulate) check(cap_accum_reset(w.ctx), "RaytracingSystem");
     check(cap_render(w.ctx, w.frame_count, w.settings.frames_per_render, (uint32_t)std::max(0, w.settings.num_diffuse_bounces),
                      CAP_RENDER_STAGE_TIMERS),
@@ -236,6 +256,7 @@ void Render()
     // RenderSystem::Run: submit + ++frame_count_ (render_system.cpp:53-84)
     check(cap_sync(w.ctx), "RenderSystem");
     w.frame_count += w.settings.frames_per_render;
+    w.prev_camera = w.camera;  // CameraSystem keeps this frame's data as the next frame's prev_camera_data
 }
 
 void ShutdownRenderSession()
@@ -261,7 +282,10 @@ uint32_t    FrameCount() { return world().frame_count; }
 void ReadFrame(float* dst)
 {
     World& w = world();
-    check(cap_readback(w.ctx, CAP_BUF_ACCUM_MEAN, dst), "ReadFrame");
+    if (w.settings.reconstruct)
+        check(cap_post_readback(w.ctx, dst), "ReadFrame");  // current_frame_output(), raytracing_system.cpp:320-324
+    else
+        check(cap_readback(w.ctx, CAP_BUF_ACCUM_MEAN, dst), "ReadFrame");
 }
 
 void SaveFramePPM(const std::string& path)
@@ -296,6 +320,7 @@ std::string TimingsReport()
       << "RT Indirect diffuse (closest-hit traversal): " << s.ms_trace_closest << " ms\n"
       << "RT shadow rays (any-hit traversal): " << s.ms_trace_any << " ms\n"
       << "Accumulate: " << s.ms_resolve << " ms\n"
+      << "Spatial gather + Temporal accumulation + EAW denoise + Combine + TAA: " << s.ms_post << " ms over " << s.post_frames << " frames\n"
       << "total: " << s.ms_total << " ms over " << s.frames << " frames, rays primary/extension/shadow = " << s.rays_primary << "/"
       << s.rays_extension << "/" << s.rays_shadow << "\n";
     return o.str();

@@ -24,6 +24,21 @@ struct Settings
     int      num_diffuse_bounces = 1;   // gui_system.h:39
     uint32_t frames_per_render   = 1;   // reference: exactly one frame per Render()
     bool     accumulate          = true;  // plain running mean instead of the temporal EMA
+    // The reference's own frame pipeline (raytracing_system.cpp:262-317): one frame per Render(), reconstruction chain after
+    // the ray passes, G-buffer feedback in the indirect pass.  ReadFrame() then returns current_frame_output().
+    bool  reconstruct               = false;
+    bool  gbuffer_feedback          = true;    // RaytracingOptions::gbuffer_feedback, raytracing_system.h:26
+    bool  gather                    = true;    // gui_system.h:20-37
+    bool  denoise                   = true;
+    bool  eaw5                      = true;
+    float eaw_normal_sigma          = 128.f;
+    float eaw_depth_sigma           = 3.f;
+    float eaw_luma_sigma            = 3.f;
+    float gather_normal_sigma       = 64.f;
+    float gather_depth_sigma        = 2.f;
+    float gather_luma_sigma         = 3.f;
+    float temporal_upscale_feedback = 0.975f;
+    float taa_feedback              = 0.9f;
 };
 
 // CameraData (camera_system.h:16-31), defaults from CameraSystem's ctor (camera_system.cpp:25-33).

@@ -82,6 +82,7 @@ enum StageId
     ST_ANY,
     ST_SHADE,
     ST_RESOLVE,
+    ST_POST,
     ST_COUNT
 };
 
@@ -153,7 +154,7 @@ struct CapContext
 
     // reconstruction chain (row-major W*H images)
     DevBuf<float4> post_in[4];  // indirect, direct, albedo, normal_depth of the frame
-    DevBuf<float4> post_ihist[2], post_mhist[2], post_chist[2], post_prev_nd, post_itemp, post_temp[2];
+    DevBuf<float4> post_ihist[2], post_mhist[2], post_chist[2], post_prev_nd, post_itemp, post_temp[2], post_normals;
     uint32_t       post_w = 0, post_h = 0;
     int            post_last_dst = -1;
 
@@ -189,6 +190,7 @@ int sync_and_collect(CapContext* c)
             case ST_ANY: c->stats.ms_trace_any += ms; break;
             case ST_SHADE: c->stats.ms_shade += ms; break;
             case ST_RESOLVE: c->stats.ms_resolve += ms; break;
+            case ST_POST: c->stats.ms_post += ms; break;
             case ST_COUNT: c->stats.ms_total += ms; break;
             }
         }
@@ -1015,7 +1017,7 @@ int cap_post_reset(CapContext* c)
     const size_t npix = (size_t)c->screen.width * c->screen.height;
     DevBuf<float4>* all[] = {&c->post_in[0],   &c->post_in[1],   &c->post_in[2],   &c->post_in[3],  &c->post_ihist[0], &c->post_ihist[1],
                              &c->post_mhist[0], &c->post_mhist[1], &c->post_chist[0], &c->post_chist[1], &c->post_prev_nd, &c->post_itemp,
-                             &c->post_temp[0],  &c->post_temp[1]};
+                             &c->post_temp[0],  &c->post_temp[1], &c->post_normals};
     for (DevBuf<float4>* b : all)
     {
         HIP_TRY(b->ensure(npix));
@@ -1052,9 +1054,13 @@ int cap_post_frame(CapContext* c, const CapPostSettings* s, uint32_t frame_count
     for (int k = 0; k < 2; ++k)
         a.indirect_history[k] = c->post_ihist[k].p, a.moments_history[k] = c->post_mhist[k].p, a.combined_history[k] = c->post_chist[k].p,
         a.temp[k] = c->post_temp[k].p;
-    a.prev_normal_depth = c->post_prev_nd.p, a.indirect_temp = c->post_itemp.p;
-    launch_post_chain(c->stream, a);
+    a.prev_normal_depth = c->post_prev_nd.p, a.indirect_temp = c->post_itemp.p, a.normals = c->post_normals.p;
+    {
+        StageTimer t(c, ST_POST);
+        launch_post_chain(c->stream, a);
+    }
     HIP_TRY(hipGetLastError());
+    ++c->stats.post_frames;
     c->post_last_dst = (int)(frame_count % 2);
     return CAP_OK;
 }

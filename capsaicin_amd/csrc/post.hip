@@ -112,13 +112,26 @@ __device__ __forceinline__ bool pixel_of_thread(uint32_t w, uint32_t h, uint32_t
     return x < w && y < h;
 }
 
-// spatial_gather.hlsl:28-109
+// The three stencil filters decode every neighbour's octahedral normal (a normalize = sqrt + division per tap, ~200 taps per
+// pixel and frame over the whole chain).  The decode depends on the texel only, so it is done once per pixel and frame here:
+// out = (OctDecode(nd.xy), nd.w) — the same values the per-tap decode would give, a quarter of the filters' VALU work less.
+__global__ __launch_bounds__(kBlock) void k_decode_normals(const float4* nd, float4* out, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    {
+        const float4 g = nd[i];
+        const v3     d = oct_decode(g.x, g.y);
+        out[i]         = make_float4(d.x, d.y, d.z, g.w);
+    }
+}
+
+// spatial_gather.hlsl:28-109.  nd = decoded (normal.xyz, depth) image of k_decode_normals.
 __global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color, Img nd, float4* out)
 {
     uint32_t x, y;
     if (!pixel_of_thread(color.w, color.h, x, y)) return;
     const float4 cg = ld(nd, x, y);
-    const v3     cn = oct_decode(cg.x, cg.y);
+    const v3     cn = xyz(cg);
     const float  cd = cg.w;
     const v3     cc = xyz(ld(color, x, y));
     float4       res;
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color,
                 const v3     c = xyz(ldi(color, sx, sy));
                 const float4 g = ldi(nd, sx, sy);
                 if (g.w < 1e-5f) continue;
-                const v3    n   = oct_decode(g.x, g.y);
+                const v3    n   = xyz(g);
                 const float len = sqrtf((float)(dx * dx + dy * dy));
                 const float wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * len) * luma_weight(luminance(cc), luminance(c), s_luma);
                 filtered = filtered + c * wgt;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_blur_disocclusion(PostSettingsDev s,
     if (!pixel_of_thread(color.w, color.h, x, y)) return;
     const float  hist = ld(moments, x, y).w;
     const float4 cg   = ld(nd, x, y);
-    const v3     cn   = oct_decode(cg.x, cg.y);
+    const v3     cn   = xyz(cg);
     const float  cd   = cg.w;
     const float4 cv   = ld(color, x, y);
     const v3     cc   = remove_fireflies(cv);
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_blur_disocclusion(PostSettingsDev s,
                 const float4 g = ldi(nd, sx, sy);
                 const float4 m = ldi(moments, sx, sy);
                 if (g.w < 1e-5f) continue;
-                const v3    n   = oct_decode(g.x, g.y);
+                const v3    n   = xyz(g);
                 const float len = sqrtf((float)(dx * dx + dy * dy));
                 const float wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * len) * luma_weight(luminance(cc), luminance(c), s_luma);
                 filtered = filtered + c * wgt;
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_blur(PostSettingsDev s, uint32_t str
     uint32_t x, y;
     if (!pixel_of_thread(color.w, color.h, x, y)) return;
     const float4 cg   = ld(nd, x, y);
-    const v3     cn   = oct_decode(cg.x, cg.y);
+    const v3     cn   = xyz(cg);
     const float  cd   = cg.w;
     const float4 cv   = ld(color, x, y);
     const v3     cc   = remove_fireflies(cv);
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_blur(PostSettingsDev s, uint32_t str
                 const v3     c = remove_fireflies(v);
                 const float4 g = ldi(nd, sx, sy);
                 if (g.w < 1e-5f) continue;
-                const v3    n   = oct_decode(g.x, g.y);
+                const v3    n   = xyz(g);
                 const float lw  = luma_weight(luminance(cc), luminance(c), s_luma);
                 const float hw  = kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy];
                 const float len = sqrtf((float)(dx * dx + dy * dy));
@@ -389,9 +402,14 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     const size_t   bytes = sizeof(float4) * (size_t)W * H;
     auto           img   = [&](const float4* p) { return Img{p, W, H}; };
     const uint32_t src = (a.frame_count + 1) % 2, dst = a.frame_count % 2;  // raytracing_system.cpp:1709-1710, 1754-1755
+    uint32_t cg = (W * H + kBlock - 1) / kBlock;  // grid of the streaming (stencil-free) kernels
+    if (cg > 4096) cg = 4096;
+    if (cg == 0) cg = 1;
+    if (a.settings.gather || a.settings.denoise)
+        hipLaunchKernelGGL(k_decode_normals, dim3(cg), block, 0, stream, a.normal_depth, a.normals, W * H);
     // SpatialGather (cpp:1541-1604)
     if (a.settings.gather)
-        hipLaunchKernelGGL(k_gather, grid, block, 0, stream, a.settings, img(a.indirect), img(a.normal_depth), a.indirect_temp);
+        hipLaunchKernelGGL(k_gather, grid, block, 0, stream, a.settings, img(a.indirect), img(a.normals), a.indirect_temp);
     else
         (void)hipMemcpyAsync(a.indirect_temp, a.indirect, bytes, hipMemcpyDeviceToDevice, stream);
     // IntegrateTemporally (cpp:1283-1342)
@@ -401,22 +419,20 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     // Denoise (cpp:1437-1538)
     if (a.settings.denoise)
     {
-        hipLaunchKernelGGL(k_blur_disocclusion, grid, block, 0, stream, a.settings, img(a.indirect_history[dst]), img(a.normal_depth),
+        hipLaunchKernelGGL(k_blur_disocclusion, grid, block, 0, stream, a.settings, img(a.indirect_history[dst]), img(a.normals),
                            img(a.moments_history[dst]), a.temp[0]);
-        hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 1u, img(a.temp[0]), img(a.normal_depth), a.temp[1]);
-        hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 3u, img(a.temp[1]), img(a.normal_depth), a.temp[0]);
+        hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 1u, img(a.temp[0]), img(a.normals), a.temp[1]);
+        hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 3u, img(a.temp[1]), img(a.normals), a.temp[0]);
         if (a.settings.eaw5)
         {
-            hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 5u, img(a.temp[0]), img(a.normal_depth), a.temp[1]);
-            hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 7u, img(a.temp[1]), img(a.normal_depth), a.temp[0]);
+            hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 5u, img(a.temp[0]), img(a.normals), a.temp[1]);
+            hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 7u, img(a.temp[1]), img(a.normals), a.temp[0]);
         }
     }
     else
         (void)hipMemcpyAsync(a.temp[0], a.indirect_history[dst], bytes, hipMemcpyDeviceToDevice, stream);
     // CombineIllumination (cpp:1400-1435)
-    uint32_t cg = (W * H + kBlock - 1) / kBlock;
-    if (cg > 4096) cg = 4096;
-    hipLaunchKernelGGL(k_combine, dim3(cg ? cg : 1), block, 0, stream, a.temp[0], a.albedo, a.direct, W * H);
+    hipLaunchKernelGGL(k_combine, dim3(cg), block, 0, stream, a.temp[0], a.albedo, a.direct, W * H);
     // ApplyTAA (cpp:1344-1398)
     hipLaunchKernelGGL(k_taa, grid, block, 0, stream, a.settings, a.camera, a.prev_camera, img(a.temp[0]), img(a.normal_depth),
                        img(a.combined_history[src]), a.combined_history[dst]);

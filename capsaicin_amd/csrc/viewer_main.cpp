@@ -14,7 +14,8 @@ int main(int argc, char** argv)
     RenderSessionParams params;  // 1920x1080 like main.cpp:53-54
     std::string         scene = "assets/cornell_box.obj", out = "frame.ppm";
     int                 frames = 64, bounces = 1;
-    bool                cornell_camera = true;
+    bool                cornell_camera = true, realtime = false, feedback = true;
+    float               move[3] = {0.f, 0.f, 0.f};  // camera translation per frame (a scripted fly-through, input_system.cpp:49-148)
     for (int i = 1; i < argc; ++i)
     {
         auto next = [&]() { return i + 1 < argc ? argv[++i] : ""; };
@@ -26,9 +27,13 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--bounces")) bounces = std::atoi(next());
         else if (!std::strcmp(argv[i], "--device")) params.device = std::atoi(next());
         else if (!std::strcmp(argv[i], "--default-camera")) cornell_camera = false;
+        else if (!std::strcmp(argv[i], "--realtime")) realtime = true;  // the reference pipeline: 1 spp per frame + reconstruction chain
+        else if (!std::strcmp(argv[i], "--no-feedback")) feedback = false;
+        else if (!std::strcmp(argv[i], "--move"))
+            for (int k = 0; k < 3; ++k) move[k] = (float)std::atof(next());
         else
         {
-            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--default-camera]\n", argv[0]);
+            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--default-camera] [--realtime [--no-feedback] [--move dx dy dz]]\n", argv[0]);
             return 2;
         }
     }
@@ -38,6 +43,8 @@ int main(int argc, char** argv)
         capsaicin::InitRenderSession(&params);
         capsaicin::LoadSceneFromOBJ(scene);
         capsaicin::GetSettings().num_diffuse_bounces = bounces;
+        capsaicin::GetSettings().reconstruct         = realtime;
+        capsaicin::GetSettings().gbuffer_feedback    = feedback;
         if (cornell_camera)
         {
             // the reference default (0,15,0)/+z is tuned for Sponza; SURVEY.md 8d fixes this view for the Cornell box
@@ -48,7 +55,11 @@ int main(int argc, char** argv)
             cam.up[0] = 0.f, cam.up[1] = 1.f, cam.up[2] = 0.f;
             cam.focal_length = 0.035f;
         }
-        for (int f = 0; f < frames; ++f) capsaicin::Render();  // one Render() per WM_PAINT in the reference (main.cpp:17-19)
+        for (int f = 0; f < frames; ++f)
+        {
+            capsaicin::Render();  // one Render() per WM_PAINT in the reference (main.cpp:17-19)
+            for (int k = 0; k < 3; ++k) capsaicin::GetCamera().position[k] += move[k];
+        }
         capsaicin::SaveFramePPM(out);
         std::fputs(capsaicin::TimingsReport().c_str(), stderr);
         capsaicin::ShutdownRenderSession();

@@ -115,6 +115,8 @@ typedef struct CapStats
     uint64_t guard_shade;     /* malformed queue entries caught by the kernels' bounds guards: always 0 in a correct run */
     uint64_t guard_trace_any;
     uint64_t guard_last;      /* (queue index or bounce) << 32 | path id of the last offender */
+    double   ms_post;         /* reconstruction chain, "Spatial gather" .. "TAA" (cap_post_frame), always timed */
+    uint64_t post_frames;
 } CapStats;
 
 typedef struct CapBvhInfo
