@@ -33,7 +33,8 @@ constexpr uint32_t kExhaustiveMax = 64;  // scenes up to this many triangles are
 struct BvhDev
 {
     const float4* nodes;
-    const float4* tris;
+    const float4* tris;        // 64-B intersection records in leaf order (.w of the 4th float4 = global triangle id)
+    const float4* tris_by_id;  // the same records in global triangle id order (exhaustive small-scene kernels)
     int32_t       root;       // 0, or ~0 for a single triangle
     uint32_t      tri_count;  // 0 -> every ray misses
 };

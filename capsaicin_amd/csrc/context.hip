@@ -310,6 +310,7 @@ BvhDev bvh_dev(const CapContext* c)
     BvhDev b{};
     b.nodes     = c->nodes.p;
     b.tris      = c->tris_sorted.p;
+    b.tris_by_id = c->tri_raw.p;
     b.tri_count = c->tri_count;
     b.root      = c->tri_count >= 2 ? 0 : ~0;
     return b;

@@ -199,8 +199,36 @@ __device__ __forceinline__ void load_const_tri(const float4* base, uint32_t k, f
 #endif
 }
 
-__device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const Ray& r, float& best_t, float& best_u, float& best_v,
-                                                   uint32_t& best_gid)
+// The determinant-scaled quantities of tri_test() for one triangle record, sign-flipped so that det >= 0.  Same values bit for
+// bit: det = -(d.n) and V = -(e1.q) are exact negations, so their sign bits are folded into the flip masks instead of being
+// applied first (three bit operations instead of five).
+struct TriScaled
+{
+    float det, U, V, T;  // det = |d.n|
+};
+__device__ __forceinline__ TriScaled tri_scaled(const Ray& r, const float4 t0, const float4 t1, const float4 t2)
+{
+    const v3 v0 = mk3(t0.x, t0.y, t0.z), e1 = mk3(t0.w, t1.x, t1.y), e2 = mk3(t1.z, t1.w, t2.x), n = mk3(t2.y, t2.z, t2.w);
+    const v3 tvec = r.o - v0;
+    const v3 q    = cross3(tvec, r.d);
+    const float    ddn = dot3(r.d, n);                 // det = -ddn
+    const uint32_t s   = f2u(ddn) & 0x80000000u;       // sign of ddn = NOT sign of det
+    TriScaled o;
+    o.det = fabsf(ddn);
+    o.U   = u2f(f2u(dot3(e2, q)) ^ (s ^ 0x80000000u));  // U ^ sign(det)
+    o.V   = u2f(f2u(dot3(e1, q)) ^ s);                  // (-e1.q) ^ sign(det)
+    o.T   = u2f(f2u(dot3(tvec, n)) ^ (s ^ 0x80000000u));
+    return o;
+}
+
+// Exhaustive closest hit over the records in global id order.  Same rule as tri_test() + "minimum t, ties to the lower id":
+// visiting in id order makes "first strictly smaller t" that rule (an equal t never replaces an earlier triangle), and with
+// best_t starting at tmax, t < best_t implies t < tmax.  Only t and the id are tracked in the loop; the barycentrics of the
+// winner are recomputed once after it (identical operations, identical bits) instead of being multiplied out and selected for
+// every triangle.
+// rec_tab: where the winner's record is re-read from (bvh.tris_by_id, or its LDS copy).
+__device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const float4* rec_tab, const Ray& r, float& best_t, float& best_u,
+                                                   float& best_v, uint32_t& best_gid)
 {
     best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
     const uint32_t n = bvh.tri_count;
@@ -208,18 +236,24 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const Ray&
     for (uint32_t k = 0; k < n; ++k)
     {
         float4 t0, t1, t2, t3;
-        load_const_tri(bvh.tris, k, t0, t1, t2, t3);
-        const uint32_t gid = f2u(t3.x);
-        float        t, u, v;
-        const bool   hit    = tri_test(r, t0, t1, t2, t, u, v);
-        const bool   better = hit & ((t < best_t) | ((t == best_t) & (gid < best_gid)));
-        best_t   = better ? t : best_t;
-        best_u   = better ? u : best_u;
-        best_v   = better ? v : best_v;
-        best_gid = better ? gid : best_gid;
+        load_const_tri(bvh.tris_by_id, k, t0, t1, t2, t3);
+        const TriScaled s      = tri_scaled(r, t0, t1, t2);
+        const bool      inside = (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det);
+        const float     tt     = s.T * rcp_c(s.det);
+        const bool      better = inside & (tt > r.tmin) & (tt < best_t);
+        best_t   = better ? tt : best_t;
+        best_gid = better ? k : best_gid;
+    }
+    if (best_gid != kInvalidId)
+    {
+        const float4*   rec = rec_tab + 4 * (size_t)best_gid;
+        const TriScaled s   = tri_scaled(r, rec[0], rec[1], rec[2]);
+        const float     inv = rcp_c(s.det);
+        best_u = s.U * inv, best_v = s.V * inv;
     }
 }
 
+// det == 0 needs no test: then U = V = 0 is the only way past the first three conditions and 0 < T < 0 rejects.
 __device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r)
 {
     const uint32_t n   = bvh.tri_count;
@@ -228,8 +262,9 @@ __device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r)
     for (uint32_t k = 0; k < n; ++k)
     {
         float4 t0, t1, t2, t3;
-        load_const_tri(bvh.tris, k, t0, t1, t2, t3);
-        hit |= tri_occludes(r, t0, t1, t2);
+        load_const_tri(bvh.tris_by_id, k, t0, t1, t2, t3);
+        const TriScaled s = tri_scaled(r, t0, t1, t2);
+        hit |= (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det) & (s.T > r.tmin * s.det) & (s.T < r.tmax * s.det);
     }
     return hit;
 }
@@ -240,7 +275,7 @@ __device__ __forceinline__ void trace_closest_any_size(const BvhDev& bvh, const 
                                                        uint32_t& gid)
 {
     if constexpr (STACK == 0)
-        exhaustive_closest(bvh, r, t, u, v, gid);
+        exhaustive_closest(bvh, bvh.tris_by_id, r, t, u, v, gid);
     else
         traverse_closest<STACK>(bvh, r, stack, t, u, v, gid);
 }
@@ -758,10 +793,27 @@ struct ShadePre
     v3    L, I;    // lighting.h:20-33 of this path's frame
     float r1, r2;  // sampling.h:13-23 sample of (pixel, frame * 25 + bounce)
     float r3, r4, r5, r6;  // EXT only: B, A of the same texel; R, G of the texel of count + 7
+    float r1n, r2n;        // CARRY only: the sample of the path's NEXT vertex (count + 1), handed on in the queue entry
 };
 
-template <bool EXT = false>
-__device__ __forceinline__ ShadePre shade_prefetch(const ShadeArgs& a, bool active, uint32_t pid)
+// The per-frame constants of the batch (48 B x n_slots <= 3 KB) are staged in LDS once per workgroup: a path finds its frame's
+// light and sample counter with a ~64-cycle ds_read instead of a global load that the blue-noise fetch would have to wait for.
+__device__ __forceinline__ void stage_frames(const ShadeArgs& a, FrameConst* lds_frames)
+{
+    const uint32_t  words = a.n_slots * (uint32_t)(sizeof(FrameConst) / 4);
+    const uint32_t* src   = reinterpret_cast<const uint32_t*>(a.frames);
+    uint32_t*       dst   = reinterpret_cast<uint32_t*>(lds_frames);
+    for (uint32_t i = threadIdx.x; i < words; i += kBlock) dst[i] = src[i];
+    __syncthreads();
+}
+
+// CARRY (fused reference-model kernels): an extension ray's tmin / tmax are the constants kRayEps / kRayFar, so the two .w
+// slots of its queue entry carry the blue-noise sample of the vertex it will find.  The vertex that emits the ray fetches
+// that sample next to its other inputs, where nothing waits for it before the final stores; the vertex that receives it starts
+// shading without a dependent global load.  carried_* = the .w slots of the entry this vertex came from (bounce >= 1).
+template <bool EXT = false, bool FIRST = true, bool CARRY = false>
+__device__ __forceinline__ ShadePre shade_prefetch(const ShadeArgs& a, const FrameConst* lds_frames, bool active, uint32_t pid,
+                                                   float carried_r1 = 0.f, float carried_r2 = 0.f)
 {
     ShadePre       s;
     const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
@@ -769,13 +821,18 @@ __device__ __forceinline__ ShadePre shade_prefetch(const ShadeArgs& a, bool acti
     s.valid = active && local_pixel_to_xy(a.screen, pl, x, y);
     s.L = mk3(0, 0, 0), s.I = mk3(0, 0, 0), s.r1 = 0.f, s.r2 = 0.f;
     s.r3 = s.r4 = s.r5 = s.r6 = 0.f;
+    s.r1n = s.r2n = 0.f;
     if (s.valid)
     {
-        const FrameConst fc = a.frames[slot];
+        const FrameConst fc = lds_frames[slot < kMaxFrameSlots ? slot : 0];
         s.L = mk3(fc.light_dir[0], fc.light_dir[1], fc.light_dir[2]);
         s.I = mk3(fc.light_intensity[0], fc.light_intensity[1], fc.light_intensity[2]);
         const uint32_t count = fc.frame_count * 25u + a.bounce;
-        bluenoise4x4(a.scene.bluenoise, x, y, count, s.r1, s.r2);  // rt_indirect.hlsl:149
+        if (CARRY && !FIRST)
+            s.r1 = carried_r1, s.r2 = carried_r2;
+        else
+            bluenoise4x4(a.scene.bluenoise, x, y, count, s.r1, s.r2);  // rt_indirect.hlsl:149
+        if (CARRY) bluenoise4x4(a.scene.bluenoise, x, y, count + 1u, s.r1n, s.r2n);
         if (EXT)
         {
             bluenoise4x4(a.scene.bluenoise_ba, x, y, count, s.r3, s.r4);
@@ -808,9 +865,43 @@ __device__ __forceinline__ void wave_append2(bool emit_ext, bool emit_shadow, ui
     shadow_slot = hi + (uint32_t)__popcll(ms & below);
 }
 
-template <bool FIRST, bool FB = false>
-__device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const ShadePre& pre, uint32_t klass, uint32_t pid, float4 hit, v3 thr,
-                                             uint32_t& n_shaded)
+// Diagnostic build only (-DCAP_STAMPS): per-phase shader-clock sums of the fused kernel, see tools/stamps.py.
+#ifdef CAP_STAMPS
+__device__ unsigned long long g_stamps[16];
+struct Stamps
+{
+    unsigned long long last, acc[8];
+    __device__ void    start()
+    {
+        for (int i = 0; i < 8; ++i) acc[i] = 0;
+        last = __builtin_amdgcn_s_memtime();
+    }
+    __device__ void mark(int i, bool wait)
+    {
+        if (wait) __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[i] += now - last;
+        last = now;
+    }
+    __device__ void flush()
+    {
+        if ((threadIdx.x & 63u) == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], acc[i]);
+    }
+};
+#define STAMP(st, i, wait) (st).mark(i, wait)
+#else
+struct Stamps
+{
+    __device__ void start() {}
+    __device__ void flush() {}
+};
+#define STAMP(st, i, wait) ((void)0)
+#endif
+
+template <bool FIRST, bool FB = false, bool CARRY = false>
+__device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* shade_tab, const ShadePre& pre, uint32_t klass,
+                                             uint32_t pid, float4 hit, v3 thr, uint32_t& n_shaded, Stamps& st)
 {
     const uint32_t Ppad = a.screen.pixels_padded;
     const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
@@ -861,8 +952,8 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const ShadePre&
         {
             ++n_shaded;
             // scene.h:5-50 InterpolateAttributes on the pre-gathered triangle record
-            const float4* st = a.scene.shade_tris + 6 * (size_t)gid;
-            const float4  s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3], s4 = st[4], s5 = st[5];
+            const float4* tab = shade_tab + 6 * (size_t)gid;
+            const float4  s0 = tab[0], s1 = tab[1], s2 = tab[2], s3 = tab[3], s4 = tab[4], s5 = tab[5];
             const float   u = hit.x, v = hit.y, w = (1.0f - u) - v;
             auto          mix = [&](float c0, float c1, float c2) { return fmaf(c2, v, fmaf(c1, u, c0 * w)); };
             const v3      n = normalize3(mk3(mix(s3.x, s4.x, s5.x), mix(s3.y, s4.y, s5.y), mix(s3.z, s4.z, s5.z)));
@@ -951,7 +1042,9 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const ShadePre&
 
         // a.shadow.count == a.out.count + 1: both counters of a class share one 64-bit word (one atomic per wave for both queues)
         uint32_t ei, si;
+        STAMP(st, 2, true);  // shading inputs arrived + shading ALU
         wave_append2(emit_ext, emit_shadow, a.out.count + klass * kCounterStride, ei, si);
+        STAMP(st, 3, true);  // append atomic returned
         ei += klass * a.out.class_capacity;
         si += klass * a.shadow.class_capacity;
         if (emit_shadow)
@@ -962,8 +1055,8 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const ShadePre&
         }
         if (emit_ext)
         {
-            a.out.org_tmin[ei] = make_float4(p.x, p.y, p.z, kRayEps);
-            a.out.dir_tmax[ei] = make_float4(dir.x, dir.y, dir.z, kRayFar);
+            a.out.org_tmin[ei] = make_float4(p.x, p.y, p.z, CARRY ? pre.r1n : kRayEps);
+            a.out.dir_tmax[ei] = make_float4(dir.x, dir.y, dir.z, CARRY ? pre.r2n : kRayFar);
             a.out.thr_pid[ei]  = make_float4(thr.x, thr.y, thr.z, u2f(pid));
         }
     }
@@ -1169,6 +1262,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
     // FIRST: identity queue, item i of frame slot blockIdx.y is local pixel i.  Otherwise: chunk slots of the input queue.
     const uint32_t chunks   = FIRST ? (Ppad >> 6) : (a.in.class_capacity >> 6) * kQueueClasses;
     uint32_t       n_shaded = 0;
+    __shared__ FrameConst lds_frames[kMaxFrameSlots];
+    stage_frames(a, lds_frames);
+    Stamps st;
+    st.start();
     for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
     {
         uint32_t i, klass;
@@ -1198,7 +1295,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
                 hit = a.hits[i];
             }
         }
-        const ShadePre pre = shade_prefetch<EXT>(a, active, pid);
+        const ShadePre pre = shade_prefetch<EXT>(a, lds_frames, active, pid);
         if constexpr (EXT)
         {
             // the EXT BSDF depends on the incoming direction: the camera ray (bounce 0) or the queue entry's direction
@@ -1219,7 +1316,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
             shade_vertex_ext<FIRST>(a, pre, klass, pid, hit, thr, d, n_shaded);
         }
         else
-            shade_vertex<FIRST, FB>(a, pre, klass, pid, hit, thr, n_shaded);
+            shade_vertex<FIRST, FB>(a, a.scene.shade_tris, pre, klass, pid, hit, thr, n_shaded, st);
     }
     flush_shaded(a.shaded_counter, n_shaded);
 }
@@ -1248,18 +1345,42 @@ void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext, bool fe
 // Fused stage of the small-scene path: closest-hit (exhaustive, wave-uniform) + shading of the vertex it finds, in one pass over
 // the ray queue.  The hit record never travels through HBM and the shading stage's memory latency hides under the ALU-bound
 // triangle loop of the other waves.  FIRST generates the camera ray instead of reading a queue entry (rt_primary_visibility).
-template <bool FIRST, bool EXT, bool FB = false>
-__global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? 5 : 6)) void k_trace_shade(BvhDev bvh, ShadeArgs a)
+#ifndef CAP_TS_FIRST
+#define CAP_TS_FIRST 5  // workgroups per CU the bounce-0 kernel is register-allocated for
+#endif
+#ifndef CAP_TS_NEXT
+#define CAP_TS_NEXT 6  // ... and the bounce >= 1 kernel (8 fits in 64 VGPRs without spills but measured 8 % slower)
+#endif
+// LDS: scenes of at most kExhaustiveMax triangles keep their shading records (96 B each) and intersection records in LDS
+// (<= 10 KB per workgroup), so the gathers by hit triangle after the loop are ds_reads instead of a global round trip.
+template <bool FIRST, bool EXT, bool FB = false, bool LDS = false>
+__global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : CAP_TS_NEXT)) void k_trace_shade(BvhDev bvh, ShadeArgs a)
 {
+    constexpr bool CARRY    = !EXT;
     const uint32_t Ppad     = a.screen.pixels_padded;
     const uint32_t chunks   = FIRST ? (Ppad >> 6) : (a.in.class_capacity >> 6) * kQueueClasses;
     uint32_t       n_shaded = 0;
+    __shared__ FrameConst lds_frames[kMaxFrameSlots];
+    __shared__ float4     lds_shade[LDS ? 6 * kExhaustiveMax : 1];
+    __shared__ float4     lds_rec[LDS ? 4 * kExhaustiveMax : 1];
+    if (LDS)
+    {
+        const uint32_t n = bvh.tri_count <= kExhaustiveMax ? bvh.tri_count : kExhaustiveMax;
+        for (uint32_t k = threadIdx.x; k < 6 * n; k += kBlock) lds_shade[k] = a.scene.shade_tris[k];
+        for (uint32_t k = threadIdx.x; k < 4 * n; k += kBlock) lds_rec[k] = bvh.tris_by_id[k];
+    }
+    stage_frames(a, lds_frames);  // ends with the workgroup barrier
+    const float4* shade_tab = LDS ? lds_shade : a.scene.shade_tris;
+    const float4* rec_tab   = LDS ? lds_rec : bvh.tris_by_id;
+    Stamps st;
+    st.start();
     for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
     {
         uint32_t i, klass, pid = 0;
         bool     active;
         v3       thr = mk3(1.0f, 1.0f, 1.0f);
         Ray      r   = make_ray(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 1.f), 0.0f, 0.0f);  // empty interval: hits nothing
+        float    carried_r1 = 0.f, carried_r2 = 0.f;
         if (FIRST)
         {
             i      = chunk * 64 + (threadIdx.x & 63u);
@@ -1277,15 +1398,19 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? 5 : 6)) void k_t
             if (__ballot(active) == 0ull) continue;  // unoccupied chunk slot of this class: nothing to trace (wave-uniform)
             if (active)
             {
+                // extension rays: tmin / tmax are constants (rt_indirect.hlsl:154-157); with CARRY the .w slots hold the sample
                 const float4 o = a.in.org_tmin[i], d = a.in.dir_tmax[i], tp = a.in.thr_pid[i];
-                r   = make_ray(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), o.w, d.w);
+                r   = make_ray(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), kRayEps, kRayFar);
                 thr = mk3(tp.x, tp.y, tp.z), pid = f2u(tp.w);
+                carried_r1 = o.w, carried_r2 = d.w;
             }
         }
-        const ShadePre pre = shade_prefetch<EXT>(a, active, pid);  // issued before the triangle loop: lands under its ALU work
-        float          t, u, v;
-        uint32_t       gid;
-        exhaustive_closest(bvh, r, t, u, v, gid);
+        float    t, u, v;
+        uint32_t gid;
+        STAMP(st, 0, true);  // queue entry arrived
+        exhaustive_closest(bvh, rec_tab, r, t, u, v, gid);
+        STAMP(st, 1, true);  // triangle loop + winner's record
+        const ShadePre pre = shade_prefetch<EXT, FIRST, CARRY>(a, lds_frames, active, pid, carried_r1, carried_r2);
         if (FIRST && blockIdx.y == a.aov_slot)
         {
             // rt_primary_visibility.hlsl:46: (uv, asfloat(InstanceID), asfloat(PrimitiveIndex)); a miss keeps uv = 0, ids = ~0u
@@ -1300,31 +1425,55 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? 5 : 6)) void k_t
         if constexpr (EXT)
             shade_vertex_ext<FIRST>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
         else
-            shade_vertex<FIRST, FB>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded);
+            shade_vertex<FIRST, FB, CARRY>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded, st);
+        STAMP(st, 4, false);  // stores issued
     }
+    if (!FIRST && !EXT && !FB) st.flush();
     flush_shaded(a.shaded_counter, n_shaded);
 }
 
+#ifdef CAP_STAMPS
+extern "C" int cap_debug_stamps(unsigned long long* out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset)
+    {
+        unsigned long long z[16] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
+
 void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, bool ext, bool feedback)
 {
+    const bool lds = !ext && bvh.tri_count <= kExhaustiveMax;
     if (args.bounce == 0)
     {
         const uint32_t chunks = args.screen.pixels_padded >> 6;
         uint32_t       gx     = (chunks + 3) / 4;
         if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
         if (gx == 0) gx = 1;
+        const dim3 grid(gx, args.n_slots), block(kBlock);
         if (ext)
-            hipLaunchKernelGGL((k_trace_shade<true, true>), dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, bvh, args);
+            hipLaunchKernelGGL((k_trace_shade<true, true, false, false>), grid, block, 0, cfg.stream, bvh, args);
+        else if (lds)
+            hipLaunchKernelGGL((k_trace_shade<true, false, false, true>), grid, block, 0, cfg.stream, bvh, args);
         else
-            hipLaunchKernelGGL((k_trace_shade<true, false>), dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, bvh, args);
+            hipLaunchKernelGGL((k_trace_shade<true, false, false, false>), grid, block, 0, cfg.stream, bvh, args);
+        return;
     }
-    else if (ext)
-        hipLaunchKernelGGL((k_trace_shade<false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh, args);
+    const dim3 grid(queue_grid(cfg, args.max_count)), block(kBlock);
+    if (ext)
+        hipLaunchKernelGGL((k_trace_shade<false, true, false, false>), grid, block, 0, cfg.stream, bvh, args);
+    else if (feedback && lds)
+        hipLaunchKernelGGL((k_trace_shade<false, false, true, true>), grid, block, 0, cfg.stream, bvh, args);
     else if (feedback)
-        hipLaunchKernelGGL((k_trace_shade<false, false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh,
-                           args);
+        hipLaunchKernelGGL((k_trace_shade<false, false, true, false>), grid, block, 0, cfg.stream, bvh, args);
+    else if (lds)
+        hipLaunchKernelGGL((k_trace_shade<false, false, false, true>), grid, block, 0, cfg.stream, bvh, args);
     else
-        hipLaunchKernelGGL((k_trace_shade<false, false>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, bvh, args);
+        hipLaunchKernelGGL((k_trace_shade<false, false, false, false>), grid, block, 0, cfg.stream, bvh, args);
 }
 
 // ------------------------------------------------------------------------------------------------
