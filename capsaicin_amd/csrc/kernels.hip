@@ -232,16 +232,37 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const floa
 {
     best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
     const uint32_t n = bvh.tri_count;
-#pragma unroll 2
-    for (uint32_t k = 0; k < n; ++k)
-    {
+    // One candidate per triangle: its t, or +inf when the ray misses it.  A wave issues dependent VALU instructions at half the
+    // rate of independent ones on this machine (tools/micro/valu_peak.hip: 4.7 vs 2.6 cycles per wave64 fma per SIMD, whatever
+    // the number of resident waves), so four triangles are tested side by side and reduced by a tree; "(t, id) lexicographic
+    // minimum" is associative, so the tree gives the winner of the sequential rule.
+    auto candidate = [&](uint32_t k) {
         float4 t0, t1, t2, t3;
         load_const_tri(bvh.tris_by_id, k, t0, t1, t2, t3);
         const TriScaled s      = tri_scaled(r, t0, t1, t2);
         const bool      inside = (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det);
         const float     tt     = s.T * rcp_c(s.det);
-        const bool      better = inside & (tt > r.tmin) & (tt < best_t);
-        best_t   = better ? tt : best_t;
+        return (inside & (tt > r.tmin)) ? tt : __builtin_inff();
+    };
+    uint32_t k = 0;
+    for (; k + 4 <= n; k += 4)
+    {
+        const float c0 = candidate(k), c1 = candidate(k + 1), c2 = candidate(k + 2), c3 = candidate(k + 3);
+        const bool  p01 = c1 < c0, p23 = c3 < c2;  // strict: the earlier triangle keeps an equal t
+        const float m01 = p01 ? c1 : c0, m23 = p23 ? c3 : c2;
+        const uint32_t i01 = p01 ? k + 1 : k, i23 = p23 ? k + 3 : k + 2;
+        const bool     p   = m23 < m01;
+        const float    m   = p ? m23 : m01;
+        const uint32_t im  = p ? i23 : i01;
+        const bool     better = m < best_t;
+        best_t   = better ? m : best_t;
+        best_gid = better ? im : best_gid;
+    }
+    for (; k < n; ++k)
+    {
+        const float c      = candidate(k);
+        const bool  better = c < best_t;
+        best_t   = better ? c : best_t;
         best_gid = better ? k : best_gid;
     }
     if (best_gid != kInvalidId)
@@ -258,7 +279,7 @@ __device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r)
 {
     const uint32_t n   = bvh.tri_count;
     bool           hit = false;
-#pragma unroll 2
+#pragma unroll 4
     for (uint32_t k = 0; k < n; ++k)
     {
         float4 t0, t1, t2, t3;
@@ -1358,7 +1379,10 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
 {
     constexpr bool CARRY    = !EXT;
     const uint32_t Ppad     = a.screen.pixels_padded;
-    const uint32_t chunks   = FIRST ? (Ppad >> 6) : (a.in.class_capacity >> 6) * kQueueClasses;
+    // FIRST: the identity queue of the whole batch, chunk = slot * (Ppad / 64) + 64-pixel group.  Otherwise: chunk slots of the
+    // input queue.  Either way the grid is persistent (the LDS tables are staged once per workgroup, not once per frame slot).
+    const uint32_t cps      = Ppad >> 6;
+    const uint32_t chunks   = FIRST ? cps * a.n_slots : (a.in.class_capacity >> 6) * kQueueClasses;
     uint32_t       n_shaded = 0;
     __shared__ FrameConst lds_frames[kMaxFrameSlots];
     __shared__ float4     lds_shade[LDS ? 6 * kExhaustiveMax : 1];
@@ -1376,21 +1400,22 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
     st.start();
     for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
     {
-        uint32_t i, klass, pid = 0;
+        uint32_t i, klass, pid = 0, slot = 0;
         bool     active;
         v3       thr = mk3(1.0f, 1.0f, 1.0f);
         Ray      r   = make_ray(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 1.f), 0.0f, 0.0f);  // empty interval: hits nothing
         float    carried_r1 = 0.f, carried_r2 = 0.f;
         if (FIRST)
         {
-            i      = chunk * 64 + (threadIdx.x & 63u);
+            slot   = chunk / cps;  // wave-uniform
+            i      = (chunk - slot * cps) * 64 + (threadIdx.x & 63u);
             active = true;
-            klass  = (blockIdx.y * (Ppad >> 6) + chunk) % kQueueClasses;
-            pid    = (blockIdx.y << kPidShift) | i;
+            klass  = chunk % kQueueClasses;  // the path's class for its whole life
+            pid    = (slot << kPidShift) | i;
             uint32_t x, y;
             if (local_pixel_to_xy(a.screen, i, x, y))
                 r = make_ray(mk3(a.cam.position[0], a.cam.position[1], a.cam.position[2]),
-                             primary_dir(a.cam, a.screen, a.frames[blockIdx.y], x, y), 0.0f, kPrimaryFar);
+                             primary_dir(a.cam, a.screen, lds_frames[slot], x, y), 0.0f, kPrimaryFar);
         }
         else
         {
@@ -1411,7 +1436,7 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
         exhaustive_closest(bvh, rec_tab, r, t, u, v, gid);
         STAMP(st, 1, true);  // triangle loop + winner's record
         const ShadePre pre = shade_prefetch<EXT, FIRST, CARRY>(a, lds_frames, active, pid, carried_r1, carried_r2);
-        if (FIRST && blockIdx.y == a.aov_slot)
+        if (FIRST && slot == a.aov_slot)
         {
             // rt_primary_visibility.hlsl:46: (uv, asfloat(InstanceID), asfloat(PrimitiveIndex)); a miss keeps uv = 0, ids = ~0u
             float4 g = make_float4(0.f, 0.f, u2f(kInvalidId), u2f(kInvalidId));
@@ -1450,11 +1475,11 @@ void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs
     const bool lds = !ext && bvh.tri_count <= kExhaustiveMax;
     if (args.bounce == 0)
     {
-        const uint32_t chunks = args.screen.pixels_padded >> 6;
+        const uint32_t chunks = (args.screen.pixels_padded >> 6) * args.n_slots;
         uint32_t       gx     = (chunks + 3) / 4;
         if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
         if (gx == 0) gx = 1;
-        const dim3 grid(gx, args.n_slots), block(kBlock);
+        const dim3 grid(gx), block(kBlock);
         if (ext)
             hipLaunchKernelGGL((k_trace_shade<true, true, false, false>), grid, block, 0, cfg.stream, bvh, args);
         else if (lds)
