@@ -21,8 +21,9 @@ void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraD
 void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits);
 // Any hit for the shadow-ray queue (lighting.h:48-61); unoccluded rays add contrib to target[plane index].
 // guard: 4 x uint64 {shaded vertices, malformed path ids seen by shade, by trace_any, last offender}
+// work: kQueueClasses zeroed chunk-grab counters for this launch (exhaustive path; may be NULL for the LBVH kernels)
 void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target,
-                      uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard);
+                      uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard, uint32_t* work);
 
 // ---- shade ----
 struct ShadeArgs
@@ -42,6 +43,7 @@ struct ShadeArgs
     uint32_t          max_count;   // upper bound of the input queue length
     uint32_t          aov_slot;    // frame slot whose AOVs are kept, or ~0u
     uint64_t*         shaded_counter;
+    uint32_t*         work;        // fused kernels: kQueueClasses chunk-grab counters of this launch (zeroed), kCounterStride apart
     FeedbackDev       fb;          // read only by the feedback variants
 };
 // feedback: vertices of bounce >= 1 that the previous frame saw take its shaded colour and end the path (rt_indirect.hlsl:116-145;

@@ -354,7 +354,8 @@ int ensure_wavefront(CapContext* c, uint32_t slots, uint32_t bounces)
     HIP_TRY(c->pl_albedo.ensure(planes_np));
     HIP_TRY(c->aov_geo.ensure(c->screen.pixels_padded));
     HIP_TRY(c->aov_nd.ensure(c->screen.pixels_padded));
-    HIP_TRY(c->counters.ensure(2 * (size_t)(bounces + 1) * kQueueClasses * kCounterStride));
+    // queue counters (ext + shadow share words) + chunk-grab counters of the fused and of the any-hit launch, per bounce
+    HIP_TRY(c->counters.ensure(3 * (size_t)(bounces + 1) * kQueueClasses * kCounterStride));
     if (!c->shaded_counter.p)
     {
         HIP_TRY(c->shaded_counter.ensure(4));
@@ -814,9 +815,11 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         const size_t   per_queue     = (size_t)kQueueClasses * kCounterStride;  // counter words of one queue
         // per bounce and class one 64-bit word: low half = extension entries, high half = shadow entries (one atomic serves both)
         const size_t   counter_words = (size_t)(D + 1) * per_queue;
-        HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * counter_words, c->stream));
+        HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * 3 * counter_words, c->stream));
         uint32_t*      ext_count = c->counters.p;
         uint32_t*      sh_count  = c->counters.p + 1;
+        uint32_t*      work_shade = c->counters.p + counter_words;      // + b * per_queue: grab counters of bounce b's fused launch
+        uint32_t*      work_any   = c->counters.p + 2 * counter_words;  // ... and of its any-hit launch
         const uint32_t total_chunks   = ns * (Ppad >> 6);
         const uint32_t class_capacity = ((total_chunks + kQueueClasses - 1) / kQueueClasses) * 64u;
         const bool     last_batch = done + ns >= n_frames;
@@ -856,6 +859,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             sa.in        = RayQueue{c->q_org[pi].p, c->q_dir[pi].p, c->q_thr[pi].p, b ? ext_count + (b - 1) * per_queue : nullptr, class_capacity};
             sa.out       = RayQueue{c->q_org[po].p, c->q_dir[po].p, c->q_thr[po].p, ext_count + b * per_queue, class_capacity};
             sa.shadow    = ShadowQueue{c->s_org.p, c->s_dir.p, c->s_con.p, sh_count + b * per_queue, class_capacity};
+            sa.work      = work_shade + b * per_queue;
             if (fused)
             {
                 StageTimer t(c, b == 0 ? ST_PRIMARY : ST_CLOSEST, st);
@@ -871,7 +875,8 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             }
             {
                 StageTimer t(c, ST_ANY, st);
-                launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p);
+                launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p,
+                                 work_any + b * per_queue);
                 ++c->stats.launches_trace_any;
                 if (traced("trace_any", b)) return fail(CAP_ERR_HIP, "trace_any failed");
             }

@@ -315,6 +315,19 @@ __device__ __forceinline__ bool trace_any_any_size(const BvhDev& bvh, const Ray&
 __device__ __forceinline__ uint32_t wave_global_id() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
 __device__ __forceinline__ uint32_t wave_total() { return gridDim.x * (kBlock / 64); }
 
+// Dynamic chunk distribution.  A wave works on the chunk slots of ONE class (its index mod kQueueClasses) and takes them in order
+// from that class's work counter (64 counters on their own 128-B lines, zeroed per launch; <= 5 grabs per microsecond each).
+// Measured need (tools/wave_times.py): with a static slot-to-wave assignment the CU's oldest waves win the issue arbitration,
+// finish their share at half the kernel's duration and leave the tail to a few starved young waves (mean wave life 70 % of the
+// launch).  The grab for the NEXT chunk is issued before the current chunk is processed, so its latency is never waited for.
+__device__ __forceinline__ uint32_t grab_issue(uint32_t* work, uint32_t klass)
+{
+    uint32_t v = 0;
+    if ((threadIdx.x & 63u) == 0) v = atomicAdd(work + klass * kCounterStride, 1u);
+    return v;  // lane 0 holds the value; grab_value() broadcasts it
+}
+__device__ __forceinline__ uint32_t grab_value(uint32_t raw) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)raw); }
+
 // camera.h:39-63
 __device__ __forceinline__ v3 primary_dir(const CameraDev& cam, const ScreenDev& sc, const FrameConst& fc, uint32_t x, uint32_t y)
 {
@@ -374,15 +387,22 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(BvhDev bvh, RayQueue q
 
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded, uint32_t n_slots,
-                                                      uint64_t* guard)
+                                                      uint64_t* guard, uint32_t* work)
 {
     __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
-    uint32_t*           stack  = lds_stack + threadIdx.x;
-    const uint32_t      slots  = (q.class_capacity >> 6) * kQueueClasses;
-    for (uint32_t cs = wave_global_id(); cs < slots; cs += wave_total())
+    uint32_t*           stack    = lds_stack + threadIdx.x;
+    const uint32_t      slots    = (q.class_capacity >> 6) * kQueueClasses;
+    const uint32_t      my_class = wave_global_id() % kQueueClasses;
+    uint32_t            grab     = grab_issue(work, my_class);
+    while (true)
     {
-        uint32_t i, klass;
-        if (queue_chunk(q.count, q.class_capacity, cs, threadIdx.x & 63u, i, klass))
+        const uint32_t cs = grab_value(grab) * kQueueClasses + my_class;
+        if (cs >= slots) break;
+        grab = grab_issue(work, my_class);
+        uint32_t   i, klass;
+        const bool active = queue_chunk(q.count, q.class_capacity, cs, threadIdx.x & 63u, i, klass);
+        if (__ballot(active) == 0ull) break;  // past the end of this class's sub-queue
+        if (active)
         {
             const float4 a = q.org_tmin[i], b = q.dir_tmax[i];
             const Ray    r = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
@@ -397,13 +417,15 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q,
                     // never true for a well-formed queue; reported through CapStats::guard_* instead of faulting
                     atomicAdd((unsigned long long*)guard + 2, 1ull);
                     guard[3] = ((uint64_t)i << 32) | pid;
-                    continue;
                 }
-                const size_t   idx = (size_t)(pid >> kPidShift) * pixels_padded + (pid & kPidMask);
-                float*         tv  = reinterpret_cast<float*>(target + idx);
-                atomicAdd(tv + 0, c.x);  // sole writer of this path: IEEE adds in program order, no wait for the old value
-                atomicAdd(tv + 1, c.y);
-                atomicAdd(tv + 2, c.z);
+                else
+                {
+                    const size_t idx = (size_t)(pid >> kPidShift) * pixels_padded + (pid & kPidMask);
+                    float*       tv  = reinterpret_cast<float*>(target + idx);
+                    atomicAdd(tv + 0, c.x);  // sole writer of this path: IEEE adds in program order, no wait for the old value
+                    atomicAdd(tv + 1, c.y);
+                    atomicAdd(tv + 2, c.z);
+                }
             }
         }
     }
@@ -690,17 +712,17 @@ void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueu
 }
 
 void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target,
-                      uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard)
+                      uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard, uint32_t* work)
 {
     dim3 grid(queue_grid(cfg, max_count));
     if (cfg.stack_entries == 0)
-        hipLaunchKernelGGL(k_trace_any<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard);
+        hipLaunchKernelGGL(k_trace_any<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard, work);
     // shadow rays share one direction per frame and retire early: the plain per-chunk kernel beats the refill variant here
     // (8.3 vs 10.5 ms on the 262 k-triangle scene); k_trace_any_refill stays available for incoherent occlusion rays (EXT: NEE)
     else if (cfg.stack_entries <= 32)
-        hipLaunchKernelGGL(k_trace_any<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard);
+        hipLaunchKernelGGL(k_trace_any<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard, work);
     else
-        hipLaunchKernelGGL(k_trace_any<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard);
+        hipLaunchKernelGGL(k_trace_any<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard, work);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -889,20 +911,24 @@ __device__ __forceinline__ void wave_append2(bool emit_ext, bool emit_shadow, ui
 // Diagnostic build only (-DCAP_STAMPS): per-phase shader-clock sums of the fused kernel, see tools/stamps.py.
 #ifdef CAP_STAMPS
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_wave_times[2 * 16384];  // (start, end) s_memrealtime of every wave of the LAST fused launch
 struct Stamps
 {
-    unsigned long long last, acc[8];
+    unsigned long long last, acc[8], t_begin;
     __device__ void    start()
     {
         for (int i = 0; i < 8; ++i) acc[i] = 0;
-        last = __builtin_amdgcn_s_memtime();
+        last    = __builtin_amdgcn_s_memtime();
+        t_begin = __builtin_amdgcn_s_memrealtime();
     }
     __device__ void mark(int i, bool wait)
     {
+#ifdef CAP_STAMPS_PHASES
         if (wait) __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
         const unsigned long long now = __builtin_amdgcn_s_memtime();
         acc[i] += now - last;
         last = now;
+#endif
     }
     __device__ void flush()
     {
@@ -1398,8 +1424,19 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
     const float4* rec_tab   = LDS ? lds_rec : bvh.tris_by_id;
     Stamps st;
     st.start();
+#ifdef CAP_FUSED_DYNAMIC
+    const uint32_t my_class = wave_global_id() % kQueueClasses;
+    uint32_t       grab     = grab_issue(a.work, my_class);
+    while (true)
+    {
+        const uint32_t chunk = grab_value(grab) * kQueueClasses + my_class;  // slot j of this class
+        if (chunk >= chunks) break;
+        grab = grab_issue(a.work, my_class);
+#else
+    // static assignment here: the grab costs this kernel more (one more returned atomic per chunk) than the balance buys
     for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
     {
+#endif
         uint32_t i, klass, pid = 0, slot = 0;
         bool     active;
         v3       thr = mk3(1.0f, 1.0f, 1.0f);
@@ -1420,7 +1457,7 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
         else
         {
             active = queue_chunk(a.in.count, a.in.class_capacity, chunk, threadIdx.x & 63u, i, klass);
-            if (__ballot(active) == 0ull) continue;  // unoccupied chunk slot of this class: nothing to trace (wave-uniform)
+            if (__ballot(active) == 0ull) break;  // past the end of this class's sub-queue: every later slot is empty too
             if (active)
             {
                 // extension rays: tmin / tmax are constants (rt_indirect.hlsl:154-157); with CARRY the .w slots hold the sample
@@ -1454,12 +1491,20 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
         STAMP(st, 4, false);  // stores issued
     }
     if (!FIRST && !EXT && !FB) st.flush();
+#ifdef CAP_STAMPS
+    if (!FIRST && !EXT && !FB && (threadIdx.x & 63u) == 0 && wave_global_id() < 16384)
+    {
+        g_wave_times[2 * wave_global_id() + 0] = st.t_begin;
+        g_wave_times[2 * wave_global_id() + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     flush_shaded(a.shaded_counter, n_shaded);
 }
 
 #ifdef CAP_STAMPS
 extern "C" int cap_debug_stamps(unsigned long long* out, int reset)
 {
+    if (reset == 2) return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), 2 * 16384 * sizeof(unsigned long long));
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long));
     if (e == hipSuccess && reset)
     {
