@@ -17,8 +17,9 @@ RENDER_AOV = 1
 RENDER_EXT_MATERIALS = 2
 RENDER_STAGE_TIMERS = 4
 RENDER_GBUFFER_FEEDBACK = 8
+RENDER_LOWRES_INDIRECT = 16
 
-BUF_GBUFFER_GEO, BUF_DIRECT, BUF_ALBEDO, BUF_NORMAL_DEPTH, BUF_INDIRECT, BUF_COMBINED, BUF_ACCUM_SUM, BUF_ACCUM_MEAN = range(8)
+BUF_GBUFFER_GEO, BUF_DIRECT, BUF_ALBEDO, BUF_NORMAL_DEPTH, BUF_INDIRECT, BUF_COMBINED, BUF_ACCUM_SUM, BUF_ACCUM_MEAN, BUF_INDIRECT_LOWRES = range(9)
 
 
 class CapError(RuntimeError):
@@ -56,10 +57,10 @@ class PostSettings(C.Structure):
     _fields_ = [("gather", C.c_int32), ("denoise", C.c_int32), ("eaw5", C.c_int32), ("eaw_normal_sigma", C.c_float),
                 ("eaw_depth_sigma", C.c_float), ("eaw_luma_sigma", C.c_float), ("gather_normal_sigma", C.c_float),
                 ("gather_depth_sigma", C.c_float), ("gather_luma_sigma", C.c_float), ("temporal_upscale_feedback", C.c_float),
-                ("taa_feedback", C.c_float)]
+                ("taa_feedback", C.c_float), ("lowres_indirect", C.c_int32)]
 
     def __init__(self, **kw):
-        super().__init__(1, 1, 1, 128.0, 3.0, 3.0, 64.0, 2.0, 3.0, 0.975, 0.9)
+        super().__init__(1, 1, 1, 128.0, 3.0, 3.0, 64.0, 2.0, 3.0, 0.975, 0.9, 0)
         for k, v in kw.items():
             setattr(self, k, v)
 
@@ -298,7 +299,10 @@ class Renderer:
         _check(lib().cap_sync(self.ctx), "cap_sync")
 
     def readback(self, kind):
-        out = np.zeros((self.height, self.width, 4), np.float32)
+        if kind == BUF_INDIRECT_LOWRES:
+            out = np.zeros((self.height // 2, self.width // 2, 4), np.float32)
+        else:
+            out = np.zeros((self.height, self.width, 4), np.float32)
         _check(lib().cap_readback(self.ctx, kind, _p(out)), "cap_readback")
         return out
 

@@ -50,7 +50,7 @@ struct FrameConst
 {
     float    jitter_x, jitter_y;
     uint32_t frame_count;
-    uint32_t pad;
+    uint32_t lowres_sel;  // LOWRES_INDIRECT (rt_indirect.hlsl:53-59): bit 2 = on, bit 1 = sp_offset.x, bit 0 = sp_offset.y
     float    light_dir[3];
     float    pad1;
     float    light_intensity[3];

@@ -99,6 +99,7 @@ struct PostSettingsDev  // SettingsComponent subset, gui_system.h:20-37
     float eaw_normal_sigma, eaw_depth_sigma, eaw_luma_sigma;
     float gather_normal_sigma, gather_depth_sigma, gather_luma_sigma;
     float temporal_upscale_feedback, taa_feedback;
+    int   lowres_indirect;  // UPSCALE2X: `indirect` is the (W/2, H/2) image of this frame's interleave offset
 };
 struct PostChainArgs
 {
@@ -114,4 +115,6 @@ struct PostChainArgs
 };
 // The frame's output is combined_history[frame_count % 2] (raytracing_system.cpp:320-324).
 void launch_post_chain(hipStream_t stream, const PostChainArgs& a);
+// out[(y, x)] = full[(2y + oy, 2x + ox)]: the half-resolution indirect image of LOWRES_INDIRECT (rt_indirect.hlsl:53-59, :176)
+void launch_decimate2x(hipStream_t stream, const float4* full, uint32_t width, uint32_t height, uint32_t ox, uint32_t oy, float4* out);
 }  // namespace cap

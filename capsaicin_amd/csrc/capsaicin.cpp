@@ -195,10 +195,11 @@ void run_raytracing(World& w)
         // ray passes + SpatialGather .. ApplyTAA of one frame (raytracing_system.cpp:262-317)
         const Settings& s = w.settings;
         if (s.frames_per_render != 1) error_throw("RaytracingSystem: the reconstruction pipeline renders one frame per Render()");
-        const uint32_t flags = CAP_RENDER_STAGE_TIMERS | CAP_RENDER_AOV | (s.gbuffer_feedback ? (uint32_t)CAP_RENDER_GBUFFER_FEEDBACK : 0u);
+        const uint32_t flags = CAP_RENDER_STAGE_TIMERS | CAP_RENDER_AOV | (s.gbuffer_feedback ? (uint32_t)CAP_RENDER_GBUFFER_FEEDBACK : 0u) |
+                               (s.lowres_indirect ? (uint32_t)CAP_RENDER_LOWRES_INDIRECT : 0u);
         check(cap_render(w.ctx, w.frame_count, 1, (uint32_t)std::max(0, s.num_diffuse_bounces), flags), "RaytracingSystem");
         CapPostSettings ps{s.gather, s.denoise, s.eaw5, s.eaw_normal_sigma, s.eaw_depth_sigma, s.eaw_luma_sigma, s.gather_normal_sigma,
-                           s.gather_depth_sigma, s.gather_luma_sigma, s.temporal_upscale_feedback, s.taa_feedback};
+                           s.gather_depth_sigma, s.gather_luma_sigma, s.temporal_upscale_feedback, s.taa_feedback, s.lowres_indirect};
         CapCameraData   prev;
         std::memcpy(&prev, &w.prev_camera, sizeof(prev));
         check(cap_post_frame(w.ctx, &ps, w.frame_count, &prev), "RaytracingSystem");

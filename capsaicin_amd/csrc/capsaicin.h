@@ -28,6 +28,7 @@ struct Settings
     // the ray passes, G-buffer feedback in the indirect pass.  ReadFrame() then returns current_frame_output().
     bool  reconstruct               = false;
     bool  gbuffer_feedback          = true;    // RaytracingOptions::gbuffer_feedback, raytracing_system.h:26
+    bool  lowres_indirect           = false;   // RaytracingOptions::lowres_indirect, raytracing_system.h:24 (even window sizes)
     bool  gather                    = true;    // gui_system.h:20-37
     bool  denoise                   = true;
     bool  eaw5                      = true;

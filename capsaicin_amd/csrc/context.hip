@@ -150,6 +150,8 @@ struct CapContext
     uint32_t           slots_alloc = 0, bounces_alloc = 0;
     uint32_t           last_slots = 0;     // frame slots of the last batch rendered (AOV readback)
     bool               aov_valid = false;
+    bool               aov_lowres = false;  // the AOV frame was rendered with CAP_RENDER_LOWRES_INDIRECT
+    uint32_t           aov_frame  = 0;      // its frame_count (selects the 2x2 interleave offset)
     uint64_t           frames_accumulated = 0;
 
     // reconstruction chain (row-major W*H images)
@@ -289,11 +291,13 @@ CameraDev camera_dev(const CapCameraData& cd)
 }
 
 // lighting.h:20-33 + camera.h:41, evaluated once per frame on the host with the shared arithmetic contract
-FrameConst frame_const(uint32_t frame_count)
+FrameConst frame_const(uint32_t frame_count, bool lowres_indirect)
 {
     FrameConst f{};
     halton23(frame_count, f.jitter_x, f.jitter_y);
     f.frame_count = frame_count;
+    // rt_indirect.hlsl:55-56: sp_offset = ((frame % 4) / 2, (frame % 4) % 2)
+    f.lowres_sel = lowres_indirect ? (4u | (((frame_count % 4u) / 2u) << 1) | ((frame_count % 4u) % 2u)) : 0u;
     const float t = 2.0f * 3.14f * (float)(frame_count % 4096) / 4096.0f;
     float       st, ct;
     sincos_c(t, st, ct);
@@ -765,6 +769,16 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             if (int e = cap_post_reset(c)) return e;  // first frame: cleared histories, every vertex is a disocclusion
     }
 
+    const bool lowres = (flags & CAP_RENDER_LOWRES_INDIRECT) != 0;
+    if (lowres)
+    {
+        // the half-resolution indirect image only exists per frame (2x2 interleave over four frames): nothing to accumulate
+        if (ext) return fail(CAP_ERR_UNSUPPORTED, "cap_render: CAP_RENDER_LOWRES_INDIRECT is defined for the reference shading model only");
+        if (n_frames != 1) return fail(CAP_ERR_INVALID_ARG, "cap_render: CAP_RENDER_LOWRES_INDIRECT renders one frame per call (n_frames is %u)", n_frames);
+        if (c->screen.shard_count != 1) return fail(CAP_ERR_UNSUPPORTED, "cap_render: CAP_RENDER_LOWRES_INDIRECT needs an unsharded context");
+        if ((c->screen.width | c->screen.height) & 1u) return fail(CAP_ERR_INVALID_ARG, "cap_render: CAP_RENDER_LOWRES_INDIRECT needs even width and height (%ux%u)", c->screen.width, c->screen.height);
+    }
+
     const uint32_t Ppad = c->screen.pixels_padded;
     uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)8 << 20;
     uint32_t       slots  = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / std::max(1u, Ppad), kMaxFrameSlots));
@@ -775,7 +789,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     HIP_TRY(c->frames.ensure(n_frames));
     {
         std::vector<FrameConst> fcs(n_frames);
-        for (uint32_t f = 0; f < n_frames; ++f) fcs[f] = frame_const(frame_begin + f);
+        for (uint32_t f = 0; f < n_frames; ++f) fcs[f] = frame_const(frame_begin + f, lowres);
         HIP_TRY(hipMemcpy(c->frames.p, fcs.data(), sizeof(FrameConst) * n_frames, hipMemcpyHostToDevice));
     }
     const bool st = (flags & CAP_RENDER_STAGE_TIMERS) != 0;
@@ -887,6 +901,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                 ++c->stats.launches_trace_closest;
             }
         }
+        if (!lowres)
         {
             StageTimer t(c, ST_RESOLVE, st);
             launch_resolve(cfg, sa.planes, ns, Ppad, c->accum.p);
@@ -915,9 +930,11 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         }
         c->stats.rays_primary += valid * ns;
         c->stats.frames += ns;
-        c->frames_accumulated += ns;
+        if (!lowres) c->frames_accumulated += ns;
         c->last_slots = ns;
         c->aov_valid  = aov_slot != ~0u;
+        c->aov_lowres = lowres;
+        c->aov_frame  = frame_begin + done + ns - 1;
         // the next batch reuses counters/frames: serialise on the stream (already), and bound the event backlog
         if (c->spans.size() > 4096)
         {
@@ -942,7 +959,7 @@ int cap_readback(CapContext* c, CapBufferKind kind, float* dst)
     HIP_TRY(c->image_tmp.ensure(npix));
     HIP_TRY(hipMemsetAsync(c->image_tmp.p, 0, sizeof(float4) * npix, c->stream));
     LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
-    const bool is_aov = kind <= CAP_BUF_COMBINED;
+    const bool is_aov = kind <= CAP_BUF_COMBINED || kind == CAP_BUF_INDIRECT_LOWRES;
     if (is_aov && !c->aov_valid) return fail(CAP_ERR_STATE, "cap_readback: no frame rendered with CAP_RENDER_AOV");
     if (!is_aov && !c->accum.p) return fail(CAP_ERR_STATE, "cap_readback: nothing rendered");
     const size_t off = (size_t)(c->last_slots ? c->last_slots - 1 : 0) * Ppad;
@@ -958,6 +975,18 @@ int cap_readback(CapContext* c, CapBufferKind kind, float* dst)
         break;
     case CAP_BUF_ACCUM_SUM: launch_untile(cfg, c->screen, c->accum.p, nullptr, nullptr, 0, c->image_tmp.p); break;
     case CAP_BUF_ACCUM_MEAN: launch_untile(cfg, c->screen, c->accum.p, nullptr, nullptr, 2, c->image_tmp.p); break;
+    case CAP_BUF_INDIRECT_LOWRES:
+    {
+        if (!c->aov_lowres) return fail(CAP_ERR_STATE, "cap_readback: the last CAP_RENDER_AOV frame was not rendered with CAP_RENDER_LOWRES_INDIRECT");
+        launch_untile(cfg, c->screen, c->pl_color.p + off, nullptr, nullptr, 0, c->image_tmp.p);
+        HIP_TRY(c->post_itemp.ensure(npix));
+        launch_decimate2x(c->stream, c->image_tmp.p, c->screen.width, c->screen.height, (c->aov_frame % 4u) / 2u, (c->aov_frame % 4u) % 2u,
+                          c->post_itemp.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(dst, c->post_itemp.p, sizeof(float4) * (npix / 4), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return CAP_OK;
+    }
     default: return fail(CAP_ERR_INVALID_ARG, "cap_readback: unknown buffer kind %d", (int)kind);
     }
     HIP_TRY(hipGetLastError());
@@ -1047,13 +1076,28 @@ int cap_post_frame(CapContext* c, const CapPostSettings* s, uint32_t frame_count
     const uint32_t Ppad = c->screen.pixels_padded;
     const size_t   off  = (size_t)(c->last_slots ? c->last_slots - 1 : 0) * Ppad;
     LaunchCfg      cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
-    launch_untile(cfg, c->screen, c->pl_color.p + off, nullptr, nullptr, 0, c->post_in[0].p);
+    const bool lowres = s->lowres_indirect != 0;
+    if (lowres != c->aov_lowres)
+        return fail(CAP_ERR_STATE, "cap_post_frame: settings.lowres_indirect is %d but the frame was rendered %s CAP_RENDER_LOWRES_INDIRECT",
+                    (int)lowres, c->aov_lowres ? "with" : "without");
+    if (lowres && frame_count != c->aov_frame)
+        return fail(CAP_ERR_INVALID_ARG, "cap_post_frame: frame_count %u is not the rendered frame %u (it selects the 2x2 interleave offset)", frame_count, c->aov_frame);
+    if (lowres)
+    {
+        // output_indirect_ is the (W/2, H/2) image of the pixels at sp_offset (raytracing_system.cpp:499-512)
+        HIP_TRY(c->image_tmp.ensure((size_t)c->screen.width * c->screen.height));
+        launch_untile(cfg, c->screen, c->pl_color.p + off, nullptr, nullptr, 0, c->image_tmp.p);
+        launch_decimate2x(c->stream, c->image_tmp.p, c->screen.width, c->screen.height, (frame_count % 4u) / 2u, (frame_count % 4u) % 2u,
+                          c->post_in[0].p);
+    }
+    else
+        launch_untile(cfg, c->screen, c->pl_color.p + off, nullptr, nullptr, 0, c->post_in[0].p);
     launch_untile(cfg, c->screen, c->pl_direct.p + off, nullptr, nullptr, 0, c->post_in[1].p);
     launch_untile(cfg, c->screen, c->pl_albedo.p + off, nullptr, nullptr, 0, c->post_in[2].p);
     launch_untile(cfg, c->screen, c->aov_nd.p, nullptr, nullptr, 0, c->post_in[3].p);
     PostChainArgs a{};
     a.settings = PostSettingsDev{s->gather, s->denoise, s->eaw5, s->eaw_normal_sigma, s->eaw_depth_sigma, s->eaw_luma_sigma, s->gather_normal_sigma,
-                                 s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback};
+                                 s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback, s->lowres_indirect};
     a.width = c->screen.width, a.height = c->screen.height, a.frame_count = frame_count;
     a.camera = camera_dev(c->camera), a.prev_camera = camera_dev(*prev_camera);
     a.indirect = c->post_in[0].p, a.direct = c->post_in[1].p, a.albedo = c->post_in[2].p, a.normal_depth = c->post_in[3].p;

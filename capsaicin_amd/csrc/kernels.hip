@@ -837,6 +837,7 @@ struct ShadePre
     float r1, r2;  // sampling.h:13-23 sample of (pixel, frame * 25 + bounce)
     float r3, r4, r5, r6;  // EXT only: B, A of the same texel; R, G of the texel of count + 7
     float r1n, r2n;        // CARRY only: the sample of the path's NEXT vertex (count + 1), handed on in the queue entry
+    bool  indirect_on;     // false for the three pixels of a 2x2 block that get no indirect sample this frame (LOWRES_INDIRECT)
 };
 
 // The per-frame constants of the batch (48 B x n_slots <= 3 KB) are staged in LDS once per workgroup: a path finds its frame's
@@ -865,9 +866,11 @@ __device__ __forceinline__ ShadePre shade_prefetch(const ShadeArgs& a, const Fra
     s.L = mk3(0, 0, 0), s.I = mk3(0, 0, 0), s.r1 = 0.f, s.r2 = 0.f;
     s.r3 = s.r4 = s.r5 = s.r6 = 0.f;
     s.r1n = s.r2n = 0.f;
+    s.indirect_on = true;
     if (s.valid)
     {
         const FrameConst fc = lds_frames[slot < kMaxFrameSlots ? slot : 0];
+        if (fc.lowres_sel & 4u) s.indirect_on = (x & 1u) == ((fc.lowres_sel >> 1) & 1u) && (y & 1u) == (fc.lowres_sel & 1u);
         s.L = mk3(fc.light_dir[0], fc.light_dir[1], fc.light_dir[2]);
         s.I = mk3(fc.light_intensity[0], fc.light_intensity[1], fc.light_intensity[2]);
         const uint32_t count = fc.frame_count * 25u + a.bounce;
@@ -1082,7 +1085,7 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
                     thr           = thr * f;
                     if (!FIRST) thr = thr * kd;
                     // the reference traces one more ray after the last bounce whose payload is never read (:91,:173)
-                    emit_ext = a.bounce < a.num_bounces;
+                    emit_ext = a.bounce < a.num_bounces && (!FIRST || pre.indirect_on);
                 }
             }
         }

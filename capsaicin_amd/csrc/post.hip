@@ -126,11 +126,16 @@ __global__ __launch_bounds__(kBlock) void k_decode_normals(const float4* nd, flo
 }
 
 // spatial_gather.hlsl:28-109.  nd = decoded (normal.xyz, depth) image of k_decode_normals.
-__global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color, Img nd, float4* out)
+// UP (UPSCALE2X, :36-46, :83-87): the grid and `color` are half resolution and the G-buffer is read at (xy << 1) + (ox, oy).
+// The taps are bounded by the FULL window size, as the host passes it (raytracing_system.cpp:1562-1569): a tap beyond the
+// half-resolution image reads a G-buffer texel outside the window, i.e. depth 0, and is skipped as background.
+template <bool UP>
+__global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color, Img nd, float4* out, int ox, int oy)
 {
     uint32_t x, y;
     if (!pixel_of_thread(color.w, color.h, x, y)) return;
-    const float4 cg = ld(nd, x, y);
+    const int    bound_w = UP ? (int)nd.w : (int)color.w, bound_h = UP ? (int)nd.h : (int)color.h;
+    const float4 cg = UP ? ldi(nd, ((int)x << 1) + ox, ((int)y << 1) + oy) : ld(nd, x, y);
     const v3     cn = xyz(cg);
     const float  cd = cg.w;
     const v3     cc = xyz(ld(color, x, y));
@@ -146,9 +151,9 @@ __global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color,
             for (int dx = -3; dx <= 3; ++dx)
             {
                 const int sx = (int)x + dx, sy = (int)y + dy;
-                if (sx < 0 || sy < 0 || sx >= (int)color.w || sy >= (int)color.h) continue;
+                if (sx < 0 || sy < 0 || sx >= bound_w || sy >= bound_h) continue;
                 const v3     c = xyz(ldi(color, sx, sy));
-                const float4 g = ldi(nd, sx, sy);
+                const float4 g = UP ? ldi(nd, (sx << 1) + ox, (sy << 1) + oy) : ldi(nd, sx, sy);
                 if (g.w < 1e-5f) continue;
                 const v3    n   = xyz(g);
                 const float len = sqrtf((float)(dx * dx + dy * dy));
@@ -160,6 +165,17 @@ __global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color,
         res        = make_float4(r.x, r.y, r.z, 1.0f);
     }
     out[(size_t)y * color.w + x] = res;
+}
+
+// out[(y, x)] = full[(2y + oy, 2x + ox)]
+__global__ __launch_bounds__(kBlock) void k_decimate2x(const float4* full, uint32_t w, uint32_t h, uint32_t ox, uint32_t oy, float4* out)
+{
+    const uint32_t w2 = w >> 1, h2 = h >> 1;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < w2 * h2; i += gridDim.x * kBlock)
+    {
+        const uint32_t y = i / w2, x = i - y * w2;
+        out[i] = full[(size_t)(2u * y + oy) * w + (2u * x + ox)];
+    }
 }
 
 // temporal_accumulation.hlsl:179-205
@@ -177,13 +193,14 @@ __device__ __forceinline__ float closest_depth(const Img& g, f2 xy)
     return closest;
 }
 
-// temporal_accumulation.hlsl:213-325
+// temporal_accumulation.hlsl:213-325.  With UPSCALE2X (s.lowres_indirect) `color` is the half-resolution image (SampleColor uses its
+// size, :228-235) and a pixel that got no new sample this frame keeps its history (:307-313).
 __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32_t frame_count, CameraDev cam, CameraDev prev_cam, Img color,
                                                        Img nd, Img color_history, Img moments_history, Img prev_nd, float4* out_color,
                                                        float4* out_moments)
 {
     uint32_t x, y;
-    const uint32_t W = color.w, H = color.h;
+    const uint32_t W = nd.w, H = nd.h;
     if (!pixel_of_thread(W, H, x, y)) return;
     const f2     uv = f2{((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H};
     const float4 g  = ld(nd, x, y);
@@ -213,11 +230,16 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32
     }
     float          alpha    = s.temporal_upscale_feedback;
     const v3       history  = resample_bicubic(color_history, puv);
-    const uint32_t hist_len = sat_uint(ld(moments_history, sat_uint(floorf(pxy.x)), sat_uint(floorf(pxy.y))).w);
+    uint32_t       hist_len = sat_uint(ld(moments_history, sat_uint(floorf(pxy.x)), sat_uint(floorf(pxy.y))).w);
     if (hist_len < 256u)
     {
         const float t = 1.0f / (float)(hist_len + 1);
         alpha         = fminf(alpha, 1.0f - t);
+    }
+    if (s.lowres_indirect && ((x % 2u) != (frame_count % 4u) / 2u || (y % 2u) != (frame_count % 4u) % 2u))
+    {
+        alpha = 1.0f;
+        hist_len -= 1u;  // uint: a length of 0 wraps and the + 1 below brings it back to 0
     }
     const v3    mh = resample_bicubic(moments_history, puv);
     const float m0 = lerp1(l, mh.x, alpha), m1 = lerp1(l * l, mh.y, alpha);
@@ -407,14 +429,21 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     if (cg == 0) cg = 1;
     if (a.settings.gather || a.settings.denoise)
         hipLaunchKernelGGL(k_decode_normals, dim3(cg), block, 0, stream, a.normal_depth, a.normals, W * H);
-    // SpatialGather (cpp:1541-1604)
-    if (a.settings.gather)
-        hipLaunchKernelGGL(k_gather, grid, block, 0, stream, a.settings, img(a.indirect), img(a.normals), a.indirect_temp);
+    // SpatialGather (cpp:1541-1604); with lowres_indirect the input, the grid and indirect_temp are (W/2, H/2)
+    const bool     up = a.settings.lowres_indirect != 0;
+    const uint32_t IW = up ? W >> 1 : W, IH = up ? H >> 1 : H;
+    const Img      indirect_in{a.indirect, IW, IH};
+    const int      ox = (int)((a.frame_count % 4u) / 2u), oy = (int)((a.frame_count % 4u) % 2u);
+    if (a.settings.gather && up)
+        hipLaunchKernelGGL(k_gather<true>, dim3((IW + 31) / 32, (IH + 7) / 8), block, 0, stream, a.settings, indirect_in, img(a.normals),
+                           a.indirect_temp, ox, oy);
+    else if (a.settings.gather)
+        hipLaunchKernelGGL(k_gather<false>, grid, block, 0, stream, a.settings, indirect_in, img(a.normals), a.indirect_temp, 0, 0);
     else
-        (void)hipMemcpyAsync(a.indirect_temp, a.indirect, bytes, hipMemcpyDeviceToDevice, stream);
+        (void)hipMemcpyAsync(a.indirect_temp, a.indirect, sizeof(float4) * (size_t)IW * IH, hipMemcpyDeviceToDevice, stream);
     // IntegrateTemporally (cpp:1283-1342)
-    hipLaunchKernelGGL(k_accumulate, grid, block, 0, stream, a.settings, a.frame_count, a.camera, a.prev_camera, img(a.indirect_temp),
-                       img(a.normal_depth), img(a.indirect_history[src]), img(a.moments_history[src]), img(a.prev_normal_depth),
+    hipLaunchKernelGGL(k_accumulate, grid, block, 0, stream, a.settings, a.frame_count, a.camera, a.prev_camera,
+                       Img{a.indirect_temp, IW, IH}, img(a.normal_depth), img(a.indirect_history[src]), img(a.moments_history[src]), img(a.prev_normal_depth),
                        a.indirect_history[dst], a.moments_history[dst]);
     // Denoise (cpp:1437-1538)
     if (a.settings.denoise)
@@ -438,5 +467,14 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
                        img(a.combined_history[src]), a.combined_history[dst]);
     // CopyGBuffer of the next frame (cpp:955-1009)
     (void)hipMemcpyAsync(a.prev_normal_depth, a.normal_depth, bytes, hipMemcpyDeviceToDevice, stream);
+}
+
+void launch_decimate2x(hipStream_t stream, const float4* full, uint32_t width, uint32_t height, uint32_t ox, uint32_t oy, float4* out)
+{
+    const uint32_t n = (width >> 1) * (height >> 1);
+    uint32_t       g = (n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL(k_decimate2x, dim3(g), dim3(kBlock), 0, stream, full, width, height, ox, oy, out);
 }
 }  // namespace cap

@@ -14,7 +14,7 @@ int main(int argc, char** argv)
     RenderSessionParams params;  // 1920x1080 like main.cpp:53-54
     std::string         scene = "assets/cornell_box.obj", out = "frame.ppm";
     int                 frames = 64, bounces = 1;
-    bool                cornell_camera = true, realtime = false, feedback = true;
+    bool                cornell_camera = true, realtime = false, feedback = true, lowres = false;
     float               move[3] = {0.f, 0.f, 0.f};  // camera translation per frame (a scripted fly-through, input_system.cpp:49-148)
     for (int i = 1; i < argc; ++i)
     {
@@ -29,11 +29,12 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--default-camera")) cornell_camera = false;
         else if (!std::strcmp(argv[i], "--realtime")) realtime = true;  // the reference pipeline: 1 spp per frame + reconstruction chain
         else if (!std::strcmp(argv[i], "--no-feedback")) feedback = false;
+        else if (!std::strcmp(argv[i], "--lowres")) lowres = true;  // half-resolution interleaved indirect (lowres_indirect)
         else if (!std::strcmp(argv[i], "--move"))
             for (int k = 0; k < 3; ++k) move[k] = (float)std::atof(next());
         else
         {
-            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--default-camera] [--realtime [--no-feedback] [--move dx dy dz]]\n", argv[0]);
+            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--default-camera] [--realtime [--no-feedback] [--lowres] [--move dx dy dz]]\n", argv[0]);
             return 2;
         }
     }
@@ -45,6 +46,7 @@ int main(int argc, char** argv)
         capsaicin::GetSettings().num_diffuse_bounces = bounces;
         capsaicin::GetSettings().reconstruct         = realtime;
         capsaicin::GetSettings().gbuffer_feedback    = feedback;
+        capsaicin::GetSettings().lowres_indirect     = lowres;
         if (cornell_camera)
         {
             // the reference default (0,15,0)/+z is tuned for Sponza; SURVEY.md 8d fixes this view for the Cornell box

@@ -77,7 +77,12 @@ enum
     /* RaytracingOptions::gbuffer_feedback (raytracing_system.h:26, rt_indirect.hlsl:116-145): a path vertex of bounce >= 1
      * that the previous frame saw takes that frame's cap_post_frame output and ends the path.  One frame per call, unsharded
      * context, reference shading model; needs cap_prev_camera_set and cap_post_frame after every frame. */
-    CAP_RENDER_GBUFFER_FEEDBACK = 1u << 3
+    CAP_RENDER_GBUFFER_FEEDBACK = 1u << 3,
+    /* RaytracingOptions::lowres_indirect (raytracing_system.h:24; LOWRES_INDIRECT, rt_indirect.hlsl:53-59): only the pixel at
+     * sp_offset = ((frame % 4) / 2, (frame % 4) % 2) of every 2x2 block gets an indirect sample.  One frame per call, unsharded
+     * context, even width and height, reference shading model; the frame is not added to the accumulation buffer.  Read the
+     * (W/2, H/2) image with CAP_BUF_INDIRECT_LOWRES or hand it to cap_post_frame (settings.lowres_indirect = 1). */
+    CAP_RENDER_LOWRES_INDIRECT = 1u << 4
 };
 
 /* cap_readback kinds: the reference's RaytracingSystem outputs (raytracing_system.h, cpp:466-575). */
@@ -90,7 +95,8 @@ typedef enum CapBufferKind
     CAP_BUF_INDIRECT     = 4, /* rt_indirect.hlsl:176            output_indirect_                         */
     CAP_BUF_COMBINED     = 5, /* combine_illumination.hlsl:29    indirect*albedo + direct (xyz; w = 1)    */
     CAP_BUF_ACCUM_SUM    = 6, /* running fp32 sum of COMBINED over all frames since cap_accum_reset (w = frames) */
-    CAP_BUF_ACCUM_MEAN   = 7  /* ACCUM_SUM / frames                                                       */
+    CAP_BUF_ACCUM_MEAN   = 7, /* ACCUM_SUM / frames                                                       */
+    CAP_BUF_INDIRECT_LOWRES = 8 /* output_indirect_ of a CAP_RENDER_LOWRES_INDIRECT frame: (width/2)*(height/2)*4 floats */
 } CapBufferKind;
 
 /* Per-stage names follow the reference's timestamp labels (raytracing_system.cpp:1024, 1099, 1207). */
@@ -220,6 +226,8 @@ typedef struct CapPostSettings
     float   gather_luma_sigma;         /* 3     */
     float   temporal_upscale_feedback; /* 0.975 */
     float   taa_feedback;              /* 0.9   */
+    int32_t lowres_indirect;           /* false: RaytracingOptions::lowres_indirect, UPSCALE2X in Gather and Accumulate
+                                          (spatial_gather.hlsl:36-46, temporal_accumulation.hlsl:228-235, 307-313) */
 } CapPostSettings;
 /* Runs the chain on the planes of the last frame rendered with CAP_RENDER_AOV (frame_count = that frame's index; the
  * camera is the one set for it; prev_camera = the previous frame's, CameraComponent/prev_camera of

@@ -655,7 +655,7 @@ f3 sample_bilinear(const float* img, uint32_t w, uint32_t h, f2 uv)
 
 void shade_pixel(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, uint32_t x, uint32_t y, uint32_t w,
                  uint32_t h, uint32_t frame_count, uint32_t num_bounces, bool use_bvh, PixelOut* o, uint64_t rays[3],
-                 const Feedback* fb = nullptr)
+                 const Feedback* fb = nullptr, bool lowres = false)
 {
     f3 org, dir;
     create_primary_ray(cam, x, y, w, h, frame_count, &org, &dir);
@@ -703,6 +703,17 @@ void shade_pixel(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, ui
     }
 
     // ---- rt_indirect.hlsl:82-176 ----
+    if (lowres)
+    {
+        // LOWRES_INDIRECT (:53-59): the pass runs on the half-resolution grid; of every 2x2 full-resolution block only the pixel
+        // at sp_offset = ((frame % 4) / 2, (frame % 4) % 2) gets an indirect sample this frame
+        const uint32_t ox = (frame_count % 4) / 2, oy = (frame_count % 4) % 2;
+        if ((x & 1u) != ox || (y & 1u) != oy)
+        {
+            set4(o->indirect, 0, 0, 0, 0);
+            return;
+        }
+    }
     f3 color = make3(0, 0, 0), thr = make3(1, 1, 1);
     for (uint32_t bounce = 0; bounce <= num_bounces; ++bounce)
     {
@@ -933,7 +944,7 @@ void shade_pixel_ext(const Scene& sc, const OracleCamera& cam, const uint8_t* bn
 
 void render_rows(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, uint32_t w, uint32_t h, uint32_t frame,
                  uint32_t bounces, bool use_bvh, bool ext, uint32_t row0, uint32_t row_step, OracleFrameOutputs* out, uint64_t rays[3],
-                 const Feedback* fb)
+                 const Feedback* fb, bool lowres)
 {
     for (uint32_t y = row0; y < h; y += row_step)
         for (uint32_t x = 0; x < w; ++x)
@@ -942,13 +953,15 @@ void render_rows(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, ui
             if (ext)
                 shade_pixel_ext(sc, cam, bn, x, y, w, h, frame, bounces, use_bvh, &po, rays);
             else
-                shade_pixel(sc, cam, bn, x, y, w, h, frame, bounces, use_bvh, &po, rays, fb);
+                shade_pixel(sc, cam, bn, x, y, w, h, frame, bounces, use_bvh, &po, rays, fb, lowres);
             size_t i = 4 * ((size_t)y * w + x);
             if (out->gbuffer_geo) memcpy(out->gbuffer_geo + i, po.geo, 16);
             if (out->direct) memcpy(out->direct + i, po.direct, 16);
             if (out->albedo) memcpy(out->albedo + i, po.albedo, 16);
             if (out->normal_depth) memcpy(out->normal_depth + i, po.nd, 16);
             if (out->indirect) memcpy(out->indirect + i, po.indirect, 16);
+            if (lowres && out->indirect_lowres && (x & 1u) == (frame % 4) / 2 && (y & 1u) == (frame % 4) % 2)
+                memcpy(out->indirect_lowres + 4 * ((size_t)(y >> 1) * (w >> 1) + (x >> 1)), po.indirect, 16);  // g_output_indirect[xy]
             if (out->combined)
                 for (int c = 0; c < 4; ++c)  // combine_illumination.hlsl:24,29 (indirect.w forced to 1)
                     out->combined[i + c] = (c == 3 ? 1.0f : po.indirect[c]) * po.albedo[c] + po.direct[c];
@@ -1015,13 +1028,15 @@ static int render_frame_impl(void* scene, const OracleCamera* cam, const uint8_t
     bool     ext = (flags & ORACLE_FLAG_EXT_MATERIALS) != 0;
     if (ext && sc.materials.size() != sc.meshes.size()) return 2;  // EXT needs one material per mesh
     if (ext && fb) return 3;                                        // the feedback branch belongs to the reference model
+    const bool lowres = (flags & ORACLE_FLAG_LOWRES_INDIRECT) != 0;
+    if (lowres && (ext || (w & 1u) || (h & 1u))) return 4;          // half-resolution indirect: reference model, even extents
     uint32_t nt  = std::max(1u, std::min(num_threads, h));
     std::vector<uint64_t> rays(3 * (size_t)nt, 0);
     std::vector<std::thread> th;
     for (uint32_t t = 1; t < nt; ++t)
         th.emplace_back(render_rows, std::cref(sc), std::cref(*cam), bn, w, h, frame_count, num_bounces, bvh, ext, t, nt, out,
-                        rays.data() + 3 * t, fb);
-    render_rows(sc, *cam, bn, w, h, frame_count, num_bounces, bvh, ext, 0, nt, out, rays.data(), fb);
+                        rays.data() + 3 * t, fb, lowres);
+    render_rows(sc, *cam, bn, w, h, frame_count, num_bounces, bvh, ext, 0, nt, out, rays.data(), fb, lowres);
     for (auto& t : th) t.join();
     out->rays[0] = out->rays[1] = out->rays[2] = 0;
     for (uint32_t t = 0; t < nt; ++t)

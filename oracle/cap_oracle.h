@@ -90,6 +90,9 @@ enum
 {
     ORACLE_FLAG_USE_BVH       = 1u << 0, /* CPU BVH instead of brute force (same hits by construction) */
     ORACLE_FLAG_EXT_MATERIALS = 1u << 1, /* EXT: per-mesh kd / GGX / emission + next-event estimation */
+    /* RaytracingOptions::lowres_indirect (raytracing_system.h:24; LOWRES_INDIRECT, rt_indirect.hlsl:53-59): the indirect pass
+     * runs on the (W/2, H/2) grid, 2x2-interleaved over four frames; needs even W and H; fills indirect_lowres */
+    ORACLE_FLAG_LOWRES_INDIRECT = 1u << 2,
 };
 
 typedef struct OracleFrameOutputs
@@ -102,6 +105,7 @@ typedef struct OracleFrameOutputs
     float* indirect;      /* rt_indirect.hlsl:176 */
     float* combined;      /* indirect*albedo + direct, combine_illumination.hlsl:29 */
     uint64_t rays[3];     /* primary, extension, shadow rays actually traced */
+    float* indirect_lowres; /* ORACLE_FLAG_LOWRES_INDIRECT: (W/2)*(H/2)*4 floats, g_output_indirect of the half-res pass; or NULL */
 } OracleFrameOutputs;
 
 void* oracle_scene_create(const OracleScene* scene);
@@ -141,6 +145,8 @@ typedef struct OraclePostSettings
     float gather_luma_sigma;         /* 3     */
     float temporal_upscale_feedback; /* 0.975 */
     float taa_feedback;              /* 0.9   */
+    int   lowres_indirect;           /* false: RaytracingOptions::lowres_indirect (UPSCALE2X in Gather and Accumulate); the
+                                        `indirect` argument of oracle_post_frame is then the (W/2)*(H/2) image */
 } OraclePostSettings;
 
 void* oracle_post_create(uint32_t width, uint32_t height);

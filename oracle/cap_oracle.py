@@ -26,7 +26,7 @@ class SceneDesc(C.Structure):
 
 class FrameOutputs(C.Structure):
     _fields_ = [("gbuffer_geo", C.c_void_p), ("direct", C.c_void_p), ("albedo", C.c_void_p), ("normal_depth", C.c_void_p),
-                ("indirect", C.c_void_p), ("combined", C.c_void_p), ("rays", C.c_uint64 * 3)]
+                ("indirect", C.c_void_p), ("combined", C.c_void_p), ("rays", C.c_uint64 * 3), ("indirect_lowres", C.c_void_p)]
 
 
 class PostSettings(C.Structure):
@@ -34,16 +34,17 @@ class PostSettings(C.Structure):
     _fields_ = [("gather", C.c_int), ("denoise", C.c_int), ("eaw5", C.c_int), ("eaw_normal_sigma", C.c_float),
                 ("eaw_depth_sigma", C.c_float), ("eaw_luma_sigma", C.c_float), ("gather_normal_sigma", C.c_float),
                 ("gather_depth_sigma", C.c_float), ("gather_luma_sigma", C.c_float), ("temporal_upscale_feedback", C.c_float),
-                ("taa_feedback", C.c_float)]
+                ("taa_feedback", C.c_float), ("lowres_indirect", C.c_int)]
 
     def __init__(self, **kw):
-        super().__init__(1, 1, 1, 128.0, 3.0, 3.0, 64.0, 2.0, 3.0, 0.975, 0.9)
+        super().__init__(1, 1, 1, 128.0, 3.0, 3.0, 64.0, 2.0, 3.0, 0.975, 0.9, 0)
         for k, v in kw.items():
             setattr(self, k, v)
 
 
 FLAG_USE_BVH = 1
 FLAG_EXT_MATERIALS = 2
+FLAG_LOWRES_INDIRECT = 4
 
 
 def build(force=False):
@@ -140,6 +141,9 @@ class Scene:
         out = FrameOutputs()
         for n in names:
             setattr(out, n, _p(bufs[n]))
+        if flags & FLAG_LOWRES_INDIRECT:
+            bufs["indirect_lowres"] = np.zeros((height // 2, width // 2, 4), np.float32)
+            out.indirect_lowres = _p(bufs["indirect_lowres"])
         bn = np.ascontiguousarray(bluenoise, np.uint8)
         if feedback is not None:
             prev_cam, pnd, hist = feedback
@@ -178,7 +182,8 @@ class PostChain:
             self.handle = None
 
     def frame(self, settings, frame_count, cam, prev_cam, planes):
-        a = [np.ascontiguousarray(planes[k], np.float32) for k in ("indirect", "direct", "albedo", "normal_depth")]
+        a = [np.ascontiguousarray(planes[k], np.float32)
+             for k in ("indirect_lowres" if settings.lowres_indirect else "indirect", "direct", "albedo", "normal_depth")]
         out = np.zeros((self.h, self.w, 4), np.float32)
         rc = lib().oracle_post_frame(self.handle, C.byref(settings), frame_count, C.byref(cam), C.byref(prev_cam), _p(a[0]), _p(a[1]),
                                      _p(a[2]), _p(a[3]), _p(out))

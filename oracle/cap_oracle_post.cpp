@@ -271,6 +271,48 @@ void gather(const OraclePostSettings& s, const Image& color, const Image& nd, Im
         }
 }
 
+// spatial_gather.hlsl:28-109 with UPSCALE2X (:36-46, :83-87): the grid and `color` are half resolution, the G-buffer is read at
+// (xy << 1) + sp_offset.  The host passes the FULL window size as g_constants.width/height in this mode too
+// (raytracing_system.cpp:1562-1569), so the taps' bound test is against the full size; a tap beyond the half-resolution image
+// reads colour 0 and a G-buffer texel outside the window, i.e. depth 0, and is skipped as background.
+void gather_lowres(const OraclePostSettings& s, uint32_t frame_count, uint32_t full_w, uint32_t full_h, const Image& color, const Image& nd,
+                   Image& out)
+{
+    const int ox = (int)((frame_count % 4) / 2), oy = (int)((frame_count % 4) % 2);
+    for (uint32_t y = 0; y < out.h; ++y)
+        for (uint32_t x = 0; x < out.w; ++x)
+        {
+            f4    cg = nd.loadi(((int)x << 1) + ox, ((int)y << 1) + oy);
+            f3    cn = oct_decode(cg.x, cg.y);
+            float cd = cg.w;
+            f3    cc = xyz(color.load(x, y));
+            if (cd < 1e-5f)
+            {
+                out.store(x, y, f4{cc.x, cc.y, cc.z, 0.0f});
+                continue;
+            }
+            const float s_depth = cd * s.gather_depth_sigma, s_normal = s.gather_normal_sigma, s_luma = s.gather_luma_sigma;
+            f3    filtered = mk(0, 0, 0);
+            float total    = 0.0f;
+            for (int dy = -3; dy <= 3; ++dy)
+                for (int dx = -3; dx <= 3; ++dx)
+                {
+                    int sx = (int)x + dx, sy = (int)y + dy;
+                    if (sx < 0 || sy < 0 || sx >= (int)full_w || sy >= (int)full_h) continue;
+                    f3 c = xyz(color.loadi(sx, sy));
+                    f4 g = nd.loadi((sx << 1) + ox, (sy << 1) + oy);
+                    if (g.w < 1e-5f) continue;
+                    f3    n = oct_decode(g.x, g.y);
+                    float len = sqrtf((float)(dx * dx + dy * dy));
+                    float wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * len) * luma_weight(luminance(cc), luminance(c), s_luma);
+                    filtered = filtered + c * wgt;
+                    total += wgt;
+                }
+            f3 r = (total < kEps) ? cc : filtered / total;
+            out.store(x, y, f4{r.x, r.y, r.z, 1.0f});
+        }
+}
+
 float closest_depth(const Image& g, f2 xy)  // temporal_accumulation.hlsl:179-205
 {
     float closest = g.loadi((int)xy.x, (int)xy.y).w;
@@ -285,7 +327,8 @@ float closest_depth(const Image& g, f2 xy)  // temporal_accumulation.hlsl:179-20
     return closest;
 }
 
-// temporal_accumulation.hlsl:213-325
+// temporal_accumulation.hlsl:213-325.  With UPSCALE2X (s.lowres_indirect) `color` is the half-resolution image: SampleColor uses its
+// size (input_buffer_size, :228-235), and pixels that got no new sample this frame keep their history untouched (:307-313).
 void accumulate(const OraclePostSettings& s, uint32_t frame_count, const OracleCamera& cam, const OracleCamera& prev_cam,
                 const Image& color, const Image& nd, const Image& color_history, const Image& moments_history, const Image& prev_nd,
                 Image& out_color, Image& out_moments)
@@ -331,6 +374,11 @@ void accumulate(const OraclePostSettings& s, uint32_t frame_count, const OracleC
             {
                 float t = 1.0f / (float)(hist_len + 1);
                 alpha   = fminf(alpha, 1.0f - t);
+            }
+            if (s.lowres_indirect && ((x % 2u) != (frame_count % 4) / 2 || (y % 2u) != (frame_count % 4) % 2))
+            {
+                alpha = 1.0f;
+                hist_len -= 1;  // uint: a length of 0 wraps and the + 1 below brings it back to 0
             }
             f3    mh = resample_bicubic(moments_history, puv);
             float l  = luminance(c);
@@ -529,12 +577,21 @@ int oracle_post_frame(void* handle, const OraclePostSettings* s, uint32_t frame_
     if (!handle || !s || !cam || !prev_cam || !indirect || !direct || !albedo || !normal_depth || !out) return 1;
     Chain&         c = *(Chain*)handle;
     const uint32_t W = c.w, H = c.h;
+    const bool lowres = s->lowres_indirect != 0;
+    if (lowres && ((W & 1u) || (H & 1u))) return 2;
     Image raw, dir, alb, nd;
-    raw.init(W, H), dir.init(W, H), alb.init(W, H), nd.init(W, H);
+    if (lowres)
+        raw.init(W >> 1, H >> 1);  // output_indirect_ and indirect_temp_ are half resolution (raytracing_system.cpp:499-512)
+    else
+        raw.init(W, H);
+    dir.init(W, H), alb.init(W, H), nd.init(W, H);
     from_floats(raw, indirect), from_floats(dir, direct), from_floats(alb, albedo), from_floats(nd, normal_depth);
+    if (c.indirect_temp.w != raw.w || c.indirect_temp.h != raw.h) c.indirect_temp.init(raw.w, raw.h);
     const uint32_t src = (frame_count + 1) % 2, dst = frame_count % 2;  // raytracing_system.cpp:1709-1710, 1754-1755
     // SpatialGather (cpp:1541-1604)
-    if (s->gather)
+    if (s->gather && lowres)
+        gather_lowres(*s, frame_count, W, H, raw, nd, c.indirect_temp);
+    else if (s->gather)
         gather(*s, raw, nd, c.indirect_temp);
     else
         c.indirect_temp = raw;

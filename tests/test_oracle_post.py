@@ -95,6 +95,55 @@ def test_history_length_and_reset_on_camera_cut():
     assert np.array_equal(cut[:-1, :-1, :3], want[:-1, :-1])
 
 
+def test_lowres_indirect_is_the_interleaved_quarter(bluenoise, cornell_path, native_lib):
+    """LOWRES_INDIRECT (rt_indirect.hlsl:53-59): the half-resolution indirect image of frame f holds exactly the full-resolution
+    pass's pixels at sp_offset = ((f % 4) / 2, (f % 4) % 2); a quarter of the extension rays are traced; direct lighting and
+    the G-buffer stay full resolution.  Four consecutive frames cover every pixel once."""
+    from capsaicin_amd import capi
+    geo = capi.Geometry(cornell_path)
+    sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes)
+    w, h, D = 64, 48, 2
+    cam = capi.cornell_camera(w, h)
+    oc = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1],
+                       cam.focal_length)
+    seen = np.zeros((h, w), bool)
+    for f in range(4):
+        low = sc.render_frame(oc, bluenoise, w, h, f, D, flags=O.FLAG_LOWRES_INDIRECT, threads=4)
+        full = sc.render_frame(oc, bluenoise, w, h, f, D, threads=4)
+        ox, oy = (f % 4) // 2, (f % 4) % 2
+        assert np.array_equal(low["indirect_lowres"], full["indirect"][oy::2, ox::2])
+        for k in ("direct", "albedo", "normal_depth", "gbuffer_geo"):
+            assert np.array_equal(low[k].view(np.uint32), full[k].view(np.uint32))  # gbuffer_geo carries ids as float bits
+        assert low["rays"][0] == full["rays"][0] and low["rays"][1] < 0.3 * full["rays"][1]
+        seen[oy::2, ox::2] = True
+    assert seen.all()
+    with pytest.raises(RuntimeError):  # odd extents have no 2x2 blocks
+        sc.render_frame(oc, bluenoise, w + 1, h, 0, D, flags=O.FLAG_LOWRES_INDIRECT)
+
+
+def test_lowres_chain_keeps_unsampled_history():
+    """UPSCALE2X Accumulate (temporal_accumulation.hlsl:307-313): a pixel without a new sample this frame keeps its colour
+    history (alpha = 1) and its history length; the sampled pixel of each 2x2 block blends as usual."""
+    w, h = 32, 24
+    cam = camera(w, h)
+    s = O.PostSettings(lowres_indirect=1, gather=0, denoise=0)
+    chain = O.PostChain(w, h)
+    rng = np.random.default_rng(5)
+    outs = []
+    for f in range(6):
+        planes = wall_planes(w, h, cam)
+        planes["indirect_lowres"] = rng.uniform(0.2, 0.8, (h // 2, w // 2, 4)).astype(np.float32)
+        outs.append(chain.frame(s, f, cam, cam, planes))
+        assert np.all(np.isfinite(outs[-1]))
+    # constant lowres input is a fixed point of the upscaling chain as well
+    chain = O.PostChain(w, h)
+    for f in range(5):
+        planes = wall_planes(w, h, cam)
+        planes["indirect_lowres"] = np.full((h // 2, w // 2, 4), 0.37, np.float32)
+        out = chain.frame(O.PostSettings(lowres_indirect=1), f, cam, cam, planes)
+    assert np.abs(out[..., :3] - 0.37).max() < 1.5e-3
+
+
 def test_deterministic():
     w, h = 32, 32
     cam = camera(w, h)

@@ -113,6 +113,57 @@ def test_gbuffer_feedback_parity(native_lib, bluenoise, cornell_path, traversal)
     r.close()
 
 
+@pytest.mark.parametrize("feedback", [False, True])
+def test_lowres_indirect_parity(native_lib, bluenoise, cornell_path, feedback):
+    """RaytracingOptions::lowres_indirect (SURVEY.md 8f-4): the indirect pass on the half-resolution grid, 2x2-interleaved over
+    four frames (rt_indirect.hlsl:53-59), Gather and Accumulate in their UPSCALE2X form.  Ray passes, the half-resolution image
+    and the chain output against the oracle, bit for bit, over two interleave cycles with camera motion."""
+    from oracle import cap_oracle as O
+    w, h, D = 136, 90, 2
+    geo = capi.Geometry(cornell_path)
+    r = capi.Renderer(0)
+    r.upload_geometry(geo)
+    r.upload_bluenoise(bluenoise)
+    r.build_bvh()
+    r.set_resolution(w, h)
+    sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes)
+    chain = O.PostChain(w, h)
+    base = capi.cornell_camera(w, h)
+    cams = [base] * 5 + [moved(base, 0.02 * k, 0.01 * k, -0.03 * k) for k in range(1, 5)]
+    gs, os_ = capi.PostSettings(lowres_indirect=1), O.PostSettings(lowres_indirect=1)
+    prev, prev_nd, hist = cams[0], np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    flags = capi.RENDER_AOV | capi.RENDER_LOWRES_INDIRECT | (capi.RENDER_GBUFFER_FEEDBACK if feedback else 0)
+    for f, cam in enumerate(cams):
+        r.set_camera(cam)
+        r.set_prev_camera(prev)
+        r.stats_reset()
+        r.render(f, 1, D, flags)
+        ref = sc.render_frame(ocam_of(O, cam), bluenoise, w, h, f, D, flags=O.FLAG_LOWRES_INDIRECT, threads=8,
+                              feedback=(ocam_of(O, prev), prev_nd, hist) if feedback else None)
+        for name, kind in (("direct", capi.BUF_DIRECT), ("albedo", capi.BUF_ALBEDO), ("normal_depth", capi.BUF_NORMAL_DEPTH),
+                           ("indirect_lowres", capi.BUF_INDIRECT_LOWRES)):
+            got = r.readback(kind)
+            assert got.shape == ref[name].shape
+            nbad = int((bits(got) != bits(ref[name])).any(-1).sum())
+            assert nbad == 0, "frame %d %s: %d pixels differ" % (f, name, nbad)
+        s = r.stats()
+        assert (s.rays_primary, s.rays_extension, s.rays_shadow) == ref["rays"]
+        assert s.rays_extension < 0.5 * w * h  # a quarter of the pixels start an indirect path
+        r.post_frame(gs, f, prev)
+        got = r.post_readback()
+        want = chain.frame(os_, f, ocam_of(O, cam), ocam_of(O, prev), ref)
+        nbad = int((bits(got) != bits(want)).any(-1).sum())
+        assert nbad == 0, "frame %d chain output: %d pixels differ, max abs %g" % (f, nbad, float(np.abs(got - want).max()))
+        prev, prev_nd, hist = cam, ref["normal_depth"], want
+    # misuse
+    with pytest.raises(capi.CapError, match="lowres_indirect"):
+        r.post_frame(capi.PostSettings(), len(cams) - 1, prev)
+    r.set_resolution(w + 1, h)
+    with pytest.raises(capi.CapError, match="even"):
+        r.render(0, 1, D, capi.RENDER_LOWRES_INDIRECT)
+    r.close()
+
+
 def test_post_chain_reset_and_errors(native_lib, bluenoise, cornell_path):
     w, h = 64, 48
     r = capi.Renderer(0)
