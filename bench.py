@@ -11,6 +11,7 @@ Prints one JSON line (rank 0) with the bench contract fields plus `roofline` (do
 extension rays, timed with HIP events on the render stream) and `cpu_baseline` (the scalar CPU oracle on the host cores).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -205,8 +206,19 @@ def main():
                 all_bytes = BYTES_CLOSEST * sp.rays_extension + 16 * sp.rays_primary + BYTES_ANY * sp.rays_shadow + BYTES_VERTEX * sp.shaded_vertices
             bytes_per_launch = kernel_bytes / sp.launches_trace_closest
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            # HBM bytes per launch of this kernel from the committed PMC passes of the same workload (profiles/*_traffic.json;
+            # counters cannot be collected from inside the timed process), over the launch duration measured live above
+            traffic, traffic_src = None, None
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if tfiles and args.spp == SPP and args.scene == "cornell" and world == 1:
+                try:
+                    tj = json.load(open(tfiles[-1]))
+                    traffic = tj["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+                    traffic_src = os.path.relpath(tfiles[-1], ROOT)
+                except Exception:  # a malformed file must not break the bench line
+                    traffic = None
             roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_ms": avg_ms, "launches": int(sp.launches_trace_closest),
                         "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_ray": kernel_bytes / max(1, sp.rays_extension),
                         "rays_per_launch": sp.rays_extension / sp.launches_trace_closest,

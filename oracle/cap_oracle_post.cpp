@@ -5,8 +5,9 @@
  * combine_illumination.hlsl with eaw_edge_stopping.h, aabb.h, color_space.h, math_functions.h, utils.h, camera.h;
  * pass order and buffers: src/systems/raytracing_system.cpp:262-317, 1283-1604, 1700-1790).
  *
- * Full-resolution configuration of the reference's defaults (raytracing_system.h:22-27): LOWRES_INDIRECT / UPSCALE2X off,
- * CALCULATE_VARIANCE and USE_VARIANCE on.  PARITY UNPINNED against the real renderer (no tests, no golden images; the
+ * The reference's default configuration (raytracing_system.h:22-27: LOWRES_INDIRECT / UPSCALE2X off, CALCULATE_VARIANCE and
+ * USE_VARIANCE on) and, with OraclePostSettings::lowres_indirect, the half-resolution one (UPSCALE2X Gather and Accumulate,
+ * spatial_gather.hlsl:36-46, temporal_accumulation.hlsl:228-235, 307-313).  PARITY UNPINNED against the real renderer (no tests, no golden images; the
  * reference stores these buffers as RGBA16F, this build keeps fp32).  Stated choices where HLSL/D3D leave room:
  *   - uint(x) of a negative float saturates to 0; int(x) truncates; an out-of-bounds texture read returns 0;
  *   - rcp(x) = 1/x, lerp(a,b,t) = a + t*(b - a), exp/pow through the exp2/log2 polynomials of the arithmetic contract;
