@@ -780,7 +780,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     }
 
     const uint32_t Ppad = c->screen.pixels_padded;
-    uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)8 << 20;
+    uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)32 << 20;  // measured on the headline workload: 8 Mi 39.6 ms, 16 Mi 35.1, 32 Mi 34.7, 64 Mi 35.8 per step
     uint32_t       slots  = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / std::max(1u, Ppad), kMaxFrameSlots));
     slots                 = std::min(slots, n_frames);
     // drain the previous call (its per-frame constants and counters are reused below), then stage this call's constants
