@@ -35,6 +35,11 @@ struct BvhDev
     const float4* nodes;
     const float4* tris;        // 64-B intersection records in leaf order (.w of the 4th float4 = global triangle id)
     const float4* tris_by_id;  // the same records in global triangle id order (exhaustive small-scene kernels)
+    // exhaustive loop order: fan pairs (triangles id, id + 1 sharing v0 and the edge v0->v2), 20 floats each
+    //   (v0, e1, e2, e3, nA, nB, asfloat(id), 0), ascending id; then the unpaired triangles as 64-B records, ascending id
+    const float4* fan_pairs;
+    const float4* fan_singles;
+    uint32_t      fan_pair_count, fan_single_count;
     int32_t       root;       // 0, or ~0 for a single triangle
     uint32_t      tri_count;  // 0 -> every ray misses
 };

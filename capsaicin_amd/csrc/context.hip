@@ -130,6 +130,8 @@ struct CapContext
 
     // BVH
     DevBuf<float4>   shade_tris, tris_sorted, nodes, tri_raw, tri_box;
+    DevBuf<float4>   fan_pairs, fan_singles;  // exhaustive path: fan-pair records (5 float4) and the unpaired triangles (4 float4)
+    uint32_t         fan_pair_count = 0, fan_single_count = 0;
     DevBuf<uint32_t> leaf_tri, keys0, keys1, vals0, vals1, hist, parent, flags, bvh_misc;  // bvh_misc: 6 bounds + depth
     CapBvhInfo       bvh_info{};
     bool             bvh_ready = false;
@@ -315,6 +317,8 @@ BvhDev bvh_dev(const CapContext* c)
     b.nodes     = c->nodes.p;
     b.tris      = c->tris_sorted.p;
     b.tris_by_id = c->tri_raw.p;
+    b.fan_pairs = c->fan_pairs.p, b.fan_singles = c->fan_singles.p;
+    b.fan_pair_count = c->fan_pair_count, b.fan_single_count = c->fan_single_count;
     b.tri_count = c->tri_count;
     b.root      = c->tri_count >= 2 ? 0 : ~0;
     return b;
@@ -649,6 +653,44 @@ int cap_bvh_build(CapContext* c)
     if (bi.max_depth > 64)
         return fail(CAP_ERR_UNSUPPORTED, "LBVH depth %u exceeds the 64-entry traversal stack", bi.max_depth);
     bi.stack_entries = bi.max_depth <= 32 ? 32 : 64;
+    // Exhaustive path (cap_set_traversal): triangles that come in fans (k, k + 1 share v0 and the edge v0->v2, as every
+    // triangulated quad of an OBJ face does) are stored as one record, so the kernels compute tvec, q and the shared edge's dot
+    // product once for both.  Same per-triangle arithmetic, same results; the pairing only depends on bit-equal vertices.
+    c->fan_pair_count = c->fan_single_count = 0;
+    if (n && n <= 4096)
+    {
+        std::vector<float> raw(16 * (size_t)n);
+        HIP_TRY(hipMemcpy(raw.data(), c->tri_raw.p, sizeof(float) * raw.size(), hipMemcpyDeviceToHost));
+        std::vector<float> pairs, singles;
+        auto rec = [&](uint32_t k) { return raw.data() + 16 * (size_t)k; };  // v0(3) e1(3) e2(3) n(3) id(1) pad(3)
+        for (uint32_t k = 0; k < n;)
+        {
+            const float* a = rec(k);
+            const float* b = k + 1 < n ? rec(k + 1) : nullptr;
+            const bool   fan = b && memcmp(a, b, 12) == 0 && memcmp(a + 6, b + 3, 12) == 0;  // same v0, e2(k) == e1(k+1)
+            if (fan)
+            {
+                // (v0, e1, e2, e3 = e2 of k+1, nA, nB, id of k, 0)
+                const float r[20] = {a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], b[6], b[7], b[8], a[9], a[10], a[11],
+                                     b[9], b[10], b[11], a[12], 0.0f};
+                pairs.insert(pairs.end(), r, r + 20);
+                k += 2;
+            }
+            else
+            {
+                singles.insert(singles.end(), a, a + 16);
+                k += 1;
+            }
+        }
+        c->fan_pair_count   = (uint32_t)(pairs.size() / 20);
+        c->fan_single_count = (uint32_t)(singles.size() / 16);
+        // padded by four records so that an unrolled scalar load past the end stays inside the allocation
+        pairs.resize(pairs.size() + 80, 0.0f), singles.resize(singles.size() + 64, 0.0f);
+        HIP_TRY(c->fan_pairs.ensure(pairs.size() / 4));
+        HIP_TRY(c->fan_singles.ensure(singles.size() / 4));
+        HIP_TRY(hipMemcpy(c->fan_pairs.p, pairs.data(), sizeof(float) * pairs.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->fan_singles.p, singles.data(), sizeof(float) * singles.size(), hipMemcpyHostToDevice));
+    }
     c->bvh_ready     = true;
     return CAP_OK;
 }

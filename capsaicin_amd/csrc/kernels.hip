@@ -221,49 +221,118 @@ __device__ __forceinline__ TriScaled tri_scaled(const Ray& r, const float4 t0, c
     return o;
 }
 
-// Exhaustive closest hit over the records in global id order.  Same rule as tri_test() + "minimum t, ties to the lower id":
-// visiting in id order makes "first strictly smaller t" that rule (an equal t never replaces an earlier triangle), and with
-// best_t starting at tmax, t < best_t implies t < tmax.  Only t and the id are tracked in the loop; the barycentrics of the
-// winner are recomputed once after it (identical operations, identical bits) instead of being multiplied out and selected for
-// every triangle.
+// Fan pair: triangles id and id + 1 share v0 and the edge e2(id) == e1(id + 1) (every triangulated quad), so tvec, q and that
+// edge's dot product with q are computed once.  20 floats: (v0, e1, e2, e3, nA, nB, asfloat(id), 0), read through the scalar
+// cache like the single records.  The per-triangle arithmetic is exactly tri_scaled()'s.
+struct alignas(16) RawPair
+{
+    float f[20];
+};
+struct PairScaled
+{
+    TriScaled a, b;
+    uint32_t  id;
+};
+__device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* base, uint32_t k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const RawPair ConstPair;
+    const RawPair p = ((const ConstPair*)base)[k];
+#else
+    RawPair p;
+    for (int i = 0; i < 20; ++i) p.f[i] = reinterpret_cast<const float*>(base)[20 * k + i];
+#endif
+    const v3 v0 = mk3(p.f[0], p.f[1], p.f[2]), e1 = mk3(p.f[3], p.f[4], p.f[5]), e2 = mk3(p.f[6], p.f[7], p.f[8]),
+             e3 = mk3(p.f[9], p.f[10], p.f[11]), na = mk3(p.f[12], p.f[13], p.f[14]), nb = mk3(p.f[15], p.f[16], p.f[17]);
+    const v3 tvec = r.o - v0;
+    const v3 q    = cross3(tvec, r.d);
+    const float e2q = dot3(e2, q);  // U of the first triangle, V (before its negation) of the second
+    PairScaled  o;
+    {
+        const float    ddn = dot3(r.d, na);
+        const uint32_t s   = f2u(ddn) & 0x80000000u;
+        o.a.det = fabsf(ddn);
+        o.a.U   = u2f(f2u(e2q) ^ (s ^ 0x80000000u));
+        o.a.V   = u2f(f2u(dot3(e1, q)) ^ s);
+        o.a.T   = u2f(f2u(dot3(tvec, na)) ^ (s ^ 0x80000000u));
+    }
+    {
+        const float    ddn = dot3(r.d, nb);
+        const uint32_t s   = f2u(ddn) & 0x80000000u;
+        o.b.det = fabsf(ddn);
+        o.b.U   = u2f(f2u(dot3(e3, q)) ^ (s ^ 0x80000000u));
+        o.b.V   = u2f(f2u(e2q) ^ s);
+        o.b.T   = u2f(f2u(dot3(tvec, nb)) ^ (s ^ 0x80000000u));
+    }
+    o.id = f2u(p.f[18]);
+    return o;
+}
+
+// Exhaustive closest hit.  Same rule as tri_test() + "minimum t, ties to the lower id": both record lists are in ascending id
+// order, so within a list "first strictly smaller t" is that rule (an equal t never replaces an earlier triangle); the two
+// lists' winners are merged by the explicit (t, id) order.  With best_t starting at tmax, t < best_t implies t < tmax.  Only t
+// and the id are tracked in the loops; the barycentrics of the winner are recomputed once afterwards (identical operations,
+// identical bits) instead of being multiplied out and selected for every triangle.
+// One candidate per triangle: its t, or +inf when the ray misses it.  A wave issues dependent VALU instructions at half the
+// rate of independent ones on this machine (tools/micro/valu_peak.hip: 4.7 vs 2.6 cycles per wave64 fma per SIMD, whatever the
+// number of resident waves), so four triangles are tested side by side and reduced by a tree; "(t, id) lexicographic minimum"
+// is associative, so the tree gives the winner of the sequential rule.
 // rec_tab: where the winner's record is re-read from (bvh.tris_by_id, or its LDS copy).
 __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const float4* rec_tab, const Ray& r, float& best_t, float& best_u,
                                                    float& best_v, uint32_t& best_gid)
 {
     best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
-    const uint32_t n = bvh.tri_count;
-    // One candidate per triangle: its t, or +inf when the ray misses it.  A wave issues dependent VALU instructions at half the
-    // rate of independent ones on this machine (tools/micro/valu_peak.hip: 4.7 vs 2.6 cycles per wave64 fma per SIMD, whatever
-    // the number of resident waves), so four triangles are tested side by side and reduced by a tree; "(t, id) lexicographic
-    // minimum" is associative, so the tree gives the winner of the sequential rule.
-    auto candidate = [&](uint32_t k) {
-        float4 t0, t1, t2, t3;
-        load_const_tri(bvh.tris_by_id, k, t0, t1, t2, t3);
-        const TriScaled s      = tri_scaled(r, t0, t1, t2);
-        const bool      inside = (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det);
-        const float     tt     = s.T * rcp_c(s.det);
+    auto cand = [&](const TriScaled& s) {
+        const bool  inside = (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det);
+        const float tt     = s.T * rcp_c(s.det);
         return (inside & (tt > r.tmin)) ? tt : __builtin_inff();
     };
-    uint32_t k = 0;
-    for (; k + 4 <= n; k += 4)
+    // ---- fan pairs, two at a time ----
+    const uint32_t np = bvh.fan_pair_count;
+    uint32_t       k  = 0;
+    for (; k + 2 <= np; k += 2)
     {
-        const float c0 = candidate(k), c1 = candidate(k + 1), c2 = candidate(k + 2), c3 = candidate(k + 3);
-        const bool  p01 = c1 < c0, p23 = c3 < c2;  // strict: the earlier triangle keeps an equal t
-        const float m01 = p01 ? c1 : c0, m23 = p23 ? c3 : c2;
-        const uint32_t i01 = p01 ? k + 1 : k, i23 = p23 ? k + 3 : k + 2;
-        const bool     p   = m23 < m01;
-        const float    m   = p ? m23 : m01;
-        const uint32_t im  = p ? i23 : i01;
-        const bool     better = m < best_t;
+        const PairScaled p0 = pair_scaled(r, bvh.fan_pairs, k), p1 = pair_scaled(r, bvh.fan_pairs, k + 1);
+        const float      c0 = cand(p0.a), c1 = cand(p0.b), c2 = cand(p1.a), c3 = cand(p1.b);
+        const bool       p01 = c1 < c0, p23 = c3 < c2;  // strict: the earlier triangle keeps an equal t
+        const float      m01 = p01 ? c1 : c0, m23 = p23 ? c3 : c2;
+        const uint32_t   i01 = p01 ? p0.id + 1u : p0.id, i23 = p23 ? p1.id + 1u : p1.id;
+        const bool       p   = m23 < m01;
+        const float      m   = p ? m23 : m01;
+        const uint32_t   im  = p ? i23 : i01;
+        const bool       better = m < best_t;
         best_t   = better ? m : best_t;
         best_gid = better ? im : best_gid;
     }
-    for (; k < n; ++k)
+    if (k < np)
     {
-        const float c      = candidate(k);
-        const bool  better = c < best_t;
-        best_t   = better ? c : best_t;
-        best_gid = better ? k : best_gid;
+        const PairScaled p0 = pair_scaled(r, bvh.fan_pairs, k);
+        const float      c0 = cand(p0.a), c1 = cand(p0.b);
+        const bool       p01 = c1 < c0;
+        const float      m   = p01 ? c1 : c0;
+        const bool       better = m < best_t;
+        best_t   = better ? m : best_t;
+        best_gid = better ? (p01 ? p0.id + 1u : p0.id) : best_gid;
+    }
+    // ---- unpaired triangles ----
+    const uint32_t ns = bvh.fan_single_count;
+    if (ns)
+    {
+        float    st = r.tmax;
+        uint32_t si = kInvalidId;
+#pragma unroll 2
+        for (uint32_t j = 0; j < ns; ++j)
+        {
+            float4 t0, t1, t2, t3;
+            load_const_tri(bvh.fan_singles, j, t0, t1, t2, t3);
+            const float c      = cand(tri_scaled(r, t0, t1, t2));
+            const bool  better = c < st;
+            st = better ? c : st;
+            si = better ? f2u(t3.x) : si;
+        }
+        const bool better = (st < best_t) | ((st == best_t) & (si < best_gid));
+        best_t   = better ? st : best_t;
+        best_gid = better ? si : best_gid;
     }
     if (best_gid != kInvalidId)
     {
@@ -277,15 +346,24 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const floa
 // det == 0 needs no test: then U = V = 0 is the only way past the first three conditions and 0 < T < 0 rejects.
 __device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r)
 {
-    const uint32_t n   = bvh.tri_count;
+    auto occl = [&](const TriScaled& s) {
+        return (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det) & (s.T > r.tmin * s.det) & (s.T < r.tmax * s.det);
+    };
     bool           hit = false;
-#pragma unroll 4
-    for (uint32_t k = 0; k < n; ++k)
+    const uint32_t np  = bvh.fan_pair_count;
+#pragma unroll 2
+    for (uint32_t k = 0; k < np; ++k)
+    {
+        const PairScaled p = pair_scaled(r, bvh.fan_pairs, k);
+        hit |= occl(p.a) | occl(p.b);
+    }
+    const uint32_t ns = bvh.fan_single_count;
+#pragma unroll 2
+    for (uint32_t j = 0; j < ns; ++j)
     {
         float4 t0, t1, t2, t3;
-        load_const_tri(bvh.tris_by_id, k, t0, t1, t2, t3);
-        const TriScaled s = tri_scaled(r, t0, t1, t2);
-        hit |= (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det) & (s.T > r.tmin * s.det) & (s.T < r.tmax * s.det);
+        load_const_tri(bvh.fan_singles, j, t0, t1, t2, t3);
+        hit |= occl(tri_scaled(r, t0, t1, t2));
     }
     return hit;
 }
