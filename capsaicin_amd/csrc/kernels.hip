@@ -288,31 +288,52 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const floa
         return (inside & (tt > r.tmin)) ? tt : __builtin_inff();
     };
     // ---- fan pairs, two at a time ----
+    // A ray is inside at most one triangle of a planar quad except on the shared diagonal, so a pair needs one reciprocal: of the
+    // triangle the ray is inside of.  Its t is bit for bit the one the per-triangle rule computes; the other triangle's
+    // candidate is +inf either way.  Pairs some lane is inside both triangles of (non-planar fans, rays on the diagonal) take
+    // the two-reciprocal form for the whole wave (wave-uniform branch, rare).
+    auto pair_cand = [&](const PairScaled& p, float& m, uint32_t& im) {
+        const bool ia = (p.a.U >= 0.0f) & (p.a.V >= 0.0f) & (p.a.U + p.a.V <= p.a.det);
+        const bool ib = (p.b.U >= 0.0f) & (p.b.V >= 0.0f) & (p.b.U + p.b.V <= p.b.det);
+        if (__builtin_expect(__ballot(ia & ib) != 0ull, 0))
+        {
+            const float ta = p.a.T * rcp_c(p.a.det), tb = p.b.T * rcp_c(p.b.det);
+            const float ca = (ia & (ta > r.tmin)) ? ta : __builtin_inff(), cb = (ib & (tb > r.tmin)) ? tb : __builtin_inff();
+            const bool  pb = cb < ca;  // strict: the earlier triangle keeps an equal t
+            m = pb ? cb : ca, im = pb ? p.id + 1u : p.id;
+        }
+        else
+        {
+            const float tt = (ib ? p.b.T : p.a.T) * rcp_c(ib ? p.b.det : p.a.det);
+            m  = ((ia | ib) & (tt > r.tmin)) ? tt : __builtin_inff();
+            im = ib ? p.id + 1u : p.id;
+        }
+    };
     const uint32_t np = bvh.fan_pair_count;
     uint32_t       k  = 0;
     for (; k + 2 <= np; k += 2)
     {
         const PairScaled p0 = pair_scaled(r, bvh.fan_pairs, k), p1 = pair_scaled(r, bvh.fan_pairs, k + 1);
-        const float      c0 = cand(p0.a), c1 = cand(p0.b), c2 = cand(p1.a), c3 = cand(p1.b);
-        const bool       p01 = c1 < c0, p23 = c3 < c2;  // strict: the earlier triangle keeps an equal t
-        const float      m01 = p01 ? c1 : c0, m23 = p23 ? c3 : c2;
-        const uint32_t   i01 = p01 ? p0.id + 1u : p0.id, i23 = p23 ? p1.id + 1u : p1.id;
-        const bool       p   = m23 < m01;
-        const float      m   = p ? m23 : m01;
-        const uint32_t   im  = p ? i23 : i01;
-        const bool       better = m < best_t;
+        float            m01, m23;
+        uint32_t         i01, i23;
+        pair_cand(p0, m01, i01);
+        pair_cand(p1, m23, i23);
+        const bool     p  = m23 < m01;
+        const float    m  = p ? m23 : m01;
+        const uint32_t im = p ? i23 : i01;
+        const bool     better = m < best_t;
         best_t   = better ? m : best_t;
         best_gid = better ? im : best_gid;
     }
     if (k < np)
     {
         const PairScaled p0 = pair_scaled(r, bvh.fan_pairs, k);
-        const float      c0 = cand(p0.a), c1 = cand(p0.b);
-        const bool       p01 = c1 < c0;
-        const float      m   = p01 ? c1 : c0;
-        const bool       better = m < best_t;
+        float            m;
+        uint32_t         im;
+        pair_cand(p0, m, im);
+        const bool better = m < best_t;
         best_t   = better ? m : best_t;
-        best_gid = better ? (p01 ? p0.id + 1u : p0.id) : best_gid;
+        best_gid = better ? im : best_gid;
     }
     // ---- unpaired triangles ----
     const uint32_t ns = bvh.fan_single_count;
