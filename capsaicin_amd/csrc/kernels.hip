@@ -1273,7 +1273,8 @@ __device__ __forceinline__ ExtBsdf ext_bsdf(v3 kd, v3 ks, float a2, v3 nf, v3 wo
 }
 
 template <bool FIRST>
-__device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const ShadePre& pre, uint32_t klass, uint32_t pid, float4 hit, v3 thr,
+__device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float4* shade_tab, const ShadePre& pre, uint32_t klass,
+                                                 uint32_t pid, float4 hit, v3 thr,
                                                  v3 d, uint32_t& n_shaded)
 {
     const uint32_t Ppad = a.screen.pixels_padded;
@@ -1311,7 +1312,7 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const Shade
     else if (valid)
     {
         ++n_shaded;
-        const float4* st = a.scene.shade_tris + 6 * (size_t)gid;
+        const float4* st = shade_tab + 6 * (size_t)gid;
         const float4  s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3], s4 = st[4], s5 = st[5];
         const float   u = hit.x, v = hit.y, w = (1.0f - u) - v;
         auto          mix = [&](float c0, float c1, float c2) { return fmaf(c2, v, fmaf(c1, u, c0 * w)); };
@@ -1348,7 +1349,7 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const Shade
                 if (a.scene.light_cdf[mid] > target) hi = mid; else lo = mid + 1;
             }
             const uint32_t lg = a.scene.light_tris[lo];
-            const float4*  lt = a.scene.shade_tris + 6 * (size_t)lg;
+            const float4*  lt = shade_tab + 6 * (size_t)lg;
             const float4   l0 = lt[0], l1 = lt[1], l2 = lt[2];
             const v3       q0 = mk3(l0.x, l0.y, l0.z), q1 = mk3(l1.x, l1.y, l1.z), q2 = mk3(l2.x, l2.y, l2.z);
             const float    su = sqrtf(pre.r5), b0 = 1.0f - su, b1 = su * (1.0f - pre.r6), b2 = su * pre.r6;
@@ -1493,7 +1494,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
                     d               = mk3(dq.x, dq.y, dq.z);
                 }
             }
-            shade_vertex_ext<FIRST>(a, pre, klass, pid, hit, thr, d, n_shaded);
+            shade_vertex_ext<FIRST>(a, a.scene.shade_tris, pre, klass, pid, hit, thr, d, n_shaded);
         }
         else
             shade_vertex<FIRST, FB>(a, a.scene.shade_tris, pre, klass, pid, hit, thr, n_shaded, st);
@@ -1618,7 +1619,7 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
             a.planes.aov_geo[i] = g;
         }
         if constexpr (EXT)
-            shade_vertex_ext<FIRST>(a, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
+            shade_vertex_ext<FIRST>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
         else
             shade_vertex<FIRST, FB, CARRY>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded, st);
         STAMP(st, 4, false);  // stores issued
@@ -1650,7 +1651,7 @@ extern "C" int cap_debug_stamps(unsigned long long* out, int reset)
 
 void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, bool ext, bool feedback)
 {
-    const bool lds = !ext && bvh.tri_count <= kExhaustiveMax;
+    const bool lds = bvh.tri_count <= kExhaustiveMax;
     if (args.bounce == 0)
     {
         const uint32_t chunks = (args.screen.pixels_padded >> 6) * args.n_slots;
@@ -1658,7 +1659,9 @@ void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs
         if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
         if (gx == 0) gx = 1;
         const dim3 grid(gx), block(kBlock);
-        if (ext)
+        if (ext && lds)
+            hipLaunchKernelGGL((k_trace_shade<true, true, false, true>), grid, block, 0, cfg.stream, bvh, args);
+        else if (ext)
             hipLaunchKernelGGL((k_trace_shade<true, true, false, false>), grid, block, 0, cfg.stream, bvh, args);
         else if (lds)
             hipLaunchKernelGGL((k_trace_shade<true, false, false, true>), grid, block, 0, cfg.stream, bvh, args);
@@ -1667,7 +1670,9 @@ void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs
         return;
     }
     const dim3 grid(queue_grid(cfg, args.max_count)), block(kBlock);
-    if (ext)
+    if (ext && lds)
+        hipLaunchKernelGGL((k_trace_shade<false, true, false, true>), grid, block, 0, cfg.stream, bvh, args);
+    else if (ext)
         hipLaunchKernelGGL((k_trace_shade<false, true, false, false>), grid, block, 0, cfg.stream, bvh, args);
     else if (feedback && lds)
         hipLaunchKernelGGL((k_trace_shade<false, false, true, true>), grid, block, 0, cfg.stream, bvh, args);
