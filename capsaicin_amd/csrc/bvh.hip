@@ -226,8 +226,14 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t* keys, uint
     const int gamma = i + s * d + (d < 0 ? -1 : 0);
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     const int left = (lo == gamma) ? ~gamma : gamma, right = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
-    // q3 = (child0, child1); the boxes are filled by the refit
-    nodes[4 * (size_t)i + 3] = make_float4(u2f((uint32_t)left), u2f((uint32_t)right), 0.f, 0.f);
+    // q3 = (child0, child1, traversal child0, traversal child1); the boxes are filled by the refit.  The traversal pointers
+    // treat a subtree of at most kLeafMax triangles as ONE leaf: its triangles are consecutive in sorted order, so the leaf is
+    // the range code ~(first | (count - 1) << 28).  A quarter of the box tests and stack operations go away; the binary tree
+    // (and its boxes) stays complete for the refit and for cap_bvh_readback.
+    const int      nl = gamma - lo + 1, nr = hi - gamma;
+    const uint32_t tleft  = nl <= kLeafMax ? ~((uint32_t)lo | ((uint32_t)(nl - 1) << 28)) : (uint32_t)gamma;
+    const uint32_t tright = nr <= kLeafMax ? ~((uint32_t)(gamma + 1) | ((uint32_t)(nr - 1) << 28)) : (uint32_t)(gamma + 1);
+    nodes[4 * (size_t)i + 3] = make_float4(u2f((uint32_t)left), u2f((uint32_t)right), u2f(tleft), u2f(tright));
     const uint32_t pl = ((uint32_t)i << 1), pr = ((uint32_t)i << 1) | 1u;
     if (left < 0) parent[(N - 1) + gamma] = pl; else parent[gamma] = pl;
     if (right < 0) parent[(N - 1) + gamma + 1] = pr; else parent[gamma + 1] = pr;

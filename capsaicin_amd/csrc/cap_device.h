@@ -22,10 +22,13 @@ constexpr uint32_t kBlock      = 256;  // threads per workgroup (4 waves, one pe
 constexpr uint32_t kQueueClasses  = 64;
 constexpr uint32_t kCounterStride = 32;  // uint32 words between two class counters (128 B)
 constexpr uint32_t kExhaustiveMax = 64;  // scenes up to this many triangles are traced exhaustively (kernels.hip)
+constexpr int      kLeafMax       = 4;   // LBVH traversal leaves hold up to this many consecutive sorted triangles (<= 4: 2 bits)
 
 // BVH node, 64 B = 4 x float4 (both children's boxes live in the parent, one fetch tests both):
 //   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
-//   q3 = (child0, child1, -, -) as int bits; child >= 0: internal node index, child < 0: ~leaf (sorted triangle) index
+//   q3 = (child0, child1, tchild0, tchild1) as int bits; child >= 0: internal node index, child < 0: ~leaf (sorted triangle)
+//        index.  tchild = what the traversal follows: the same, except that a subtree of <= kLeafMax triangles is one leaf,
+//        ~(first sorted triangle | (count - 1) << 28)
 // Intersection triangle, 64 B = 4 x float4, in leaf order (n = cross(e1, e2)):
 //   t0 = (v0.x v0.y v0.z e1.x)  t1 = (e1.y e1.z e2.x e2.y)  t2 = (e2.z n.x n.y n.z)  t3 = (asfloat(global triangle id), -, -, -)
 // Shading triangle, 96 B = 6 x float4, in global triangle order (mesh order, then primitive order):

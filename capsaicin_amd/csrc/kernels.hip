@@ -99,7 +99,7 @@ __device__ __forceinline__ void traverse_closest(const BvhDev& bvh, const Ray& r
             float      tn0, tn1;
             const bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tn0);
             const bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tn1);
-            const int  c0 = (int)f2u(q3.x), c1 = (int)f2u(q3.y);
+            const int  c0 = (int)f2u(q3.z), c1 = (int)f2u(q3.w);
             if (h0 && h1)
             {
                 const bool swap = tn1 < tn0;
@@ -115,13 +115,17 @@ __device__ __forceinline__ void traverse_closest(const BvhDev& bvh, const Ray& r
         }
         else
         {
-            const uint32_t leaf = (uint32_t)~node;
-            const float4   t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
-            float          t, u, v;
-            if (tri_test(r, t0, t1, t2, t, u, v))
+            // leaf = up to kLeafMax consecutive sorted triangles: ~(first | (count - 1) << 28)
+            const uint32_t code = (uint32_t)~node, first = code & 0x0fffffffu, last = first + (code >> 28);
+            for (uint32_t leaf = first; leaf <= last; ++leaf)
             {
-                const uint32_t gid = f2u(bvh.tris[4 * leaf + 3].x);
-                if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+                const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
+                float        t, u, v;
+                if (tri_test(r, t0, t1, t2, t, u, v))
+                {
+                    const uint32_t gid = f2u(bvh.tris[4 * leaf + 3].x);
+                    if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+                }
             }
         }
         if (sp == 0) break;
@@ -145,7 +149,7 @@ __device__ __forceinline__ bool traverse_any(const BvhDev& bvh, const Ray& r, ui
             float      tn0, tn1;
             const bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.tmax, tn0);
             const bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.tmax, tn1);
-            const int  c0 = (int)f2u(q3.x), c1 = (int)f2u(q3.y);
+            const int  c0 = (int)f2u(q3.z), c1 = (int)f2u(q3.w);
             if (h0 && h1)
             {
                 if (sp < STACK) stack[(sp++) * kBlock] = (uint32_t)c1;
@@ -160,9 +164,12 @@ __device__ __forceinline__ bool traverse_any(const BvhDev& bvh, const Ray& r, ui
         }
         else
         {
-            const uint32_t leaf = (uint32_t)~node;
-            const float4   t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
-            if (tri_occludes(r, t0, t1, t2)) return true;
+            const uint32_t code = (uint32_t)~node, first = code & 0x0fffffffu, last = first + (code >> 28);
+            for (uint32_t leaf = first; leaf <= last; ++leaf)
+            {
+                const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
+                if (tri_occludes(r, t0, t1, t2)) return true;
+            }
         }
         if (sp == 0) break;
         node = (int)stack[(--sp) * kBlock];
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_refill(BvhDev bvh, Ray
                 float      tn0, tn1;
                 const bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tn0);
                 const bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tn1);
-                const int  c0 = (int)f2u(q3.x), c1 = (int)f2u(q3.y);
+                const int  c0 = (int)f2u(q3.z), c1 = (int)f2u(q3.w);
                 pop           = true;
                 if (h0 && h1)
                 {
@@ -687,13 +694,16 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_refill(BvhDev bvh, Ray
         }
         else if (alive && node < 0)
         {
-            const uint32_t leaf = (uint32_t)~node;
-            const float4   t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
-            float          t, u, v;
-            if (tri_test(r, t0, t1, t2, t, u, v))
+            const uint32_t code = (uint32_t)~node, first = code & 0x0fffffffu, last = first + (code >> 28);
+            for (uint32_t leaf = first; leaf <= last; ++leaf)
             {
-                const uint32_t gid = f2u(bvh.tris[4 * leaf + 3].x);
-                if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+                const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
+                float        t, u, v;
+                if (tri_test(r, t0, t1, t2, t, u, v))
+                {
+                    const uint32_t gid = f2u(bvh.tris[4 * leaf + 3].x);
+                    if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+                }
             }
             pop = true;
         }
@@ -748,7 +758,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_refill(BvhDev bvh, ShadowQ
                 float      tn0, tn1;
                 const bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.tmax, tn0);
                 const bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.tmax, tn1);
-                const int  c0 = (int)f2u(q3.x), c1 = (int)f2u(q3.y);
+                const int  c0 = (int)f2u(q3.z), c1 = (int)f2u(q3.w);
                 if (h0 && h1)
                 {
                     if (sp < STACK) stack[(sp++) * kBlock] = (uint32_t)c1;
@@ -763,9 +773,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_refill(BvhDev bvh, ShadowQ
             }
             else
             {
-                const uint32_t leaf = (uint32_t)~node;
-                const float4   t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
-                occluded = tri_occludes(r, t0, t1, t2);
+                const uint32_t code = (uint32_t)~node, first = code & 0x0fffffffu, last = first + (code >> 28);
+                for (uint32_t leaf = first; leaf <= last && !occluded; ++leaf)
+                {
+                    const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
+                    occluded = tri_occludes(r, t0, t1, t2);
+                }
             }
             if (occluded)
                 alive = false;
