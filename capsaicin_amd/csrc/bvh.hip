@@ -231,8 +231,8 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t* keys, uint
     // the range code ~(first | (count - 1) << 28).  A quarter of the box tests and stack operations go away; the binary tree
     // (and its boxes) stays complete for the refit and for cap_bvh_readback.
     const int      nl = gamma - lo + 1, nr = hi - gamma;
-    const uint32_t tleft  = nl <= kLeafMax ? ~((uint32_t)lo | ((uint32_t)(nl - 1) << 28)) : (uint32_t)gamma;
-    const uint32_t tright = nr <= kLeafMax ? ~((uint32_t)(gamma + 1) | ((uint32_t)(nr - 1) << 28)) : (uint32_t)(gamma + 1);
+    const uint32_t tleft  = nl <= kLeafMax ? ~((uint32_t)lo | ((uint32_t)(nl - 1) << kLeafCountShift)) : (uint32_t)gamma;
+    const uint32_t tright = nr <= kLeafMax ? ~((uint32_t)(gamma + 1) | ((uint32_t)(nr - 1) << kLeafCountShift)) : (uint32_t)(gamma + 1);
     nodes[4 * (size_t)i + 3] = make_float4(u2f((uint32_t)left), u2f((uint32_t)right), u2f(tleft), u2f(tright));
     const uint32_t pl = ((uint32_t)i << 1), pr = ((uint32_t)i << 1) | 1u;
     if (left < 0) parent[(N - 1) + gamma] = pl; else parent[gamma] = pl;

@@ -116,7 +116,7 @@ __device__ __forceinline__ void traverse_closest(const BvhDev& bvh, const Ray& r
         else
         {
             // leaf = up to kLeafMax consecutive sorted triangles: ~(first | (count - 1) << 28)
-            const uint32_t code = (uint32_t)~node, first = code & 0x0fffffffu, last = first + (code >> 28);
+            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
             for (uint32_t leaf = first; leaf <= last; ++leaf)
             {
                 const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
@@ -164,7 +164,7 @@ __device__ __forceinline__ bool traverse_any(const BvhDev& bvh, const Ray& r, ui
         }
         else
         {
-            const uint32_t code = (uint32_t)~node, first = code & 0x0fffffffu, last = first + (code >> 28);
+            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
             for (uint32_t leaf = first; leaf <= last; ++leaf)
             {
                 const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_refill(BvhDev bvh, Ray
         }
         else if (alive && node < 0)
         {
-            const uint32_t code = (uint32_t)~node, first = code & 0x0fffffffu, last = first + (code >> 28);
+            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
             for (uint32_t leaf = first; leaf <= last; ++leaf)
             {
                 const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_refill(BvhDev bvh, ShadowQ
             }
             else
             {
-                const uint32_t code = (uint32_t)~node, first = code & 0x0fffffffu, last = first + (code >> 28);
+                const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
                 for (uint32_t leaf = first; leaf <= last && !occluded; ++leaf)
                 {
                     const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
