@@ -141,6 +141,75 @@ def test_triangle_soup_parity(native_lib, bluenoise, seed, ntri, w, h, D):
     r.close()
 
 
+def fan_soup(seed, nquads, nsingles, fold):
+    """Indexed quads triangulated as fans (a,b,c),(a,c,d) -- the form OBJ faces take -- plus loose triangles in between.  With
+    fold > 0 the fourth vertex leaves the plane of the first three, so a ray can be inside both triangles of a pair."""
+    rs = np.random.RandomState(seed)
+    verts, idx = [], []
+    order = ["q"] * nquads + ["s"] * nsingles
+    rs.shuffle(order)
+    for kind in order:
+        c = rs.uniform(-1.5, 1.5, 3)
+        u, v = rs.normal(size=3), rs.normal(size=3)
+        u, v = 0.9 * u / np.linalg.norm(u), 0.9 * v / np.linalg.norm(v)
+        base = len(verts)
+        if kind == "q":
+            n = np.cross(u, v)
+            quad = [c, c + u, c + u + v + fold * n / max(np.linalg.norm(n), 1e-6) * rs.uniform(-1, 1), c + v]
+            verts += quad
+            idx += [base, base + 1, base + 2, base, base + 2, base + 3]
+        else:
+            verts += [c, c + u, c + v]
+            idx += [base, base + 1, base + 2]
+    pos = np.float32(verts)
+    tri = pos[np.int64(idx)].reshape(-1, 3, 3)
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-12)
+    nrm = np.zeros_like(pos)
+    nrm[np.int64(idx)] = np.repeat(fn, 3, axis=0)  # last face wins at shared vertices: any finite normal will do
+    uv = rs.rand(len(pos), 2).astype(np.float32)
+    meshes = np.uint32([[len(pos), 0, len(idx), 0, 0, 0xFFFFFFFF, 0, 0]])
+    return pos, nrm.astype(np.float32), uv, np.uint32(idx), meshes
+
+
+@pytest.mark.parametrize("seed,nquads,nsingles,fold", [(21, 15, 0, 0.0), (22, 14, 5, 0.6), (23, 31, 2, 0.3), (24, 200, 77, 0.5)])
+def test_fan_pairs_parity(native_lib, bluenoise, seed, nquads, nsingles, fold):
+    """The exhaustive kernels test triangulated quads as fan pairs (shared tvec, q, edge product; one reciprocal unless a lane is
+    inside both triangles).  Planar and folded quads, an odd number of pairs, loose triangles between them, more than 64
+    triangles (forced exhaustive mode): exhaustive == LBVH == oracle brute force, bit for bit."""
+    from oracle import cap_oracle as O
+    pos, nrm, uv, idx, meshes = fan_soup(seed, nquads, nsingles, fold)
+    w, h, D = 96, 80, 3
+    r = capi.Renderer(0)
+    r.upload_scene(pos, nrm, uv, idx, meshes)
+    r.upload_bluenoise(bluenoise)
+    r.build_bvh()
+    cam = capi.CameraData()
+    cam.position[:] = (0.2, 0.1, 6.0)
+    cam.forward[:] = (0, 0, -1)
+    cam.right[:] = (-1, 0, 0)
+    cam.up[:] = (0, 1, 0)
+    cam.focal_length = 0.03
+    cam.sensor_size[0] = 0.036
+    cam.sensor_size[1] = np.float32(0.036) * (np.float32(h) / np.float32(w))
+    r.set_resolution(w, h)
+    r.set_camera(cam)
+    sc = O.Scene(pos, nrm, uv, idx, meshes)
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1], cam.focal_length)
+    ref = sc.render_frame(ocam, bluenoise, w, h, 5, D, threads=8)
+    assert ref["rays"][1] > 0.05 * w * h  # the camera sees the soup
+    for mode in (2, 1):
+        r.set_traversal(mode)
+        r.stats_reset()
+        r.render(5, 1, D, capi.RENDER_AOV)
+        for name, kind in (("gbuffer_geo", capi.BUF_GBUFFER_GEO), ("direct", capi.BUF_DIRECT), ("indirect", capi.BUF_INDIRECT),
+                           ("normal_depth", capi.BUF_NORMAL_DEPTH)):
+            assert_same(r.readback(kind), ref[name], "%s (traversal %d)" % (name, mode))
+        s = r.stats()
+        assert (s.rays_primary, s.rays_extension, s.rays_shadow) == ref["rays"]
+    r.close()
+
+
 def test_empty_scene_and_call_order(native_lib, bluenoise):
     r = capi.Renderer(0)
     with pytest.raises(capi.CapError):
