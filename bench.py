@@ -213,7 +213,8 @@ def main():
             if tfiles and args.spp == SPP and args.scene == "cornell" and world == 1:
                 try:
                     tj = json.load(open(tfiles[-1]))
-                    traffic = tj["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+                    # sp covers exactly one step
+                    traffic = tj["hbm_bytes_per_step"] / sp.launches_trace_closest / (avg_ms * 1e-3) / 1e9
                     traffic_src = os.path.relpath(tfiles[-1], ROOT)
                 except Exception:  # a malformed file must not break the bench line
                     traffic = None

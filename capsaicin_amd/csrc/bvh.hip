@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t* keys, uint
     const int left = (lo == gamma) ? ~gamma : gamma, right = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
     // q3 = (child0, child1, traversal child0, traversal child1); the boxes are filled by the refit.  The traversal pointers
     // treat a subtree of at most kLeafMax triangles as ONE leaf: its triangles are consecutive in sorted order, so the leaf is
-    // the range code ~(first | (count - 1) << 28).  A quarter of the box tests and stack operations go away; the binary tree
+    // the range code ~(first | (count - 1) << kLeafCountShift).  Fewer box tests and stack operations; the binary tree
     // (and its boxes) stays complete for the refit and for cap_bvh_readback.
     const int      nl = gamma - lo + 1, nr = hi - gamma;
     const uint32_t tleft  = nl <= kLeafMax ? ~((uint32_t)lo | ((uint32_t)(nl - 1) << kLeafCountShift)) : (uint32_t)gamma;

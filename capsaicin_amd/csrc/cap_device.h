@@ -34,7 +34,7 @@ constexpr uint32_t kLeafFirstMask  = (1u << kLeafCountShift) - 1u;  // < 134 M t
 //   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
 //   q3 = (child0, child1, tchild0, tchild1) as int bits; child >= 0: internal node index, child < 0: ~leaf (sorted triangle)
 //        index.  tchild = what the traversal follows: the same, except that a subtree of <= kLeafMax triangles is one leaf,
-//        ~(first sorted triangle | (count - 1) << 28)
+//        ~(first sorted triangle | (count - 1) << kLeafCountShift)
 // Intersection triangle, 64 B = 4 x float4, in leaf order (n = cross(e1, e2)):
 //   t0 = (v0.x v0.y v0.z e1.x)  t1 = (e1.y e1.z e2.x e2.y)  t2 = (e2.z n.x n.y n.z)  t3 = (asfloat(global triangle id), -, -, -)
 // Shading triangle, 96 B = 6 x float4, in global triangle order (mesh order, then primitive order):

@@ -115,7 +115,7 @@ __device__ __forceinline__ void traverse_closest(const BvhDev& bvh, const Ray& r
         }
         else
         {
-            // leaf = up to kLeafMax consecutive sorted triangles: ~(first | (count - 1) << 28)
+            // leaf = up to kLeafMax consecutive sorted triangles: ~(first | (count - 1) << kLeafCountShift)
             const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
             for (uint32_t leaf = first; leaf <= last; ++leaf)
             {
