@@ -218,8 +218,27 @@ def main():
                     traffic_src = os.path.relpath(tfiles[-1], ROOT)
                 except Exception:  # a malformed file must not break the bench line
                     traffic = None
+            # the empirical stream peak of this box, measured in the same run (1 GiB float copy, read + write)
+            empirical = None
+            if world == 1:
+                try:
+                    src_t = torch.empty(1 << 28, dtype=torch.float32, device="cuda").fill_(1.0)
+                    dst_t = torch.empty_like(src_t)
+                    dst_t.copy_(src_t)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        dst_t.copy_(src_t)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    empirical = 5 * 2 * src_t.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                    del src_t, dst_t
+                except Exception:
+                    empirical = None
             roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                        "empirical_stream_peak": empirical, "frac_of_empirical": (achieved / empirical) if empirical else None,
                         "avg_launch_ms": avg_ms, "launches": int(sp.launches_trace_closest),
                         "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_ray": kernel_bytes / max(1, sp.rays_extension),
                         "rays_per_launch": sp.rays_extension / sp.launches_trace_closest,
