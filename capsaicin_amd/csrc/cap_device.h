@@ -120,11 +120,13 @@ struct RayQueue
     uint32_t* count;     // kQueueClasses device counters, kCounterStride apart
     uint32_t  class_capacity;  // entries per class, a multiple of 64
 };
+// EXT model: (o.xyz, tmin) (d.xyz, tmax) (contribution.xyz, asfloat(path id)).  Reference model (directional light, constant
+// tmin / tmax, lighting.h:39-47): (o.xyz, asfloat(path id)) in org_tmin, (contribution.xyz, -) in contrib_pid, dir_tmax unused.
 struct ShadowQueue
 {
     float4*   org_tmin;
     float4*   dir_tmax;
-    float4*   contrib_pid;  // (radiance added when unoccluded .xyz, asfloat(path id))
+    float4*   contrib_pid;  // radiance added when unoccluded
     uint32_t* count;
     uint32_t  class_capacity;
 };

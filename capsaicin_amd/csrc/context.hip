@@ -932,7 +932,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             {
                 StageTimer t(c, ST_ANY, st);
                 launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p,
-                                 work_any + b * per_queue, /* next-event estimation: most shadow rays reach the light */ ext);
+                                 work_any + b * per_queue, /* next-event estimation: most shadow rays reach the light */ ext, frames);
                 ++c->stats.launches_trace_any;
                 if (traced("trace_any", b)) return fail(CAP_ERR_HIP, "trace_any failed");
             }

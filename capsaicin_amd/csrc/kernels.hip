@@ -497,12 +497,22 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(BvhDev bvh, RayQueue q
 // L2 atomic operations per ray; with next-event estimation ~90 % of the shadow rays are unoccluded and the atomics' L2 rate
 // (about 15 per clock chip-wide, measured 31 ms per step) was the kernel's bound.  Either way the path is the word's only
 // writer within a launch, and launches are ordered on the stream, so the sums are the same IEEE additions in the same order.
+// Entry formats.  RMW (EXT model, next-event rays): (origin, tmin) (direction, tmax) (contribution, path id), 48 B.
+// !RMW (reference model): (origin, path id) (contribution, -), 32 B; direction = the light of the path's frame (LDS copy of the
+// batch's frame constants), tmin / tmax = kRayEps / kRayFar (lighting.h:39-47).
 template <int STACK, bool RMW>
 __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded, uint32_t n_slots,
-                                                      uint64_t* guard, uint32_t* work)
+                                                      uint64_t* guard, uint32_t* work, const FrameConst* frames)
 {
     __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
+    __shared__ float4   lds_light[RMW ? 1 : kMaxFrameSlots];
     uint32_t*           stack    = lds_stack + threadIdx.x;
+    if (!RMW)
+    {
+        for (uint32_t k = threadIdx.x; k < n_slots && k < kMaxFrameSlots; k += kBlock)
+            lds_light[k] = make_float4(frames[k].light_dir[0], frames[k].light_dir[1], frames[k].light_dir[2], 0.f);
+        __syncthreads();
+    }
     const uint32_t      slots    = (q.class_capacity >> 6) * kQueueClasses;
     const uint32_t      my_class = wave_global_id() % kQueueClasses;
     uint32_t            grab     = grab_issue(work, my_class);
@@ -516,16 +526,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q,
         if (__ballot(active) == 0ull) break;  // past the end of this class's sub-queue
         if (active)
         {
-            const float4 a = q.org_tmin[i], b = q.dir_tmax[i];
-            const Ray    r = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
+            const float4 a = q.org_tmin[i];
             float4       c = make_float4(0.f, 0.f, 0.f, 0.f), cur = c;
+            uint32_t     pid = 0;
             size_t       idx = 0;
             bool         good = true;
             auto         locate = [&]() {
-                c                  = q.contrib_pid[i];
-                const uint32_t pid = f2u(c.w);
-                good               = (pid >> kPidShift) < n_slots && (pid & kPidMask) < pixels_padded;
-                idx                = (size_t)(pid >> kPidShift) * pixels_padded + (pid & kPidMask);
+                good = (pid >> kPidShift) < n_slots && (pid & kPidMask) < pixels_padded;
+                idx  = (size_t)(pid >> kPidShift) * pixels_padded + (pid & kPidMask);
                 if (!good)
                 {
                     // never true for a well-formed queue; reported through CapStats::guard_* instead of faulting
@@ -533,21 +541,33 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q,
                     guard[3] = ((uint64_t)i << 32) | pid;
                 }
             };
+            Ray r;
             if (RMW)
             {
+                const float4 b = q.dir_tmax[i];
+                r   = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
+                c   = q.contrib_pid[i];
+                pid = f2u(c.w);
                 locate();
                 if (good) cur = target[idx];
+            }
+            else
+            {
+                pid = f2u(a.w);
+                locate();
+                const float4 L = lds_light[good ? (pid >> kPidShift) : 0u];
+                r = make_ray(mk3(a.x, a.y, a.z), mk3(L.x, L.y, L.z), kRayEps, good ? kRayFar : 0.0f);  // malformed entry: empty interval
             }
             if (!trace_any_any_size<STACK>(bvh, r, stack))
             {
                 // lighting.h:57-60: unoccluded -> the contribution evaluated at shading time is added
-                if (!RMW) locate();
                 if (good)
                 {
                     if (RMW)
                         target[idx] = make_float4(cur.x + c.x, cur.y + c.y, cur.z + c.z, cur.w);
                     else
                     {
+                        c         = q.contrib_pid[i];
                         float* tv = reinterpret_cast<float*>(target + idx);
                         atomicAdd(tv + 0, c.x);
                         atomicAdd(tv + 1, c.y);
@@ -846,13 +866,14 @@ void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueu
 }
 
 void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target,
-                      uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard, uint32_t* work, bool mostly_unoccluded)
+                      uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard, uint32_t* work, bool mostly_unoccluded,
+                      const FrameConst* frames)
 {
     dim3 grid(queue_grid(cfg, max_count));
     // shadow rays share one direction per frame and retire early: the plain per-chunk kernel beats the refill variant here
     // (8.3 vs 10.5 ms on the 262 k-triangle scene); k_trace_any_refill stays available for incoherent occlusion rays (EXT: NEE)
 #define CAP_LAUNCH_ANY(S, R) \
-    hipLaunchKernelGGL((k_trace_any<S, R>), grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard, work)
+    hipLaunchKernelGGL((k_trace_any<S, R>), grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard, work, frames)
     if (cfg.stack_entries == 0)
     {
         if (mostly_unoccluded) CAP_LAUNCH_ANY(0, true); else CAP_LAUNCH_ANY(0, false);
@@ -1242,9 +1263,10 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
         si += klass * a.shadow.class_capacity;
         if (emit_shadow)
         {
-            a.shadow.org_tmin[si]    = make_float4(p.x, p.y, p.z, kRayEps);
-            a.shadow.dir_tmax[si]    = make_float4(pre.L.x, pre.L.y, pre.L.z, kRayFar);
-            a.shadow.contrib_pid[si] = make_float4(contrib.x, contrib.y, contrib.z, u2f(pid));
+            // reference model: the shadow ray's direction is its frame's light and tmin / tmax are constants (lighting.h:39-47), so
+            // the entry is 32 B -- (origin, path id) and the contribution; the any-hit kernel looks the direction up by frame slot
+            a.shadow.org_tmin[si]    = make_float4(p.x, p.y, p.z, u2f(pid));
+            a.shadow.contrib_pid[si] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
         }
         if (emit_ext)
         {
