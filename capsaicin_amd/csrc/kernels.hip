@@ -558,7 +558,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q,
                 const float4 L = lds_light[good ? (pid >> kPidShift) : 0u];
                 r = make_ray(mk3(a.x, a.y, a.z), mk3(L.x, L.y, L.z), kRayEps, good ? kRayFar : 0.0f);  // malformed entry: empty interval
             }
-            if (!trace_any_any_size<STACK>(bvh, r, stack))
+            if (STACK == 0) __builtin_amdgcn_s_setprio(0);
+            const bool occluded = trace_any_any_size<STACK>(bvh, r, stack);
+            if (STACK == 0) __builtin_amdgcn_s_setprio(3);
+            if (!occluded)
             {
                 // lighting.h:57-60: unoccluded -> the contribution evaluated at shading time is added
                 if (good)
@@ -1639,7 +1642,13 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
         float    t, u, v;
         uint32_t gid;
         STAMP(st, 0, true);  // queue entry arrived
+        // The triangle loop is the long, purely arithmetic phase; everything around it (queue reads, shading with its LDS gathers,
+        // the append atomic, the stores) is short and latency-bound.  Raising the wave's priority outside the loop lets those
+        // phases issue ahead of other waves' loops, so more memory operations are in flight per SIMD (closest 18.1 -> 17.5 ms;
+        // the opposite assignment: no gain).
+        __builtin_amdgcn_s_setprio(0);
         exhaustive_closest(bvh, rec_tab, r, t, u, v, gid);
+        __builtin_amdgcn_s_setprio(3);
         STAMP(st, 1, true);  // triangle loop + winner's record
         const ShadePre pre = shade_prefetch<EXT, FIRST, CARRY>(a, lds_frames, active, pid, carried_r1, carried_r2);
         if (FIRST && slot == a.aov_slot)
