@@ -196,10 +196,13 @@ def main():
                 # writes one 48-B extension entry and one 48-B shadow entry per ray it emits (DESIGN.md "algorithmic bytes")
                 ext_out = sp.rays_extension - sp.rays_extension_bounce0
                 sh_out = sp.rays_shadow - sp.rays_shadow_bounce0
-                kernel_bytes = 48 * sp.rays_extension + 48 * ext_out + 48 * sh_out
+                SH_ENTRY = 32  # reference-model shadow entry: (origin, path id) + (contribution, -); see DESIGN.md "Data layout"
+                kernel_bytes = 48 * sp.rays_extension + 48 * ext_out + SH_ENTRY * sh_out
                 kernel_name = "k_trace_shade<bounce>=1> (exhaustive closest hit + shading, fused)"
-                all_bytes = kernel_bytes + 48 * (sp.rays_extension_bounce0 + sp.rays_shadow_bounce0) + 48 * sp.rays_primary + \
-                    (48 + 32) * sp.rays_shadow + 48 * sp.rays_primary
+                # + bounce-0 kernel (3 planes + its queue writes), any-hit (16-B origin read per ray, 16-B contribution read and 12 B
+                # added per unoccluded ray: counted as 16 + 12 per ray, an upper bound), resolve (48 B per path)
+                all_bytes = kernel_bytes + 48 * sp.rays_extension_bounce0 + SH_ENTRY * sp.rays_shadow_bounce0 + 48 * sp.rays_primary + \
+                    (16 + 12) * sp.rays_shadow + 48 * sp.rays_primary
             else:
                 kernel_bytes = BYTES_CLOSEST * sp.rays_extension
                 kernel_name = "k_trace_closest"
