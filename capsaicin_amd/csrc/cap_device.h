@@ -27,6 +27,8 @@ constexpr uint32_t kExhaustiveMax = 64;  // scenes up to this many triangles are
 #define CAP_LEAF_MAX 2  // 262 k-triangle scene, ms per step: 1: 31.0, 2: 28.6, 3: 29.2, 4: 30.4, 8: 34.7
 #endif
 constexpr int      kLeafMax        = CAP_LEAF_MAX;  // <= 8 (3 bits)
+constexpr int      kNoChild        = 0x7fffffff;  // unused slot of a wide node
+constexpr uint32_t kSpillEntries   = 16;  // per-thread traversal-stack entries kept in global memory behind the 32 in LDS
 constexpr uint32_t kLeafCountShift = 27;
 constexpr uint32_t kLeafFirstMask  = (1u << kLeafCountShift) - 1u;  // < 134 M triangles
 
@@ -42,6 +44,10 @@ constexpr uint32_t kLeafFirstMask  = (1u << kLeafCountShift) - 1u;  // < 134 M t
 struct BvhDev
 {
     const float4* nodes;
+    const float4* nodes4;      // wide view: per internal node the four grandchild boxes, SoA, 128 B (bvh.hip k_node4)
+    uint32_t*     stack_spill; // kSpillEntries words per thread of the persistent grid: stack entries beyond the LDS part
+    uint32_t      spill_threads;  // threads the spill area is sized for
+    uint32_t      wide_ok;        // the wide kernels' stack bound 3 * ceil(depth / 2) fits 32 LDS + kSpillEntries entries
     const float4* tris;        // 64-B intersection records in leaf order (.w of the 4th float4 = global triangle id)
     const float4* tris_by_id;  // the same records in global triangle id order (exhaustive small-scene kernels)
     // exhaustive loop order: fan pairs (triangles id, id + 1 sharing v0 and the edge v0->v2), 20 floats each

@@ -130,6 +130,8 @@ struct CapContext
 
     // BVH
     DevBuf<float4>   shade_tris, tris_sorted, nodes, tri_raw, tri_box;
+    DevBuf<float4>   nodes4;                  // wide view of the tree, 8 float4 per internal node (bvh.hip k_node4)
+    DevBuf<uint32_t> stack_spill;             // traversal-stack entries beyond the LDS part, per thread of the persistent grid
     DevBuf<float4>   fan_pairs, fan_singles;  // exhaustive path: fan-pair records (5 float4) and the unpaired triangles (4 float4)
     uint32_t         fan_pair_count = 0, fan_single_count = 0;
     DevBuf<uint32_t> leaf_tri, keys0, keys1, vals0, vals1, hist, parent, flags, bvh_misc;  // bvh_misc: 6 bounds + depth
@@ -317,6 +319,11 @@ BvhDev bvh_dev(const CapContext* c)
     b.nodes     = c->nodes.p;
     b.tris      = c->tris_sorted.p;
     b.tris_by_id = c->tri_raw.p;
+    b.nodes4 = c->nodes4.p;
+    b.stack_spill   = c->stack_spill.p;
+    b.spill_threads = (uint32_t)(c->stack_spill.n / kSpillEntries);
+    static const bool binary_only = getenv("CAP_BVH_BINARY") != nullptr;  // A/B switch: binary traversal kernels only
+    b.wide_ok = !binary_only && c->stack_spill.p && c->tri_count >= 2 && 3u * ((c->bvh_info.max_depth + 1u) / 2u) <= 32u + kSpillEntries;
     b.fan_pairs = c->fan_pairs.p, b.fan_singles = c->fan_singles.p;
     b.fan_pair_count = c->fan_pair_count, b.fan_single_count = c->fan_single_count;
     b.tri_count = c->tri_count;
@@ -607,6 +614,8 @@ int cap_bvh_build(CapContext* c)
     HIP_TRY(c->tri_raw.ensure(4 * (size_t)n));
     HIP_TRY(c->tri_box.ensure(2 * (size_t)n));
     HIP_TRY(c->nodes.ensure(4 * (size_t)(n > 1 ? n - 1 : 1)));
+    HIP_TRY(c->nodes4.ensure(8 * (size_t)(n > 1 ? n - 1 : 1)));
+    HIP_TRY(c->stack_spill.ensure((size_t)c->cu_count * 8 * kBlock * kSpillEntries));  // up to 8 workgroups per CU
     HIP_TRY(c->leaf_tri.ensure(n));
     HIP_TRY(c->keys0.ensure(n));
     HIP_TRY(c->keys1.ensure(n));
@@ -620,6 +629,7 @@ int cap_bvh_build(CapContext* c)
     a.positions = c->positions.p, a.normals = c->normals.p, a.texcoords = c->texcoords.p, a.indices = c->indices.p;
     a.tri_ids = c->tri_ids.p, a.mesh_offsets = c->mesh_offsets.p, a.tri_count = n;
     a.shade_tris = c->shade_tris.p, a.tris_sorted = c->tris_sorted.p, a.nodes = c->nodes.p, a.leaf_tri = c->leaf_tri.p;
+    a.nodes4 = c->nodes4.p;
     a.tri_raw = c->tri_raw.p, a.tri_box = c->tri_box.p;
     a.keys[0] = c->keys0.p, a.keys[1] = c->keys1.p, a.vals[0] = c->vals0.p, a.vals[1] = c->vals1.p;
     a.hist = c->hist.p, a.parent = c->parent.p, a.flags = c->flags.p, a.bounds = c->bvh_misc.p, a.max_depth = c->bvh_misc.p + 6;

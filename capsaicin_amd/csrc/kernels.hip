@@ -743,6 +743,127 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_refill(BvhDev bvh, Ray
     }
 }
 
+// The same kernel on the wide view of the tree (bvh.hip k_node4): two binary levels per step.
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void k_trace_closest_refill4(BvhDev bvh, RayQueue q, float4* hits)
+{
+    __shared__ uint32_t lds_stack[STACK * kBlock];
+    uint32_t*           stack = lds_stack + threadIdx.x;
+    // entries beyond the LDS part (a wide step pushes up to three; the host checks 3 * ceil(depth / 2) <= STACK + kSpillEntries)
+    uint32_t* const spill = bvh.stack_spill + (size_t)(blockIdx.x * kBlock + threadIdx.x) * kSpillEntries;
+    WaveFeed            feed;
+    feed_init(feed, q.class_capacity);
+    if (bvh.tri_count == 0)
+    {
+        // no geometry: every queued ray misses
+        for (uint32_t cs = wave_global_id(); cs < feed.slots; cs += wave_total())
+        {
+            uint32_t i, klass;
+            if (queue_chunk(q.count, q.class_capacity, cs, threadIdx.x & 63u, i, klass)) hits[i] = make_float4(0.f, 0.f, u2f(kInvalidId), 0.f);
+        }
+        return;
+    }
+    bool     alive = false;
+    Ray      r     = make_ray(mk3(0, 0, 0), mk3(0, 0, 1), 0.f, 0.f);
+    float    best_t = 0.f, best_u = 0.f, best_v = 0.f;
+    uint32_t best_gid = kInvalidId, out = 0;
+    int      node = 0, sp = 0;
+    auto     push = [&](int x) {
+        if (sp < STACK)
+            stack[sp * kBlock] = (uint32_t)x;
+        else
+            spill[sp - STACK] = (uint32_t)x;
+        ++sp;
+    };
+    while (true)
+    {
+        const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+        if (!feed.exhausted && 64u - n_alive >= kRefillIdle)
+        {
+            const uint32_t i = feed_take(feed, !alive, q.count, q.class_capacity);
+            if (i != kInvalidId)
+            {
+                const float4 a = q.org_tmin[i], b = q.dir_tmax[i];
+                r      = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
+                best_t = r.tmax, best_u = 0.f, best_v = 0.f, best_gid = kInvalidId;
+                out = i, node = bvh.root, sp = 0, alive = true;
+            }
+        }
+        if (__ballot(alive) == 0ull) break;  // feed exhausted and every lane retired
+        // while-while: as long as enough lanes sit on an internal node only the box code runs; lanes that reached a leaf wait
+        // until leaves are due (few lanes left on internal nodes), then only the triangle code runs.  Every iteration pays for
+        // one of the two bodies instead of both.
+        const unsigned long long m_inner = __ballot(alive && node >= 0);
+        const unsigned long long m_leaf  = __ballot(alive && node < 0);
+        const bool               inner_phase = __popcll(m_inner) >= kLeafBatch || m_leaf == 0ull;
+        bool pop = false;
+        if (inner_phase)
+        {
+            if (alive && node >= 0)
+            {
+                // four grandchild boxes with one 112-B fetch (k_node4), sorted by entry distance: nearest next, the others pushed
+                // farthest first
+                const float4* N  = bvh.nodes4 + 8 * (size_t)node;
+                const float4  lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], cc = N[6];
+                float         tn[4];
+                int           ch[4] = {(int)f2u(cc.x), (int)f2u(cc.y), (int)f2u(cc.z), (int)f2u(cc.w)};
+                // an unused slot is told by its child value, not by its box: the slab test's overflow handling is conservative
+                // (inf * inv never rejects), so no box content reliably fails it
+                const bool    h0 = slab(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, best_t, tn[0]) && ch[0] != kNoChild;
+                const bool    h1 = slab(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, best_t, tn[1]) && ch[1] != kNoChild;
+                const bool    h2 = slab(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, best_t, tn[2]) && ch[2] != kNoChild;
+                const bool    h3 = slab(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, best_t, tn[3]) && ch[3] != kNoChild;
+                const float   kInf = __builtin_inff();
+                tn[0] = h0 ? tn[0] : kInf, tn[1] = h1 ? tn[1] : kInf, tn[2] = h2 ? tn[2] : kInf, tn[3] = h3 ? tn[3] : kInf;
+                auto cswap = [&](int i, int j) {
+                    const bool  sw = tn[j] < tn[i];
+                    const float ta = sw ? tn[j] : tn[i], tb = sw ? tn[i] : tn[j];
+                    const int   ca = sw ? ch[j] : ch[i], cb = sw ? ch[i] : ch[j];
+                    tn[i] = ta, tn[j] = tb, ch[i] = ca, ch[j] = cb;
+                };
+                cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
+                const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+                pop          = nh == 0;
+                if (nh > 0)
+                {
+                    node = ch[0];
+                    if (nh > 3) push(ch[3]);
+                    if (nh > 2) push(ch[2]);
+                    if (nh > 1) push(ch[1]);
+                }
+            }
+        }
+        else if (alive && node < 0)
+        {
+            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
+            for (uint32_t leaf = first; leaf <= last; ++leaf)
+            {
+                const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
+                float        t, u, v;
+                if (tri_test(r, t0, t1, t2, t, u, v))
+                {
+                    const uint32_t gid = f2u(bvh.tris[4 * leaf + 3].x);
+                    if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+                }
+            }
+            pop = true;
+        }
+        if (pop)
+        {
+            if (sp == 0)
+            {
+                hits[out] = make_float4(best_u, best_v, u2f(best_gid), best_t);
+                alive     = false;
+            }
+            else
+            {
+                --sp;
+                node = (int)(sp < STACK ? stack[sp * kBlock] : spill[sp - STACK]);
+            }
+        }
+    }
+}
+
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_trace_any_refill(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded,
                                                              uint32_t n_slots, uint64_t* guard)
@@ -862,6 +983,8 @@ void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueu
     dim3 grid(queue_grid(cfg, max_count));
     if (cfg.stack_entries == 0)
         hipLaunchKernelGGL(k_trace_closest<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
+    else if (bvh.wide_ok && grid.x * kBlock <= bvh.spill_threads)
+        hipLaunchKernelGGL(k_trace_closest_refill4<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
     else if (cfg.stack_entries <= 32)
         hipLaunchKernelGGL(k_trace_closest_refill<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
     else
