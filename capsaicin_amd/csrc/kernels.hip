@@ -80,6 +80,135 @@ __device__ __forceinline__ bool tri_occludes(const Ray& r, const float4 t0, cons
     return (det > 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= det) & (T > r.tmin * det) & (T < r.tmax * det);
 }
 
+// ---- wide view of the tree (bvh.hip k_node4): four grandchild boxes per 128-B node, two binary levels per step ----
+// Per-lane stack: STACK entries in LDS, then kSpillEntries in global memory (a wide step pushes up to three entries; the host
+// enables these paths only when 3 * ceil(depth / 2) fits, BvhDev::wide_ok, and only on 1-D grids the spill area covers).
+template <int STACK>
+struct LaneStack
+{
+    uint32_t* lds;    // this lane's column: entry k at lds[k * kBlock]
+    uint32_t* spill;  // this thread's kSpillEntries words
+    int       sp;
+    __device__ __forceinline__ void push(int x)
+    {
+        if (sp < STACK)
+            lds[sp * kBlock] = (uint32_t)x;
+        else
+            spill[sp - STACK] = (uint32_t)x;
+        ++sp;
+    }
+    __device__ __forceinline__ int pop()
+    {
+        --sp;
+        return (int)(sp < STACK ? lds[sp * kBlock] : spill[sp - STACK]);
+    }
+};
+__device__ __forceinline__ uint32_t* spill_of_thread(const BvhDev& bvh)
+{
+    return bvh.stack_spill + (size_t)(blockIdx.x * kBlock + threadIdx.x) * kSpillEntries;
+}
+// Tests the four slots of wide node `node`; returns the number of boxes hit and their children sorted by entry distance.
+__device__ __forceinline__ int wide_step(const BvhDev& bvh, const Ray& r, int node, float tfar, bool sorted, int ch[4])
+{
+    const float4* N  = bvh.nodes4 + 8 * (size_t)node;
+    const float4  lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], cc = N[6];
+    float         tn[4];
+    ch[0] = (int)f2u(cc.x), ch[1] = (int)f2u(cc.y), ch[2] = (int)f2u(cc.z), ch[3] = (int)f2u(cc.w);
+    // an unused slot is told by its child value, not by its box: the slab test's overflow handling is conservative
+    // (inf * inv never rejects), so no box content reliably fails it
+    const bool  h0 = slab(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, tfar, tn[0]) && ch[0] != kNoChild;
+    const bool  h1 = slab(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, tfar, tn[1]) && ch[1] != kNoChild;
+    const bool  h2 = slab(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, tfar, tn[2]) && ch[2] != kNoChild;
+    const bool  h3 = slab(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, tfar, tn[3]) && ch[3] != kNoChild;
+    const float kInf = __builtin_inff();
+    tn[0] = h0 ? tn[0] : kInf, tn[1] = h1 ? tn[1] : kInf, tn[2] = h2 ? tn[2] : kInf, tn[3] = h3 ? tn[3] : kInf;
+    auto cswap = [&](int i, int j) {
+        const bool  sw = tn[j] < tn[i];
+        const float ta = sw ? tn[j] : tn[i], tb = sw ? tn[i] : tn[j];
+        const int   ca = sw ? ch[j] : ch[i], cb = sw ? ch[i] : ch[j];
+        tn[i] = ta, tn[j] = tb, ch[i] = ca, ch[j] = cb;
+    };
+    cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);  // misses (+inf) end up last even when order is not needed
+    (void)sorted;
+    return (int)h0 + (int)h1 + (int)h2 + (int)h3;
+}
+
+template <int STACK>
+__device__ __forceinline__ void traverse_closest4(const BvhDev& bvh, const Ray& r, uint32_t* stack, float& best_t, float& best_u,
+                                                  float& best_v, uint32_t& best_gid)
+{
+    best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
+    LaneStack<STACK> st{stack, spill_of_thread(bvh), 0};
+    int              node = bvh.root;
+    while (true)
+    {
+        if (node >= 0)
+        {
+            int       ch[4];
+            const int nh = wide_step(bvh, r, node, best_t, true, ch);
+            if (nh > 0)
+            {
+                node = ch[0];
+                if (nh > 3) st.push(ch[3]);
+                if (nh > 2) st.push(ch[2]);
+                if (nh > 1) st.push(ch[1]);
+                continue;
+            }
+        }
+        else
+        {
+            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
+            for (uint32_t leaf = first; leaf <= last; ++leaf)
+            {
+                const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
+                float        t, u, v;
+                if (tri_test(r, t0, t1, t2, t, u, v))
+                {
+                    const uint32_t gid = f2u(bvh.tris[4 * leaf + 3].x);
+                    if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+                }
+            }
+        }
+        if (st.sp == 0) break;
+        node = st.pop();
+    }
+}
+
+template <int STACK>
+__device__ __forceinline__ bool traverse_any4(const BvhDev& bvh, const Ray& r, uint32_t* stack)
+{
+    LaneStack<STACK> st{stack, spill_of_thread(bvh), 0};
+    int              node = bvh.root;
+    while (true)
+    {
+        if (node >= 0)
+        {
+            int       ch[4];
+            const int nh = wide_step(bvh, r, node, r.tmax, false, ch);
+            if (nh > 0)
+            {
+                node = ch[0];
+                if (nh > 3) st.push(ch[3]);
+                if (nh > 2) st.push(ch[2]);
+                if (nh > 1) st.push(ch[1]);
+                continue;
+            }
+        }
+        else
+        {
+            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
+            for (uint32_t leaf = first; leaf <= last; ++leaf)
+            {
+                const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
+                if (tri_occludes(r, t0, t1, t2)) return true;
+            }
+        }
+        if (st.sp == 0) break;
+        node = st.pop();
+    }
+    return false;
+}
+
 // Closest hit: minimum t, equal t resolved towards the lower global triangle id (visit-order independent).
 // stack: this lane's column of the per-wave LDS stack; entry k lives at stack[k * kBlock].
 template <int STACK>
@@ -88,6 +217,7 @@ __device__ __forceinline__ void traverse_closest(const BvhDev& bvh, const Ray& r
 {
     best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
     if (bvh.tri_count == 0) return;
+    if (bvh.wide_ok) return traverse_closest4<STACK>(bvh, r, stack, best_t, best_u, best_v, best_gid);  // wave-uniform
     int node = bvh.root;
     int sp   = 0;
     while (true)
@@ -138,6 +268,7 @@ template <int STACK>
 __device__ __forceinline__ bool traverse_any(const BvhDev& bvh, const Ray& r, uint32_t* stack)
 {
     if (bvh.tri_count == 0) return false;
+    if (bvh.wide_ok) return traverse_any4<STACK>(bvh, r, stack);  // wave-uniform
     int node = bvh.root;
     int sp   = 0;
     while (true)
@@ -445,6 +576,9 @@ __device__ __forceinline__ v3 primary_dir(const CameraDev& cam, const ScreenDev&
     return normalize3(d);
 }
 
+// One workgroup per four 64-pixel groups of a frame slot (blockIdx.y): camera rays are coherent but their cost varies strongly
+// over the image, and a persistent grid with static slots left long tails here (4.1 -> 5.4 ms on the 262 k-triangle scene).
+// The grid is therefore far larger than the wide traversal's spill area: binary traversal (wide_ok cleared by the launcher).
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_trace_primary(BvhDev bvh, CameraDev cam, ScreenDev screen, const FrameConst* frames,
                                                           float4* hits)
@@ -955,6 +1089,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_refill(BvhDev bvh, ShadowQ
     }
 }
 
+// the wide traversal paths need every thread of the (1-D) grid to own a slice of the spill area
+static BvhDev for_grid(const BvhDev& bvh, uint32_t grid_blocks)
+{
+    BvhDev b = bvh;
+    if ((uint64_t)grid_blocks * kBlock > b.spill_threads) b.wide_ok = 0;
+    return b;
+}
+
 void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraDev& cam, const ScreenDev& screen,
                           const FrameConst* frames, uint32_t n_slots, float4* hits)
 {
@@ -962,13 +1104,15 @@ void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraD
     uint32_t       gx     = (chunks + 3) / 4;
     if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
     if (gx == 0) gx = 1;
-    dim3 grid(gx, n_slots);
+    const dim3 grid(gx, n_slots);
+    BvhDev     b = bvh;
+    b.wide_ok    = 0;  // 2-D grid: no per-thread spill slice
     if (cfg.stack_entries == 0)
-        hipLaunchKernelGGL(k_trace_primary<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, cam, screen, frames, hits);
+        hipLaunchKernelGGL(k_trace_primary<0>, grid, dim3(kBlock), 0, cfg.stream, b, cam, screen, frames, hits);
     else if (cfg.stack_entries <= 32)
-        hipLaunchKernelGGL(k_trace_primary<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, cam, screen, frames, hits);
+        hipLaunchKernelGGL(k_trace_primary<32>, grid, dim3(kBlock), 0, cfg.stream, b, cam, screen, frames, hits);
     else
-        hipLaunchKernelGGL(k_trace_primary<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, cam, screen, frames, hits);
+        hipLaunchKernelGGL(k_trace_primary<64>, grid, dim3(kBlock), 0, cfg.stream, b, cam, screen, frames, hits);
 }
 
 static uint32_t queue_grid(const LaunchCfg& cfg, uint32_t max_count)
@@ -995,11 +1139,12 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
                       uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard, uint32_t* work, bool mostly_unoccluded,
                       const FrameConst* frames)
 {
-    dim3 grid(queue_grid(cfg, max_count));
+    dim3         grid(queue_grid(cfg, max_count));
+    const BvhDev bw = for_grid(bvh, grid.x);
     // shadow rays share one direction per frame and retire early: the plain per-chunk kernel beats the refill variant here
     // (8.3 vs 10.5 ms on the 262 k-triangle scene); k_trace_any_refill stays available for incoherent occlusion rays (EXT: NEE)
 #define CAP_LAUNCH_ANY(S, R) \
-    hipLaunchKernelGGL((k_trace_any<S, R>), grid, dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard, work, frames)
+    hipLaunchKernelGGL((k_trace_any<S, R>), grid, dim3(kBlock), 0, cfg.stream, bw, q, target, pixels_padded, n_slots, guard, work, frames)
     if (cfg.stack_entries == 0)
     {
         if (mostly_unoccluded) CAP_LAUNCH_ANY(0, true); else CAP_LAUNCH_ANY(0, false);
