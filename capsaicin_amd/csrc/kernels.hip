@@ -776,9 +776,15 @@ __device__ __forceinline__ uint32_t feed_take(WaveFeed& f, bool idle, const uint
     return mine;
 }
 
-constexpr uint32_t kRefillIdle = 20;  // refill once this many lanes are idle (amortises the ray-load latency over several lanes)
+#ifndef CAP_REFILL_IDLE
+#define CAP_REFILL_IDLE 28
+#endif
+#ifndef CAP_LEAF_BATCH
+#define CAP_LEAF_BATCH 24
+#endif
+constexpr uint32_t kRefillIdle = CAP_REFILL_IDLE;  // refill once this many lanes are idle (amortises the ray-load latency over several lanes)
 constexpr uint32_t kRefillIdleAny = 40;  // shadow rays retire quickly: refill in larger batches
-constexpr int      kLeafBatch  = 24;  // keep running the box code while at least this many lanes are on internal nodes
+constexpr int      kLeafBatch  = CAP_LEAF_BATCH;  // keep running the box code while at least this many lanes are on internal nodes
 
 template <int STACK>
 __global__ __launch_bounds__(kBlock) void k_trace_closest_refill(BvhDev bvh, RayQueue q, float4* hits)
