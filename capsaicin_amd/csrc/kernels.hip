@@ -783,7 +783,6 @@ __device__ __forceinline__ uint32_t feed_take(WaveFeed& f, bool idle, const uint
 #define CAP_LEAF_BATCH 24
 #endif
 constexpr uint32_t kRefillIdle = CAP_REFILL_IDLE;  // refill once this many lanes are idle (amortises the ray-load latency over several lanes)
-constexpr uint32_t kRefillIdleAny = 40;  // shadow rays retire quickly: refill in larger batches
 constexpr int      kLeafBatch  = CAP_LEAF_BATCH;  // keep running the box code while at least this many lanes are on internal nodes
 
 template <int STACK>
@@ -1004,96 +1003,6 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_refill4(BvhDev bvh, Ra
     }
 }
 
-template <int STACK>
-__global__ __launch_bounds__(kBlock) void k_trace_any_refill(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded,
-                                                             uint32_t n_slots, uint64_t* guard)
-{
-    __shared__ uint32_t lds_stack[STACK * kBlock];
-    uint32_t*           stack = lds_stack + threadIdx.x;
-    WaveFeed            feed;
-    feed_init(feed, q.class_capacity);
-    bool     alive = false;
-    Ray      r     = make_ray(mk3(0, 0, 0), mk3(0, 0, 1), 0.f, 0.f);
-    uint32_t out   = 0;
-    int      node = 0, sp = 0;
-    while (true)
-    {
-        const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
-        if (!feed.exhausted && 64u - n_alive >= kRefillIdleAny)
-        {
-            const uint32_t i = feed_take(feed, !alive, q.count, q.class_capacity);
-            if (i != kInvalidId)
-            {
-                const float4 a = q.org_tmin[i], b = q.dir_tmax[i];
-                r   = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
-                out = i, node = bvh.root, sp = 0, alive = true;
-            }
-        }
-        if (__ballot(alive) == 0ull) break;
-        if (alive)
-        {
-            bool pop = true, occluded = false;
-            if (bvh.tri_count == 0)
-                sp = 0;  // nothing to hit: retire unoccluded
-            else if (node >= 0)
-            {
-                const float4 q0 = bvh.nodes[4 * node + 0], q1 = bvh.nodes[4 * node + 1], q2 = bvh.nodes[4 * node + 2],
-                             q3 = bvh.nodes[4 * node + 3];
-                float      tn0, tn1;
-                const bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r.tmax, tn0);
-                const bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r.tmax, tn1);
-                const int  c0 = (int)f2u(q3.z), c1 = (int)f2u(q3.w);
-                if (h0 && h1)
-                {
-                    if (sp < STACK) stack[(sp++) * kBlock] = (uint32_t)c1;
-                    node = c0;
-                    pop  = false;
-                }
-                else if (h0 || h1)
-                {
-                    node = h0 ? c0 : c1;
-                    pop  = false;
-                }
-            }
-            else
-            {
-                const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
-                for (uint32_t leaf = first; leaf <= last && !occluded; ++leaf)
-                {
-                    const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
-                    occluded = tri_occludes(r, t0, t1, t2);
-                }
-            }
-            if (occluded)
-                alive = false;
-            else if (pop)
-            {
-                if (sp == 0)
-                {
-                    // lighting.h:57-60: unoccluded -> add the contribution evaluated at shading time (sole writer of this path)
-                    const float4   c   = q.contrib_pid[out];
-                    const uint32_t pid = f2u(c.w);
-                    if ((pid >> kPidShift) >= n_slots || (pid & kPidMask) >= pixels_padded)
-                    {
-                        atomicAdd((unsigned long long*)guard + 2, 1ull);
-                        guard[3] = ((uint64_t)out << 32) | pid;
-                    }
-                    else
-                    {
-                        const size_t idx = (size_t)(pid >> kPidShift) * pixels_padded + (pid & kPidMask);
-                        float*       tv  = reinterpret_cast<float*>(target + idx);
-                        atomicAdd(tv + 0, c.x);
-                        atomicAdd(tv + 1, c.y);
-                        atomicAdd(tv + 2, c.z);
-                    }
-                    alive = false;
-                }
-                else
-                    node = (int)stack[(--sp) * kBlock];
-            }
-        }
-    }
-}
 
 // the wide traversal paths need every thread of the (1-D) grid to own a slice of the spill area
 static BvhDev for_grid(const BvhDev& bvh, uint32_t grid_blocks)
@@ -1148,7 +1057,7 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
     dim3         grid(queue_grid(cfg, max_count));
     const BvhDev bw = for_grid(bvh, grid.x);
     // shadow rays share one direction per frame and retire early: the plain per-chunk kernel beats the refill variant here
-    // (8.3 vs 10.5 ms on the 262 k-triangle scene); k_trace_any_refill stays available for incoherent occlusion rays (EXT: NEE)
+    // (8.3 vs 10.5 ms on the 262 k-triangle scene when it was tried)
 #define CAP_LAUNCH_ANY(S, R) \
     hipLaunchKernelGGL((k_trace_any<S, R>), grid, dim3(kBlock), 0, cfg.stream, bw, q, target, pixels_padded, n_slots, guard, work, frames)
     if (cfg.stack_entries == 0)
