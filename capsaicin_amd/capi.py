@@ -84,6 +84,7 @@ SYMBOLS = {
     "cap_bluenoise_upload": (_i, [_vp, _vp]),
     "cap_materials_upload": (_i, [_vp, _vp, _u32]),
     "cap_bvh_build": (_i, [_vp]),
+    "cap_set_bvh_build": (_i, [_vp, _u32]),
     "cap_bvh_info": (_i, [_vp, C.POINTER(BvhInfo)]),
     "cap_bvh_readback": (_i, [_vp, _vp, _vp]),
     "cap_camera_set": (_i, [_vp, C.POINTER(CameraData)]),
@@ -250,6 +251,10 @@ class Renderer:
     def upload_materials(self, materials):
         m = np.ascontiguousarray(materials, np.float32).reshape(-1, 12)
         _check(lib().cap_materials_upload(self.ctx, _p(m), m.shape[0]), "cap_materials_upload")
+
+    def set_bvh_build(self, mode):
+        """0 auto, 1 LBVH on the device (fast build), 2 SAH on the host (fast trace)."""
+        _check(lib().cap_set_bvh_build(self.ctx, mode), "cap_set_bvh_build")
 
     def build_bvh(self):
         _check(lib().cap_bvh_build(self.ctx), "cap_bvh_build")

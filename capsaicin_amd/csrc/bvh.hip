@@ -349,14 +349,21 @@ __global__ __launch_bounds__(kBlock) void k_depth(const uint32_t* parent, uint32
     for (int off = 32; off > 0; off >>= 1) depth = max(depth, (uint32_t)__shfl_down(depth, off));
     if ((threadIdx.x & 63u) == 0 && depth) atomicMax(max_depth, depth);
 }
+// Host-built tree (sah_builder.cpp): copy the intersection records into leaf order.
+__global__ __launch_bounds__(kBlock) void k_gather_sorted(BvhBuildArgs a)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.tri_count) return;
+    const uint32_t g = a.leaf_tri[i];
+    for (int k = 0; k < 4; ++k) a.tris_sorted[4 * (size_t)i + k] = a.tri_raw[4 * (size_t)g + k];
+}
 }  // namespace
 
 size_t bvh_radix_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 
-void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
+static void bvh_setup(hipStream_t stream, const BvhBuildArgs& a)
 {
-    const uint32_t n = a.tri_count;
-    if (n == 0) return;
+    const uint32_t n      = a.tri_count;
     const uint32_t blocks = (n + kBlock - 1) / kBlock;
     // bounds = (+inf, +inf, +inf, -inf, -inf, -inf) in the ordered encoding; flags, depth = 0
     const uint32_t init[6] = {0xFF800000u, 0xFF800000u, 0xFF800000u, 0x007FFFFFu, 0x007FFFFFu, 0x007FFFFFu};
@@ -364,6 +371,29 @@ void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
     (void)hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * n, stream);
     (void)hipMemsetAsync(a.max_depth, 0, sizeof(uint32_t), stream);
     hipLaunchKernelGGL(k_tri_setup, dim3(blocks), dim3(kBlock), 0, stream, a);
+}
+
+void launch_bvh_setup(hipStream_t stream, const BvhBuildArgs& a)
+{
+    if (a.tri_count) bvh_setup(stream, a);
+}
+
+void launch_bvh_finish_host(hipStream_t stream, const BvhBuildArgs& a)
+{
+    const uint32_t n = a.tri_count;
+    if (n == 0) return;
+    const uint32_t blocks = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_gather_sorted, dim3(blocks), dim3(kBlock), 0, stream, a);
+    if (n >= 2 && a.nodes4) hipLaunchKernelGGL(k_node4, dim3(blocks), dim3(kBlock), 0, stream, a.nodes, n - 1, a.nodes4);
+}
+
+
+void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
+{
+    const uint32_t n = a.tri_count;
+    if (n == 0) return;
+    const uint32_t blocks = (n + kBlock - 1) / kBlock;
+    bvh_setup(stream, a);
     const uint32_t* sorted_keys = a.keys[0];
     const uint32_t* sorted_vals = a.vals[0];
     if (n >= 2)

@@ -93,6 +93,10 @@ struct BvhBuildArgs
 };
 size_t bvh_radix_blocks(uint32_t n);
 void   launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a);
+// Host-built tree (sah_builder.cpp): setup = triangle records, boxes and scene bounds only; finish = after `nodes` and
+// `leaf_tri` have been uploaded: intersection records into leaf order + the wide view.
+void launch_bvh_setup(hipStream_t stream, const BvhBuildArgs& a);
+void launch_bvh_finish_host(hipStream_t stream, const BvhBuildArgs& a);
 
 // ---- reconstruction chain (post.hip): Gather -> Accumulate -> BlurDisocclusion -> Blur -> Combine -> TAA ----
 struct PostSettingsDev  // SettingsComponent subset, gui_system.h:20-37

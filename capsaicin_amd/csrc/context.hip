@@ -13,7 +13,10 @@
 #include <vector>
 
 #include "../../include/capsaicin_hip.h"
+#include <chrono>
+
 #include "cap_kernels.h"
+#include "sah_builder.h"
 
 using namespace cap;
 
@@ -144,6 +147,7 @@ struct CapContext
     ScreenDev     screen{};
     uint64_t      max_batch_paths = 0;
     uint32_t      traversal_mode  = CAP_TRAVERSAL_AUTO;
+    uint32_t      bvh_build_mode  = CAP_BVH_BUILD_AUTO;
 
     // wavefront state
     DevBuf<float4>     hits, q_org[2], q_dir[2], q_thr[2], s_org, s_dir, s_con, pl_color, pl_direct, pl_albedo, aov_geo, aov_nd,
@@ -633,22 +637,37 @@ int cap_bvh_build(CapContext* c)
     a.tri_raw = c->tri_raw.p, a.tri_box = c->tri_box.p;
     a.keys[0] = c->keys0.p, a.keys[1] = c->keys1.p, a.vals[0] = c->vals0.p, a.vals[1] = c->vals1.p;
     a.hist = c->hist.p, a.parent = c->parent.p, a.flags = c->flags.p, a.bounds = c->bvh_misc.p, a.max_depth = c->bvh_misc.p + 6;
-    hipEvent_t e0 = get_event(c), e1 = get_event(c);
-    HIP_TRY(hipEventRecord(e0, c->stream));
-    launch_bvh_build(c->stream, a);
+    // AUTO: scenes the exhaustive kernels handle need no tree quality; everything else is built once and traced for a long
+    // time (the reference asks the driver for PREFER_FAST_TRACE, blas_system.cpp:42-47), so it gets the host-side SAH build.
+    const bool sah = n >= 2 && (c->bvh_build_mode == CAP_BVH_BUILD_SAH || (c->bvh_build_mode == CAP_BVH_BUILD_AUTO && n > kExhaustiveMax));
+    const auto wall0 = std::chrono::steady_clock::now();
+    uint32_t   host_depth = 0;
+    if (sah)
+    {
+        launch_bvh_setup(c->stream, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<float> boxes(8 * (size_t)n);
+        HIP_TRY(hipMemcpy(boxes.data(), c->tri_box.p, sizeof(float) * boxes.size(), hipMemcpyDeviceToHost));
+        HostTree tree;
+        build_sah_tree(boxes.data(), n, kLeafMax, kLeafCountShift, tree);
+        host_depth = tree.depth;
+        HIP_TRY(hipMemcpy(c->nodes.p, tree.nodes.data(), sizeof(float) * tree.nodes.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->leaf_tri.p, tree.order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+        launch_bvh_finish_host(c->stream, a);
+    }
+    else
+        launch_bvh_build(c->stream, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    c->event_pool.push_back(e0), c->event_pool.push_back(e1);
+    const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     uint32_t misc[8] = {0};
     if (n) HIP_TRY(hipMemcpy(misc, c->bvh_misc.p, sizeof(misc), hipMemcpyDeviceToHost));
     CapBvhInfo& bi    = c->bvh_info;
     bi                = CapBvhInfo{};
     bi.triangle_count = n;
     bi.node_count     = n > 1 ? n - 1 : 0;
-    bi.max_depth      = n ? misc[6] : 0;
+    bi.max_depth      = n ? (sah ? host_depth : misc[6]) : 0;
     bi.build_ms       = ms;
     for (int k = 0; k < 3 && n; ++k)
     {
@@ -771,6 +790,14 @@ int cap_set_batch_paths(CapContext* c, uint64_t max_paths)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_batch_paths: ctx is NULL");
     c->max_batch_paths = max_paths;
+    return CAP_OK;
+}
+
+int cap_set_bvh_build(CapContext* c, uint32_t mode)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_bvh_build: ctx is NULL");
+    if (mode > CAP_BVH_BUILD_SAH) return fail(CAP_ERR_INVALID_ARG, "cap_set_bvh_build: unknown mode %u", mode);
+    c->bvh_build_mode = mode;
     return CAP_OK;
 }
 

@@ -78,11 +78,13 @@ def check_tree(nodes, leaves, tri_lo, tri_hi):
     return max_depth
 
 
+@pytest.mark.parametrize("build", [1, 2])  # on-device LBVH, host-side SAH: same layout, same invariants
 @pytest.mark.parametrize("seed,ntri", [(1, 1), (2, 2), (3, 3), (4, 33), (5, 1000), (6, 20000)])
-def test_lbvh_invariants(native_lib, bluenoise, seed, ntri):
+def test_lbvh_invariants(native_lib, bluenoise, seed, ntri, build):
     pos, nrm, uv, idx, meshes = soup(seed, ntri)
     r = capi.Renderer(0)
     r.upload_scene(pos, nrm, uv, idx, meshes)
+    r.set_bvh_build(build)
     info = r.build_bvh()
     assert info.triangle_count == ntri and info.node_count == max(0, ntri - 1)
     nodes, leaves = r.bvh_readback()
@@ -110,13 +112,15 @@ def test_duplicate_centroids_and_flat_scene(native_lib, bluenoise):
     r.close()
 
 
+@pytest.mark.parametrize("build", [1, 2])
 @pytest.mark.parametrize("seed,ntri,w,h,D", [(11, 1, 48, 48, 2), (12, 2, 48, 48, 2), (13, 300, 96, 96, 3), (14, 5000, 128, 96, 4)])
-def test_triangle_soup_parity(native_lib, bluenoise, seed, ntri, w, h, D):
+def test_triangle_soup_parity(native_lib, bluenoise, seed, ntri, w, h, D, build):
     from oracle import cap_oracle as O
     pos, nrm, uv, idx, meshes = soup(seed, ntri)
     r = capi.Renderer(0)
     r.upload_scene(pos, nrm, uv, idx, meshes)
     r.upload_bluenoise(bluenoise)
+    r.set_bvh_build(build)
     r.build_bvh()
     cam = capi.CameraData()
     cam.position[:] = (0.3, 0.2, 6.0)
