@@ -34,7 +34,7 @@ struct Box
     }
 };
 
-constexpr int kBins = 16;
+constexpr int kBins = 32;
 
 struct Builder
 {
