@@ -50,6 +50,37 @@ def cpu_baseline(budget_s=12.0):
                       (frames, WIDTH, HEIGHT, DEPTH, SPP, cores, el)}
 
 
+def load_sponza_class(r, rank=0):
+    """Generates and uploads the procedural 262 k-triangle textured scene (tools/make_sponza_class.py); returns its camera."""
+    import tempfile
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_sponza_class as gen
+    from capsaicin_amd import capi
+    tmp = tempfile.mkdtemp(prefix="sponza_class_r%d_" % rank)
+    gen.write(tmp, 1.0, 256)
+    geo = capi.Geometry(os.path.join(tmp, "sponza_class.obj"))
+    r.upload_geometry(geo)
+    for i, name in enumerate(geo.texture_names):
+        raw = open(os.path.join(tmp, "textures", name), "rb").read().split(b"\n", 3)
+        tw, th = (int(x) for x in raw[1].split())
+        rgb = np.frombuffer(raw[3], np.uint8).reshape(th, tw, 3)
+        r.upload_texture(i, np.concatenate([rgb, np.full((th, tw, 1), 255, np.uint8)], -1))
+    c = gen.camera()
+    f = np.float64(c["forward"]) / np.linalg.norm(c["forward"])
+    right = -np.cross(f, (0, 1, 0))
+    right /= np.linalg.norm(right)
+    camera = capi.CameraData()
+    camera.position[:] = c["position"]
+    camera.forward[:] = f
+    camera.right[:] = right
+    camera.up[:] = np.cross(f, right)
+    camera.focal_length = c["focal_length"]
+    camera.sensor_size[0] = 0.036
+    camera.sensor_size[1] = np.float32(0.036) * (np.float32(HEIGHT) / np.float32(WIDTH))
+    return camera
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # debugging only; the contract run uses 64
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-tree-variant", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--batch-paths", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--traversal", type=int, default=0, help=argparse.SUPPRESS)  # 0 auto (contract run), 1 stack, 2 exhaustive
     ap.add_argument("--scene", default="cornell", help=argparse.SUPPRESS)  # "sponza": extra line on the procedural 262 k-triangle scene
@@ -94,31 +126,8 @@ def main():
         scene_name = "cornell_box.obj"
         camera = capi.cornell_camera(WIDTH, HEIGHT)
         if args.scene == "sponza":
-            # not the contract workload: BASELINE configs[3] stand-in (tools/make_sponza_class.py), LBVH + LDS-stack kernels
-            import tempfile
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import make_sponza_class as gen
-            tmp = tempfile.mkdtemp(prefix="sponza_class_r%d_" % rank)
-            gen.write(tmp, 1.0, 256)
-            geo = capi.Geometry(os.path.join(tmp, "sponza_class.obj"))
-            r.upload_geometry(geo)
-            for i, name in enumerate(geo.texture_names):
-                raw = open(os.path.join(tmp, "textures", name), "rb").read().split(b"\n", 3)
-                tw, th = (int(x) for x in raw[1].split())
-                rgb = np.frombuffer(raw[3], np.uint8).reshape(th, tw, 3)
-                r.upload_texture(i, np.concatenate([rgb, np.full((th, tw, 1), 255, np.uint8)], -1))
-            c = gen.camera()
-            f = np.float64(c["forward"]) / np.linalg.norm(c["forward"])
-            right = -np.cross(f, (0, 1, 0))
-            right /= np.linalg.norm(right)
-            camera = capi.CameraData()
-            camera.position[:] = c["position"]
-            camera.forward[:] = f
-            camera.right[:] = right
-            camera.up[:] = np.cross(f, right)
-            camera.focal_length = c["focal_length"]
-            camera.sensor_size[0] = 0.036
-            camera.sensor_size[1] = np.float32(0.036) * (np.float32(HEIGHT) / np.float32(WIDTH))
+            # not the contract workload: BASELINE configs[3] stand-in (tools/make_sponza_class.py), tree traversal kernels
+            camera = load_sponza_class(r, rank)
             scene_name = "sponza_class.obj (procedural, textured)"
         else:
             r.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
@@ -280,6 +289,35 @@ def main():
                            "rays_per_step": {"primary": es.rays_primary / args.steps, "extension": es.rays_extension / args.steps,
                                              "shadow": es.rays_shadow / args.steps}}
 
+        # the general path (tree traversal, textures) on the BASELINE configs[3] stand-in, 16 spp: extra line, N = 1 only
+        tree_variant = None
+        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant:
+            try:
+                r2 = capi.Renderer(device_index, stream.cuda_stream)
+                cam2 = load_sponza_class(r2)
+                r2.upload_bluenoise(capi.load_bluenoise())
+                bi2 = r2.build_bvh()
+                r2.set_resolution(WIDTH, HEIGHT)
+                r2.set_camera(cam2)
+                r2.render(0, 16, DEPTH, 0)
+                r2.sync()
+                r2.stats_reset()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    r2.accum_reset()
+                    r2.render(0, 16, DEPTH, 0)
+                r2.sync()
+                tdt = time.perf_counter() - t0
+                ts = r2.stats()
+                trays = ts.rays_primary + ts.rays_extension + ts.rays_shadow
+                tree_variant = {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d 16spp depth=%d, reference shading" %
+                                            (bi2.triangle_count, WIDTH, HEIGHT, DEPTH),
+                                "value": trays / tdt / 1e6, "unit": "Mrays/s", "ms_per_step": tdt / 2 * 1e3,
+                                "bvh": {"build": "host SAH", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)}}
+                r2.close()
+            except Exception as exc:  # the extra line must never cost the contract line
+                tree_variant = {"error": str(exc)}
+
         if rank == 0:
             # sanity of the product of the timed region: finite image, every pixel accumulated spp frames
             img = image.cpu().numpy().reshape(HEIGHT, WIDTH, 4)
@@ -292,7 +330,7 @@ def main():
                               "triangles": int(bvh.triangle_count), "bvh_depth": int(bvh.max_depth),
                               "rays_per_step": {"primary": rays_p / args.steps, "extension": rays_e / args.steps, "shadow": rays_s / args.steps},
                               "parallelism": "tiles%d" % world},
-                   "roofline": roofline, "ext_variant": ext_variant}
+                   "roofline": roofline, "ext_variant": ext_variant, "tree_variant": tree_variant}
             out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()  # rank 0, N = 1 only
             print(json.dumps(out), flush=True)
         r.close()

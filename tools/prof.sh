@@ -4,7 +4,7 @@
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
-ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_EXTRA}"
+ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tree-variant ${BENCH_EXTRA}"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python3 $ARGS > $OUT/prof_kt.log 2>&1 || exit 1
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
