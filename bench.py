@@ -45,9 +45,19 @@ def cpu_baseline(budget_s=12.0):
         el = time.time() - t0
         if el > budget_s or frames >= 16:
             break
+    # the same tracer on ONE host thread, one frame at half the resolution per axis
+    w1, h1 = WIDTH // 2, HEIGHT // 2
+    cam1 = capi.cornell_camera(w1, h1)
+    ocam1 = O.make_camera(tuple(cam1.position), tuple(cam1.forward), tuple(cam1.right), tuple(cam1.up), cam1.sensor_size[0],
+                          cam1.sensor_size[1], cam1.focal_length)
+    t1 = time.time()
+    r1 = sc.render_frame(ocam1, bn, w1, h1, 0, DEPTH, flags=O.FLAG_USE_BVH, threads=1)
+    el1 = time.time() - t1
     return {"value": rays / el / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d frame(s) of %dx%d depth %d (of the %d spp workload), oracle BVH mode, %d threads, %.1f s" %
-                      (frames, WIDTH, HEIGHT, DEPTH, SPP, cores, el)}
+                      (frames, WIDTH, HEIGHT, DEPTH, SPP, cores, el),
+            "single_thread": {"value": sum(r1["rays"]) / el1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                              "sample": "1 frame of %dx%d depth %d, %.1f s" % (w1, h1, DEPTH, el1)}}
 
 
 def load_sponza_class(r, rank=0):
