@@ -54,7 +54,9 @@ struct Builder
     {
         const uint32_t node = next_node++;
         max_depth           = std::max(max_depth, depth);
-        const uint32_t mid  = split(b, e);
+        // very unbalanced SAH splits (one triangle against the rest, over and over) would make the tree deeper than the
+        // traversal stacks allow: from depth 36 on the split is the median, which bounds the depth by 36 + log2(range)
+        const uint32_t mid  = split(b, e, depth < 36);
         Box            cb[2];
         uint32_t       child[2], tchild[2];
         const uint32_t rb[2] = {b, mid}, re[2] = {mid, e};
@@ -81,7 +83,7 @@ struct Builder
     }
 
     // partitions order[b, e) and returns the split position (b < mid < e)
-    uint32_t split(uint32_t b, uint32_t e)
+    uint32_t split(uint32_t b, uint32_t e, bool use_sah)
     {
         const uint32_t n = e - b;
         Box            cbox;
@@ -89,7 +91,7 @@ struct Builder
         for (uint32_t i = b; i < e; ++i) cbox.grow(&centroid[3 * (size_t)order[i]]);
         int   best_axis = -1, best_bin = 0;
         float best_cost = INFINITY;
-        if (n > 4)
+        if (n > 4 && use_sah)
         {
             for (int axis = 0; axis < 3; ++axis)
             {

@@ -214,6 +214,55 @@ def test_fan_pairs_parity(native_lib, bluenoise, seed, nquads, nsingles, fold):
     r.close()
 
 
+@pytest.mark.parametrize("build", [1, 2])
+def test_geometric_progression_scene(native_lib, bluenoise, build):
+    """Triangles whose size and distance grow geometrically: the SAH build wants to peel them off one by one (a tree as deep as
+    the triangle count) and Morton codes collapse most of them into one cell.  Both builders must stay within the traversal
+    stack and give the oracle's image."""
+    from oracle import cap_oracle as O
+    n = 120
+    tris = []
+    for k in range(n):
+        s = 1.08 ** k
+        x = 0.02 * s
+        tris.append([[x, -0.01 * s, -0.002 * s], [x + 0.01 * s, 0.0, -0.002 * s], [x, 0.01 * s, -0.002 * s]])
+    tris = np.float32(tris)
+    pos = tris.reshape(-1, 3)
+    nrm = np.tile(np.float32([0, 0, 1]), (len(pos), 1))
+    uv = np.zeros((len(pos), 2), np.float32)
+    idx = np.arange(len(pos), dtype=np.uint32)
+    meshes = np.uint32([[len(pos), 0, len(pos), 0, 0, 0xFFFFFFFF, 0, 0]])
+    r = capi.Renderer(0)
+    r.upload_scene(pos, nrm, uv, idx, meshes)
+    r.upload_bluenoise(bluenoise)
+    r.set_bvh_build(build)
+    info = r.build_bvh()
+    assert info.max_depth <= 64 and info.stack_entries >= min(info.max_depth, 32)
+    nodes, leaves = r.bvh_readback()
+    t3 = pos.reshape(-1, 3, 3)
+    assert check_tree(nodes, leaves, t3.min(1), t3.max(1)) == info.max_depth
+    w, h = 64, 48
+    cam = capi.CameraData()
+    cam.position[:] = (40.0, 0.0, 120.0)
+    cam.forward[:] = (0, 0, -1)
+    cam.right[:] = (-1, 0, 0)
+    cam.up[:] = (0, 1, 0)
+    cam.focal_length = 0.02
+    cam.sensor_size[0] = 0.036
+    cam.sensor_size[1] = np.float32(0.036) * (np.float32(h) / np.float32(w))
+    r.set_resolution(w, h)
+    r.set_camera(cam)
+    r.set_traversal(1)
+    r.render(1, 1, 2, capi.RENDER_AOV)
+    sc = O.Scene(pos, nrm, uv, idx, meshes)
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1], cam.focal_length)
+    ref = sc.render_frame(ocam, bluenoise, w, h, 1, 2, threads=4)
+    assert (ref["gbuffer_geo"].view(np.uint32)[..., 3] != 0xFFFFFFFF).any()
+    for name, kind in (("gbuffer_geo", capi.BUF_GBUFFER_GEO), ("indirect", capi.BUF_INDIRECT), ("direct", capi.BUF_DIRECT)):
+        assert_same(r.readback(kind), ref[name], name)
+    r.close()
+
+
 def test_empty_scene_and_call_order(native_lib, bluenoise):
     r = capi.Renderer(0)
     with pytest.raises(capi.CapError):
