@@ -112,6 +112,7 @@ SYMBOLS = {
     "cap_geometry_warning": (C.c_char_p, [_vp]),
     "cap_geometry_materials": (_i, [_vp, _vp]),
     "cap_scene_upload_geometry": (_i, [_vp, _vp]),
+    "cap_host_sah_build": (_i, [_vp, _u32, _vp, _vp, C.POINTER(_u32)]),
 }
 
 _LIB = None
@@ -208,6 +209,19 @@ class Geometry:
         if getattr(self, "h", None):
             lib().cap_geometry_free(self.h)
             self.h = None
+
+
+def host_sah_build(tri_lo, tri_hi):
+    """The host-side SAH tree over triangle boxes (no GPU): (nodes [n-1, 16] float32, order [n] uint32, depth)."""
+    lo, hi = np.asarray(tri_lo, np.float32), np.asarray(tri_hi, np.float32)
+    n = len(lo)
+    boxes = np.zeros((n, 8), np.float32)
+    boxes[:, 0:3], boxes[:, 4:7] = lo, hi
+    nodes = np.zeros((max(n - 1, 1), 16), np.float32)
+    order = np.zeros(n, np.uint32)
+    depth = C.c_uint32()
+    _check(lib().cap_host_sah_build(_p(boxes), n, _p(nodes), _p(order), C.byref(depth)), "cap_host_sah_build")
+    return nodes[:max(n - 1, 0)], order, int(depth.value)
 
 
 class Renderer:

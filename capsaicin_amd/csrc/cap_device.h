@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "cap_leaf.h"
 #include "cap_math.h"
 
 namespace cap
@@ -22,15 +23,8 @@ constexpr uint32_t kBlock      = 256;  // threads per workgroup (4 waves, one pe
 constexpr uint32_t kQueueClasses  = 64;
 constexpr uint32_t kCounterStride = 32;  // uint32 words between two class counters (128 B)
 constexpr uint32_t kExhaustiveMax = 64;  // scenes up to this many triangles are traced exhaustively (kernels.hip)
-// LBVH traversal leaves hold up to kLeafMax consecutive sorted triangles, coded ~(first | (count - 1) << kLeafCountShift)
-#ifndef CAP_LEAF_MAX
-#define CAP_LEAF_MAX 2  // 262 k-triangle scene, ms per step: 1: 31.0, 2: 28.6, 3: 29.2, 4: 30.4, 8: 34.7
-#endif
-constexpr int      kLeafMax        = CAP_LEAF_MAX;  // <= 8 (3 bits)
 constexpr int      kNoChild        = 0x7fffffff;  // unused slot of a wide node
 constexpr uint32_t kSpillEntries   = 16;  // per-thread traversal-stack entries kept in global memory behind the 32 in LDS
-constexpr uint32_t kLeafCountShift = 27;
-constexpr uint32_t kLeafFirstMask  = (1u << kLeafCountShift) - 1u;  // < 134 M triangles
 
 // BVH node, 64 B = 4 x float4 (both children's boxes live in the parent, one fetch tests both):
 //   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)

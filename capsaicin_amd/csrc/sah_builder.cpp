@@ -4,6 +4,9 @@
 // the device refit pads it (bvh.hip k_refit).
 #include "sah_builder.h"
 
+#include "../../include/capsaicin_scene.h"
+#include "cap_leaf.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -184,3 +187,14 @@ void build_sah_tree(const float* tri_box, uint32_t n, int leaf_max, uint32_t cou
     out.depth = b.max_depth;
 }
 }  // namespace cap
+
+extern "C" int cap_host_sah_build(const float* tri_boxes, uint32_t n, float* nodes, uint32_t* order, uint32_t* depth)
+{
+    if ((!tri_boxes && n) || !order || (n > 1 && !nodes)) return CAP_ERR_INVALID_ARG;
+    cap::HostTree t;
+    cap::build_sah_tree(tri_boxes, n, cap::kLeafMax, cap::kLeafCountShift, t);
+    for (uint32_t i = 0; i < n; ++i) order[i] = t.order[i];
+    if (n > 1) std::memcpy(nodes, t.nodes.data(), sizeof(float) * 16 * (size_t)(n - 1));
+    if (depth) *depth = t.depth;
+    return CAP_OK;
+}

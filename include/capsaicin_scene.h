@@ -48,6 +48,12 @@ int cap_geometry_materials(const CapGeometry* g, CapMaterial* out_materials);
 /* Convenience: cap_scene_upload(ctx, view...) */
 int cap_scene_upload_geometry(CapContext* ctx, const CapGeometry* g);
 
+/* Host-side tree build used by cap_bvh_build in SAH mode, callable without a GPU (tools, tests): triangle boxes in, the
+ * device node layout out.  tri_boxes: n x 8 floats (lo.xyz, -, hi.xyz, -); nodes: 16 floats per internal node, n - 1 of
+ * them (box of child 0, box of child 1, child0, child1, traversal child0, traversal child1 as int bits; a child < 0 is
+ * ~leaf position); order: n triangle ids in leaf order; depth: internal nodes on the longest root-to-leaf path. */
+int cap_host_sah_build(const float* tri_boxes, uint32_t n, float* nodes, uint32_t* order, uint32_t* depth);
+
 #ifdef __cplusplus
 }
 #endif
