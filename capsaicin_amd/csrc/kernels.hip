@@ -411,10 +411,9 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
 // lists' winners are merged by the explicit (t, id) order.  With best_t starting at tmax, t < best_t implies t < tmax.  Only t
 // and the id are tracked in the loops; the barycentrics of the winner are recomputed once afterwards (identical operations,
 // identical bits) instead of being multiplied out and selected for every triangle.
-// One candidate per triangle: its t, or +inf when the ray misses it.  A wave issues dependent VALU instructions at half the
-// rate of independent ones on this machine (tools/micro/valu_peak.hip: 4.7 vs 2.6 cycles per wave64 fma per SIMD, whatever the
-// number of resident waves), so four triangles are tested side by side and reduced by a tree; "(t, id) lexicographic minimum"
-// is associative, so the tree gives the winner of the sequential rule.
+// One candidate per triangle: its t, or +inf when the ray misses it.  Four triangles are tested side by side and reduced by
+// a tree instead of a sequential compare chain (measured faster: more independent instructions for the scheduler to
+// interleave); "(t, id) lexicographic minimum" is associative, so the tree gives the winner of the sequential rule.
 // rec_tab: where the winner's record is re-read from (bvh.tris_by_id, or its LDS copy).
 __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const float4* rec_tab, const Ray& r, float& best_t, float& best_u,
                                                    float& best_v, uint32_t& best_gid)
