@@ -646,20 +646,26 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q,
             lds_light[k] = make_float4(frames[k].light_dir[0], frames[k].light_dir[1], frames[k].light_dir[2], 0.f);
         __syncthreads();
     }
-    const uint32_t      slots    = (q.class_capacity >> 6) * kQueueClasses;
-    const uint32_t      my_class = wave_global_id() % kQueueClasses;
-    uint32_t            grab     = grab_issue(work, my_class);
+    // Memory round trips a chunk starts with, in order: (1) the grab issued one chunk ago (its wait also covers the previous
+    // chunk's plane updates: vmcnt retires in order), (2) the queue entry.  The class's length is read once per wave (constant
+    // during the launch), and the next grab is issued AFTER the entry loads, so that the wait for the entry is a counted
+    // vmcnt(1) that leaves the grab in flight instead of a third round trip.
+    const uint32_t my_class = wave_global_id() % kQueueClasses;
+    const uint32_t lane     = threadIdx.x & 63u;
+    uint32_t       n_class  = q.count[my_class * kCounterStride];
+    n_class                 = n_class < q.class_capacity ? n_class : q.class_capacity;
+    uint32_t       grab     = grab_issue(work, my_class);
     while (true)
     {
-        const uint32_t cs = grab_value(grab) * kQueueClasses + my_class;
-        if (cs >= slots) break;
+        const uint32_t local0 = grab_value(grab) * 64u;
+        if (local0 >= n_class) break;  // past the end of this class's sub-queue
+        const bool     active = local0 + lane < n_class;
+        const uint32_t i      = my_class * q.class_capacity + local0 + lane;
+        float4         a      = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) a = q.org_tmin[i];
         grab = grab_issue(work, my_class);
-        uint32_t   i, klass;
-        const bool active = queue_chunk(q.count, q.class_capacity, cs, threadIdx.x & 63u, i, klass);
-        if (__ballot(active) == 0ull) break;  // past the end of this class's sub-queue
         if (active)
         {
-            const float4 a = q.org_tmin[i];
             float4       c = make_float4(0.f, 0.f, 0.f, 0.f), cur = c;
             uint32_t     pid = 0;
             size_t       idx = 0;
@@ -1778,31 +1784,35 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
     const float4* rec_tab   = LDS ? lds_rec : bvh.tris_by_id;
     Stamps st;
     st.start();
-#ifndef CAP_FUSED_STATIC
-    // chunk slots from the class's work counter, like the any-hit kernel (with the priorities below: bounce 0 4.6 -> 4.1 ms,
-    // bounce >= 1 unchanged; before them it cost the bounce >= 1 kernel 7 %)
+    // Chunk slots from the class's work counter, like the any-hit kernel (with the priorities below: bounce 0 4.6 -> 4.1 ms,
+    // bounce >= 1 unchanged; before them it cost the bounce >= 1 kernel 7 %).  As there, the class's length is read once and
+    // the next grab is issued after the entry loads (see k_trace_any).
     const uint32_t my_class = wave_global_id() % kQueueClasses;
-    uint32_t       grab     = grab_issue(a.work, my_class);
+    const uint32_t lane     = threadIdx.x & 63u;
+    uint32_t       n_class  = 0;
+    if (!FIRST)
+    {
+        n_class = a.in.count[my_class * kCounterStride];
+        n_class = n_class < a.in.class_capacity ? n_class : a.in.class_capacity;
+    }
+    uint32_t grab = grab_issue(a.work, my_class);
     while (true)
     {
-        const uint32_t chunk = grab_value(grab) * kQueueClasses + my_class;  // slot j of this class
-        if (chunk >= chunks) break;
-        grab = grab_issue(a.work, my_class);
-#else
-    for (uint32_t chunk = wave_global_id(); chunk < chunks; chunk += wave_total())
-    {
-#endif
-        uint32_t i, klass, pid = 0, slot = 0;
-        bool     active;
-        v3       thr = mk3(1.0f, 1.0f, 1.0f);
-        Ray      r   = make_ray(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 1.f), 0.0f, 0.0f);  // empty interval: hits nothing
-        float    carried_r1 = 0.f, carried_r2 = 0.f;
+        const uint32_t j = grab_value(grab);  // slot j of this class
+        uint32_t       i, pid = 0, slot = 0;
+        const uint32_t klass = my_class;      // the path's class for its whole life
+        bool           active;
+        v3             thr = mk3(1.0f, 1.0f, 1.0f);
+        Ray            r   = make_ray(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 1.f), 0.0f, 0.0f);  // empty interval: hits nothing
+        float          carried_r1 = 0.f, carried_r2 = 0.f;
         if (FIRST)
         {
+            const uint32_t chunk = j * kQueueClasses + my_class;
+            if (chunk >= chunks) break;
+            grab   = grab_issue(a.work, my_class);
             slot   = chunk / cps;  // wave-uniform
-            i      = (chunk - slot * cps) * 64 + (threadIdx.x & 63u);
+            i      = (chunk - slot * cps) * 64 + lane;
             active = true;
-            klass  = chunk % kQueueClasses;  // the path's class for its whole life
             pid    = (slot << kPidShift) | i;
             uint32_t x, y;
             if (local_pixel_to_xy(a.screen, i, x, y))
@@ -1811,12 +1821,15 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
         }
         else
         {
-            active = queue_chunk(a.in.count, a.in.class_capacity, chunk, threadIdx.x & 63u, i, klass);
-            if (__ballot(active) == 0ull) break;  // past the end of this class's sub-queue: every later slot is empty too
+            if (j * 64u >= n_class) break;  // past the end of this class's sub-queue
+            active = j * 64u + lane < n_class;
+            i      = my_class * a.in.class_capacity + j * 64u + lane;
+            // extension rays: tmin / tmax are constants (rt_indirect.hlsl:154-157); with CARRY the .w slots hold the sample
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f), d = make_float4(0.f, 0.f, 1.f, 0.f), tp = make_float4(1.f, 1.f, 1.f, 0.f);
+            if (active) o = a.in.org_tmin[i], d = a.in.dir_tmax[i], tp = a.in.thr_pid[i];
+            grab = grab_issue(a.work, my_class);
             if (active)
             {
-                // extension rays: tmin / tmax are constants (rt_indirect.hlsl:154-157); with CARRY the .w slots hold the sample
-                const float4 o = a.in.org_tmin[i], d = a.in.dir_tmax[i], tp = a.in.thr_pid[i];
                 r   = make_ray(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), kRayEps, kRayFar);
                 thr = mk3(tp.x, tp.y, tp.z), pid = f2u(tp.w);
                 carried_r1 = o.w, carried_r2 = d.w;

@@ -31,3 +31,8 @@ print("end    percentiles 0/1/10/50/90/100: %s" % np.percentile(end, [0, 1, 10, 
 print("life   percentiles 0/10/50/90/100: %s  mean %.1f" % (np.percentile(end - start, [0, 10, 50, 90, 100]).round(1), (end - start).mean()))
 blk = (end - start).reshape(-1, 4).mean(1)
 print("per-workgroup mean life: first 8 %s ... last 8 %s" % (blk[:8].round(1), blk[-8:].round(1)))
+# per class (wave index mod 64): when its last wave left -- the spread is what work stealing between classes could recover
+n = (len(t) // 64) * 64
+cls_end = end[:n].reshape(-1, 64).max(0)
+print("per-class last exit: min %.1f  median %.1f  max %.1f us; mean wave life / span = %.3f" % (
+    cls_end.min(), np.median(cls_end), cls_end.max(), (end - start).mean() / end.max()))
