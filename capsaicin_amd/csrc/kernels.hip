@@ -624,12 +624,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(BvhDev bvh, RayQueue q
     }
 }
 
-// RMW: how an unoccluded ray adds its contribution to the plane.  false: three no-return float atomics (nothing is read, the
-// right choice when most rays are occluded, as under the reference's directional light inside the box).  true: the path's
-// float4 is loaded up front with the ray and stored back after the test -- one 16-B load and one 16-B store instead of three
-// L2 atomic operations per ray; with next-event estimation ~90 % of the shadow rays are unoccluded and the atomics' L2 rate
-// (about 15 per clock chip-wide, measured 31 ms per step) was the kernel's bound.  Either way the path is the word's only
-// writer within a launch, and launches are ordered on the stream, so the sums are the same IEEE additions in the same order.
+// An unoccluded ray adds its contribution to its path's plane entry by load-add-store: the path is the entry's only writer
+// within a launch and launches are ordered on the stream, so the sums are the same IEEE additions in the same order whichever
+// way they are carried out.  RMW says WHEN the entry is loaded.  true: up front with the ray (next-event rays of the EXT model,
+// ~90 % unoccluded: the load's latency hides behind the test; three float atomics per ray instead made the L2 atomic rate the
+// kernel's bound, 31 -> 10.8 ms per step).  false: after the test, by the few lanes that need it (the reference's directional
+// light inside the box: ~5 % unoccluded; an up-front load costs 7.05 -> 7.98 ms, float atomics 6.6 ms, this 5.8 ms).
 // Entry formats.  RMW (EXT model, next-event rays): (origin, tmin) (direction, tmax) (contribution, path id), 48 B.
 // !RMW (reference model): (origin, path id) (contribution, -), 32 B; direction = the light of the path's frame (LDS copy of the
 // batch's frame constants), tmin / tmax = kRayEps / kRayFar (lighting.h:39-47).
@@ -709,11 +709,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q,
                         target[idx] = make_float4(cur.x + c.x, cur.y + c.y, cur.z + c.z, cur.w);
                     else
                     {
-                        c         = q.contrib_pid[i];
-                        float* tv = reinterpret_cast<float*>(target + idx);
-                        atomicAdd(tv + 0, c.x);
-                        atomicAdd(tv + 1, c.y);
-                        atomicAdd(tv + 2, c.z);
+                        c           = q.contrib_pid[i];
+                        cur         = target[idx];
+                        target[idx] = make_float4(cur.x + c.x, cur.y + c.y, cur.z + c.z, cur.w);
                     }
                 }
             }
@@ -1347,6 +1345,7 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
                 // rt_indirect.hlsl:94-99  color += throughput * sky.  Exactly one lane in the whole grid owns this path, so the
                 // three no-return float atomics are plain IEEE adds in program order; unlike a load-add-store they do not make
                 // the wave wait for the old value.
+                // (A load-add-store here instead, as in k_trace_any: 16.4 -> 16.6 ms.)
                 float* c = reinterpret_cast<float*>(a.planes.color + plane_idx);
                 atomicAdd(c + 0, thr.x * 0.7f);
                 atomicAdd(c + 1, thr.y * 0.7f);

@@ -114,6 +114,9 @@ def test_sharded_render_equals_unsharded(cornell, bluenoise):
             floats = r.tile_buffer_floats()
             assert floats == tiles.padded_pixels(w, h, count) * 4
             t = torch.zeros(floats, dtype=torch.float32, device="cuda")
+            # the renderer of this fixture runs on its own (non-blocking) stream: torch's fill must have landed before the
+            # renderer writes the buffer (bench.py instead creates the renderer ON torch's stream)
+            torch.cuda.synchronize()
             r.resolve_tiles(t.data_ptr())
             r.sync()
             bufs.append(t)
@@ -125,6 +128,7 @@ def test_sharded_render_equals_unsharded(cornell, bluenoise):
             assert np.all(dev[~valid][:, :3] == 0)  # padding lanes of partial / absent tiles carry no radiance
         gathered = torch.cat(bufs)
         image = torch.zeros(h * w * 4, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         r.assemble_tiles(gathered.data_ptr(), count, image.data_ptr())
         r.sync()
         torch.cuda.synchronize()
