@@ -24,7 +24,11 @@ constexpr uint32_t kQueueClasses  = 64;
 constexpr uint32_t kCounterStride = 32;  // uint32 words between two class counters (128 B)
 constexpr uint32_t kExhaustiveMax = 64;  // scenes up to this many triangles are traced exhaustively (kernels.hip)
 constexpr int      kNoChild        = 0x7fffffff;  // unused slot of a wide node
-constexpr uint32_t kSpillEntries   = 16;  // per-thread traversal-stack entries kept in global memory behind the 32 in LDS
+#ifndef CAP_WIDE_LDS
+#define CAP_WIDE_LDS 24  // LDS entries of the wide closest-hit kernel's per-lane stack (24 KB per workgroup: six workgroups per CU)
+#endif
+constexpr uint32_t kWideLdsEntries = CAP_WIDE_LDS;
+constexpr uint32_t kSpillEntries   = 48 - CAP_WIDE_LDS;  // per-thread stack entries kept in global memory behind the LDS part
 
 // BVH node, 64 B = 4 x float4 (both children's boxes live in the parent, one fetch tests both):
 //   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)

@@ -10,13 +10,16 @@ struct LaunchCfg
     hipStream_t stream;
     uint32_t    grid_blocks;    // persistent grid size for queue kernels
     uint32_t    stack_entries;  // 32 or 64 (per-lane LDS traversal stack)
+    uint32_t    cu_count = 0;   // compute units (0: unknown) -- persistent kernels with a static chunk assignment clamp their grid
+                                // to what is resident at once, see resident_grid() in kernels.hip
 };
 
 // ---- trace ----
 // Primary visibility (rt_primary_visibility.hlsl:35-49): generates camera rays for frame slots [0, n_slots) of
 // the batch and writes hit records (u, v, asfloat(global triangle id | ~0u), t) at index slot * Ppad + pl.
+// work: kQueueClasses zeroed chunk-grab counters (kCounterStride apart) for the persistent wide-tree variant, or NULL
 void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraDev& cam, const ScreenDev& screen,
-                          const FrameConst* frames, uint32_t n_slots, float4* hits);
+                          const FrameConst* frames, uint32_t n_slots, float4* hits, uint32_t* work);
 // Closest hit for the extension-ray queue (rt_indirect.hlsl:173).
 void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits);
 // Any hit for the shadow-ray queue (lighting.h:48-61); unoccluded rays add contrib to target[plane index].

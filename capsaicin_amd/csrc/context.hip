@@ -327,7 +327,7 @@ BvhDev bvh_dev(const CapContext* c)
     b.stack_spill   = c->stack_spill.p;
     b.spill_threads = (uint32_t)(c->stack_spill.n / kSpillEntries);
     static const bool binary_only = getenv("CAP_BVH_BINARY") != nullptr;  // A/B switch: binary traversal kernels only
-    b.wide_ok = !binary_only && c->stack_spill.p && c->tri_count >= 2 && 3u * ((c->bvh_info.max_depth + 1u) / 2u) <= 32u + kSpillEntries;
+    b.wide_ok = !binary_only && c->stack_spill.p && c->tri_count >= 2 && 3u * ((c->bvh_info.max_depth + 1u) / 2u) <= kWideLdsEntries + kSpillEntries;
     b.fan_pairs = c->fan_pairs.p, b.fan_singles = c->fan_singles.p;
     b.fan_pair_count = c->fan_pair_count, b.fan_single_count = c->fan_single_count;
     b.tri_count = c->tri_count;
@@ -894,7 +894,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     // (launch bounds in kernels.hip), not the 8 a register-light kernel could reach.
     uint32_t blocks_per_cu = stack_entries == 0 ? 6u : (stack_entries <= 32 ? 5u : 2u);  // measured: 4..8 within 4 %, 6 best
     if (const char* e = getenv("CAP_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)std::max(1, atoi(e));
-    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * blocks_per_cu, stack_entries};
+    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * blocks_per_cu, stack_entries, (uint32_t)c->cu_count};
     const BvhDev    bvh   = bvh_dev(c);
     const SceneDev  scene = scene_dev(c);
     const CameraDev cam   = camera_dev(c->camera);
@@ -941,7 +941,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         {
             {
                 StageTimer t(c, ST_PRIMARY, st);
-                launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, c->hits.p);
+                launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, c->hits.p, work_shade /* bounce 0's slot: unused by k_shade */);
             }
             if (aov_slot != ~0u) launch_geo_aov(cfg, scene, c->hits.p + (size_t)aov_slot * Ppad, Ppad, c->aov_geo.p);
         }

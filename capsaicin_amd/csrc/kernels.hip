@@ -575,11 +575,17 @@ __device__ __forceinline__ v3 primary_dir(const CameraDev& cam, const ScreenDev&
     return normalize3(d);
 }
 
+// Workgroups per CU the stack kernels are register-allocated for: what their LDS stacks allow.  A workgroup's stack is
+// entries x 256 lanes x 4 B; of 32-KB stacks four fit into the CU's 160 KB beside the runtime's own share, of 24-KB ones six.
+// (0 = no hint: the small-scene kernels keep the compiler's default allocation; a hint of 8 squeezed k_trace_any<0> from 44 to
+// 35 VGPRs and cost 9 %.)
+constexpr int stack_residency(int stack_entries) { return stack_entries == 0 ? 0 : (stack_entries <= 24 ? 6 : (stack_entries <= 32 ? 4 : 2)); }
+
 // One workgroup per four 64-pixel groups of a frame slot (blockIdx.y): camera rays are coherent but their cost varies strongly
 // over the image, and a persistent grid with static slots left long tails here (4.1 -> 5.4 ms on the 262 k-triangle scene).
 // The grid is therefore far larger than the wide traversal's spill area: binary traversal (wide_ok cleared by the launcher).
 template <int STACK>
-__global__ __launch_bounds__(kBlock) void k_trace_primary(BvhDev bvh, CameraDev cam, ScreenDev screen, const FrameConst* frames,
+__global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_primary(BvhDev bvh, CameraDev cam, ScreenDev screen, const FrameConst* frames,
                                                           float4* hits)
 {
     __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
@@ -603,8 +609,104 @@ __global__ __launch_bounds__(kBlock) void k_trace_primary(BvhDev bvh, CameraDev 
     }
 }
 
+// Packet traversal for camera rays.  The 64 rays of a chunk are the 8x8 pixels of one screen tile: they share an origin and
+// nearly a direction, so the wave walks ONE node sequence with ONE stack (wave-uniform, in LDS) and fetches nodes and triangle
+// records through the scalar cache; a child is entered when any lane's ray hits its box (each lane prunes with its own
+// closest hit so far), nearer child first by majority.  Per-lane traversal is bound by the texture-address unit here -- seven
+// 16-B loads per lane and step, 64 lanes, all to the same address: ~112 TA cycles per step and wave -- while this form issues no
+// vector loads at all (262 k-triangle scene: 3.7 -> 2.4 ms; it is then bound by the latency of the dependent scalar fetches,
+// hence eight workgroups per CU.  The same walk on the wide view of the tree, four boxes per step ordered by the packet's
+// first live lane, was slower: 3.2 ms, the scalar sorting costs more than the halved fetch chain saves).
+// The hit rule is visit-order independent (minimum t, ties to the lower id), so the result is bit-identical.
+// wstack: this wave's kPacketStack entries (the tree depth is checked on the host against the same 64).
+constexpr uint32_t kPacketStack = 64;
+__device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const Ray& r, bool alive, uint32_t* wstack, float& best_t,
+                                                        float& best_u, float& best_v, uint32_t& best_gid)
+{
+    best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
+    int      node = bvh.root;
+    uint32_t sp   = 0;
+    while (true)
+    {
+        node = __builtin_amdgcn_readfirstlane(node);
+        bool pop = true;
+        if (node >= 0)
+        {
+            float4 q0, q1, q2, q3;
+            load_const_tri(bvh.nodes, (uint32_t)node, q0, q1, q2, q3);
+            float      tn0, tn1;
+            const bool h0 = alive && slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tn0);
+            const bool h1 = alive && slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tn1);
+            const int  c0 = (int)f2u(q3.z), c1 = (int)f2u(q3.w);
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+            if (m0 != 0ull && m1 != 0ull)
+            {
+                // lanes that hit both vote for the nearer child, the others for the one they hit
+                const unsigned long long first1 = __ballot(h1 && (!h0 || tn1 < tn0));
+                const bool               swap   = 2 * __popcll(first1) > __popcll(m0 | m1);
+                if (sp < kPacketStack) wstack[sp++] = (uint32_t)(swap ? c0 : c1);
+                node = swap ? c1 : c0;
+                pop  = false;
+            }
+            else if ((m0 | m1) != 0ull)
+            {
+                node = m0 ? c0 : c1;
+                pop  = false;
+            }
+        }
+        else
+        {
+            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
+            for (uint32_t leaf = first; leaf <= last; ++leaf)
+            {
+                float4 t0, t1, t2, t3;
+                load_const_tri(bvh.tris, leaf, t0, t1, t2, t3);
+                float t, u, v;
+                if (alive && tri_test(r, t0, t1, t2, t, u, v))
+                {
+                    const uint32_t gid = f2u(t3.x);
+                    if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+                }
+            }
+        }
+        if (pop)
+        {
+            if (sp == 0) break;
+            node = (int)wstack[--sp];
+        }
+    }
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(kBlock, 8) void k_trace_primary_packet(BvhDev bvh, CameraDev cam, ScreenDev screen, const FrameConst* frames,
+                                                                    uint32_t n_slots, float4* hits, uint32_t* work)
+{
+    __shared__ uint32_t lds_wstack[(kBlock / 64) * kPacketStack];
+    uint32_t*           wstack   = lds_wstack + (threadIdx.x >> 6) * kPacketStack;
+    const uint32_t      cps      = screen.pixels_padded >> 6;
+    const uint32_t      chunks   = cps * n_slots;
+    const uint32_t      my_class = wave_global_id() % kQueueClasses;
+    uint32_t            grab     = grab_issue(work, my_class);
+    while (true)
+    {
+        const uint32_t chunk = grab_value(grab) * kQueueClasses + my_class;
+        if (chunk >= chunks) break;
+        grab = grab_issue(work, my_class);
+        const uint32_t slot = chunk / cps;  // wave-uniform
+        const uint32_t pl   = (chunk - slot * cps) * 64 + (threadIdx.x & 63u);
+        uint32_t       x = 0, y = 0;
+        const bool     alive = local_pixel_to_xy(screen, pl, x, y);
+        const Ray      r     = make_ray(mk3(cam.position[0], cam.position[1], cam.position[2]),
+                                        alive ? primary_dir(cam, screen, frames[slot], x, y) : mk3(0.f, 0.f, 1.f), 0.0f, kPrimaryFar);
+        float          t, u, v;
+        uint32_t       gid;
+        traverse_closest_packet(bvh, r, alive, wstack, t, u, v, gid);
+        hits[(size_t)slot * screen.pixels_padded + pl] = make_float4(alive ? u : 0.0f, alive ? v : 0.0f, u2f(gid), alive ? t : kPrimaryFar);
+    }
+}
+
 template <int STACK>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(BvhDev bvh, RayQueue q, float4* hits)
+__global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_closest(BvhDev bvh, RayQueue q, float4* hits)
 {
     __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
     uint32_t*           stack  = lds_stack + threadIdx.x;
@@ -634,7 +736,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(BvhDev bvh, RayQueue q
 // !RMW (reference model): (origin, path id) (contribution, -), 32 B; direction = the light of the path's frame (LDS copy of the
 // batch's frame constants), tmin / tmax = kRayEps / kRayFar (lighting.h:39-47).
 template <int STACK, bool RMW>
-__global__ __launch_bounds__(kBlock) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded, uint32_t n_slots,
+__global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded, uint32_t n_slots,
                                                       uint64_t* guard, uint32_t* work, const FrameConst* frames)
 {
     __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
@@ -789,7 +891,7 @@ constexpr uint32_t kRefillIdle = CAP_REFILL_IDLE;  // refill once this many lane
 constexpr int      kLeafBatch  = CAP_LEAF_BATCH;  // keep running the box code while at least this many lanes are on internal nodes
 
 template <int STACK>
-__global__ __launch_bounds__(kBlock) void k_trace_closest_refill(BvhDev bvh, RayQueue q, float4* hits)
+__global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_closest_refill(BvhDev bvh, RayQueue q, float4* hits)
 {
     __shared__ uint32_t lds_stack[STACK * kBlock];
     uint32_t*           stack = lds_stack + threadIdx.x;
@@ -886,8 +988,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest_refill(BvhDev bvh, Ray
 }
 
 // The same kernel on the wide view of the tree (bvh.hip k_node4): two binary levels per step.
+#ifndef CAP_WIDE_BLOCKS
+#define CAP_WIDE_BLOCKS 6
+#endif
 template <int STACK>
-__global__ __launch_bounds__(kBlock) void k_trace_closest_refill4(BvhDev bvh, RayQueue q, float4* hits)
+__global__ __launch_bounds__(kBlock, CAP_WIDE_BLOCKS) void k_trace_closest_refill4(BvhDev bvh, RayQueue q, float4* hits)
 {
     __shared__ uint32_t lds_stack[STACK * kBlock];
     uint32_t*           stack = lds_stack + threadIdx.x;
@@ -1015,10 +1120,40 @@ static BvhDev for_grid(const BvhDev& bvh, uint32_t grid_blocks)
     return b;
 }
 
+// The lane-refill kernels deal their chunks out statically (wave w takes slots w, w + W, ...): a workgroup that is not resident
+// from the start runs its whole share after the others have finished.  Their grids are therefore clamped to what the runtime
+// says fits at once (measured on the 262 k-triangle scene: 5 workgroups per CU requested with 32-KB stacks, 4 resident,
+// closest hit 11.3 ms; 24-KB stacks, 5 resident, 7.9 ms).
+template <auto K>
+static uint32_t resident_grid(const LaunchCfg& cfg, uint32_t want)
+{
+    static int per_cu = -1;
+    if (per_cu < 0)
+    {
+        int n = 0;
+        per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K, (int)kBlock, 0) == hipSuccess && n > 0) ? n : 0;
+        if (getenv("CAP_TRACE_LAUNCHES")) fprintf(stderr, "[cap] resident workgroups per CU: %d\n", per_cu);
+    }
+    if (!cfg.cu_count || !per_cu) return want;
+    const uint32_t cap = cfg.cu_count * (uint32_t)per_cu;
+    return want < cap ? want : cap;
+}
+
 void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraDev& cam, const ScreenDev& screen,
-                          const FrameConst* frames, uint32_t n_slots, float4* hits)
+                          const FrameConst* frames, uint32_t n_slots, float4* hits, uint32_t* work)
 {
     const uint32_t chunks = screen.pixels_padded >> 6;
+    static const bool no_packet = getenv("CAP_NO_PACKET") != nullptr;  // A/B switch
+    if (cfg.stack_entries != 0 && work && bvh.tri_count >= 2 && !no_packet)
+    {
+        // latency-bound on the dependent scalar node fetches and light on registers: as many waves as fit
+        uint32_t gx = (chunks * n_slots + 3) / 4;
+        const uint32_t cap = cfg.cu_count ? resident_grid<k_trace_primary_packet<0>>(cfg, ~0u) : cfg.grid_blocks;
+        if (gx > cap) gx = cap;
+        if (gx == 0) gx = 1;
+        hipLaunchKernelGGL(k_trace_primary_packet<0>, dim3(gx), dim3(kBlock), 0, cfg.stream, bvh, cam, screen, frames, n_slots, hits, work);
+        return;
+    }
     uint32_t       gx     = (chunks + 3) / 4;
     if (gx > cfg.grid_blocks) gx = cfg.grid_blocks;
     if (gx == 0) gx = 1;
@@ -1046,11 +1181,20 @@ void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueu
     if (cfg.stack_entries == 0)
         hipLaunchKernelGGL(k_trace_closest<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
     else if (bvh.wide_ok && grid.x * kBlock <= bvh.spill_threads)
-        hipLaunchKernelGGL(k_trace_closest_refill4<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
+    {
+        grid.x = resident_grid<k_trace_closest_refill4<(int)kWideLdsEntries>>(cfg, grid.x);
+        hipLaunchKernelGGL(k_trace_closest_refill4<(int)kWideLdsEntries>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
+    }
     else if (cfg.stack_entries <= 32)
+    {
+        grid.x = resident_grid<k_trace_closest_refill<32>>(cfg, grid.x);
         hipLaunchKernelGGL(k_trace_closest_refill<32>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
+    }
     else
+    {
+        grid.x = resident_grid<k_trace_closest_refill<64>>(cfg, grid.x);
         hipLaunchKernelGGL(k_trace_closest_refill<64>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
+    }
 }
 
 void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target,
@@ -1066,6 +1210,12 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
     if (cfg.stack_entries == 0)
     {
         if (mostly_unoccluded) CAP_LAUNCH_ANY(0, true); else CAP_LAUNCH_ANY(0, false);
+    }
+    else if (bw.wide_ok)
+    {
+        // wide traversal only (its stack continues in the spill slice): the smaller LDS part lets more workgroups be resident.
+        // The binary code in this instantiation is never reached -- it has no spill and would drop entries past the LDS part.
+        if (mostly_unoccluded) CAP_LAUNCH_ANY((int)kWideLdsEntries, true); else CAP_LAUNCH_ANY((int)kWideLdsEntries, false);
     }
     else if (cfg.stack_entries <= 32)
     {
