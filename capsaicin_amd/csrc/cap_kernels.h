@@ -63,7 +63,9 @@ void launch_resolve(const LaunchCfg& cfg, const Planes& planes, uint32_t n_slots
 void launch_untile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* src, const float4* albedo, const float4* direct,
                    int plane_kind, float4* image);
 void launch_tiles_mean(const LaunchCfg& cfg, const float4* accum, uint32_t pixels_padded, float4* dst);
-void launch_assemble(const LaunchCfg& cfg, const ScreenDev& screen, const float4* gathered, uint32_t shard_count, float4* image);
+// shard_stride: float4 elements between two shards' buffers (0: pixels_padded, i.e. back to back)
+void launch_assemble(const LaunchCfg& cfg, const ScreenDev& screen, const float4* gathered, uint32_t shard_count, float4* image,
+                     size_t shard_stride = 0);
 void launch_geo_aov(const LaunchCfg& cfg, const SceneDev& scene, const float4* hits_slot, uint32_t pixels_padded, float4* aov_geo);
 
 // ---- LBVH build (bvh.hip) ----

@@ -1142,6 +1142,72 @@ int cap_post_reset(CapContext* c)
     return CAP_OK;
 }
 
+// Common tail of cap_post_frame / cap_post_frame_gathered: the chain on post_in[0..3].
+static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t frame_count, const CapCameraData* prev_camera)
+{
+    PostChainArgs a{};
+    a.settings = PostSettingsDev{s->gather, s->denoise, s->eaw5, s->eaw_normal_sigma, s->eaw_depth_sigma, s->eaw_luma_sigma, s->gather_normal_sigma,
+                                 s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback, s->lowres_indirect};
+    a.width = c->screen.width, a.height = c->screen.height, a.frame_count = frame_count;
+    a.camera = camera_dev(c->camera), a.prev_camera = camera_dev(*prev_camera);
+    a.indirect = c->post_in[0].p, a.direct = c->post_in[1].p, a.albedo = c->post_in[2].p, a.normal_depth = c->post_in[3].p;
+    for (int k = 0; k < 2; ++k)
+        a.indirect_history[k] = c->post_ihist[k].p, a.moments_history[k] = c->post_mhist[k].p, a.combined_history[k] = c->post_chist[k].p,
+        a.temp[k] = c->post_temp[k].p;
+    a.prev_normal_depth = c->post_prev_nd.p, a.indirect_temp = c->post_itemp.p, a.normals = c->post_normals.p;
+    {
+        StageTimer t(c, ST_POST);
+        launch_post_chain(c->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    ++c->stats.post_frames;
+    c->post_last_dst = (int)(frame_count % 2);
+    return CAP_OK;
+}
+
+int cap_aov_tile_buffer_floats(CapContext* c, size_t* out_floats)
+{
+    if (!c || !out_floats) return fail(CAP_ERR_INVALID_ARG, "cap_aov_tile_buffer_floats: NULL argument");
+    if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_aov_tile_buffer_floats: resolution not set");
+    *out_floats = (size_t)c->screen.pixels_padded * 4 * 4;
+    return CAP_OK;
+}
+
+int cap_resolve_aov_tiles(CapContext* c, float* device_dst)
+{
+    if (!c || !device_dst) return fail(CAP_ERR_INVALID_ARG, "cap_resolve_aov_tiles: NULL argument");
+    if (!c->aov_valid) return fail(CAP_ERR_STATE, "cap_resolve_aov_tiles: no frame rendered with CAP_RENDER_AOV");
+    if (c->aov_lowres) return fail(CAP_ERR_UNSUPPORTED, "cap_resolve_aov_tiles: the frame was rendered with CAP_RENDER_LOWRES_INDIRECT");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t Ppad  = c->screen.pixels_padded;
+    const size_t   off   = (size_t)(c->last_slots ? c->last_slots - 1 : 0) * Ppad;
+    const size_t   bytes = sizeof(float4) * (size_t)Ppad;
+    float4*        dst   = reinterpret_cast<float4*>(device_dst);
+    // the four inputs of the chain, in its order (cap_post_frame): indirect, direct, albedo, normal/depth
+    const float4* src[4] = {c->pl_color.p + off, c->pl_direct.p + off, c->pl_albedo.p + off, c->aov_nd.p};
+    for (int k = 0; k < 4; ++k) HIP_TRY(hipMemcpyAsync(dst + (size_t)k * Ppad, src[k], bytes, hipMemcpyDeviceToDevice, c->stream));
+    return CAP_OK;
+}
+
+int cap_post_frame_gathered(CapContext* c, const CapPostSettings* s, uint32_t frame_count, const CapCameraData* prev_camera,
+                            const float* device_gathered, uint32_t shard_count)
+{
+    if (!c || !s || !prev_camera || !device_gathered) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame_gathered: NULL argument");
+    if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_post_frame_gathered: resolution not set");
+    if (shard_count != c->screen.shard_count)
+        return fail(CAP_ERR_INVALID_ARG, "cap_post_frame_gathered: shard_count %u != context's %u", shard_count, c->screen.shard_count);
+    if (s->lowres_indirect) return fail(CAP_ERR_UNSUPPORTED, "cap_post_frame_gathered: lowres_indirect needs an unsharded context");
+    if (!(s->eaw_luma_sigma > 0.0f) || !(s->gather_luma_sigma > 0.0f)) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame_gathered: luma sigmas must be > 0");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->post_w != c->screen.width || c->post_h != c->screen.height)
+        if (int e = cap_post_reset(c)) return e;
+    const uint32_t Ppad = c->screen.pixels_padded;
+    LaunchCfg      cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
+    const float4*  g = reinterpret_cast<const float4*>(device_gathered);
+    for (int k = 0; k < 4; ++k) launch_assemble(cfg, c->screen, g + (size_t)k * Ppad, shard_count, c->post_in[k].p, (size_t)4 * Ppad);
+    return run_post_chain(c, s, frame_count, prev_camera);
+}
+
 int cap_post_frame(CapContext* c, const CapPostSettings* s, uint32_t frame_count, const CapCameraData* prev_camera)
 {
     if (!c || !s || !prev_camera) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame: NULL argument");
@@ -1174,24 +1240,7 @@ int cap_post_frame(CapContext* c, const CapPostSettings* s, uint32_t frame_count
     launch_untile(cfg, c->screen, c->pl_direct.p + off, nullptr, nullptr, 0, c->post_in[1].p);
     launch_untile(cfg, c->screen, c->pl_albedo.p + off, nullptr, nullptr, 0, c->post_in[2].p);
     launch_untile(cfg, c->screen, c->aov_nd.p, nullptr, nullptr, 0, c->post_in[3].p);
-    PostChainArgs a{};
-    a.settings = PostSettingsDev{s->gather, s->denoise, s->eaw5, s->eaw_normal_sigma, s->eaw_depth_sigma, s->eaw_luma_sigma, s->gather_normal_sigma,
-                                 s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback, s->lowres_indirect};
-    a.width = c->screen.width, a.height = c->screen.height, a.frame_count = frame_count;
-    a.camera = camera_dev(c->camera), a.prev_camera = camera_dev(*prev_camera);
-    a.indirect = c->post_in[0].p, a.direct = c->post_in[1].p, a.albedo = c->post_in[2].p, a.normal_depth = c->post_in[3].p;
-    for (int k = 0; k < 2; ++k)
-        a.indirect_history[k] = c->post_ihist[k].p, a.moments_history[k] = c->post_mhist[k].p, a.combined_history[k] = c->post_chist[k].p,
-        a.temp[k] = c->post_temp[k].p;
-    a.prev_normal_depth = c->post_prev_nd.p, a.indirect_temp = c->post_itemp.p, a.normals = c->post_normals.p;
-    {
-        StageTimer t(c, ST_POST);
-        launch_post_chain(c->stream, a);
-    }
-    HIP_TRY(hipGetLastError());
-    ++c->stats.post_frames;
-    c->post_last_dst = (int)(frame_count % 2);
-    return CAP_OK;
+    return run_post_chain(c, s, frame_count, prev_camera);
 }
 
 int cap_post_readback(CapContext* c, float* dst)

@@ -2149,8 +2149,8 @@ void launch_tiles_mean(const LaunchCfg& cfg, const float4* accum, uint32_t Ppad,
     hipLaunchKernelGGL(k_tiles_mean, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, accum, Ppad, dst);
 }
 
-// gathered: [shard][Ppad] tile-ordered pixels -> row-major image
-__global__ __launch_bounds__(kBlock) void k_assemble(ScreenDev sc, const float4* gathered, uint32_t shard_count, float4* image)
+// gathered: [shard][shard_stride >= Ppad] tile-ordered pixels -> row-major image
+__global__ __launch_bounds__(kBlock) void k_assemble(ScreenDev sc, const float4* gathered, uint32_t shard_count, size_t shard_stride, float4* image)
 {
     const uint32_t total = sc.tile_count * kTilePixels;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock)
@@ -2160,15 +2160,17 @@ __global__ __launch_bounds__(kBlock) void k_assemble(ScreenDev sc, const float4*
         const uint32_t ty = gt / sc.tiles_x, tx = gt - ty * sc.tiles_x;
         const uint32_t x = tx * kTileDim + (w & 7u), y = ty * kTileDim + (w >> 3);
         if (x < sc.width && y < sc.height)
-            image[(size_t)y * sc.width + x] = gathered[(size_t)shard * sc.pixels_padded + lt * kTilePixels + w];
+            image[(size_t)y * sc.width + x] = gathered[(size_t)shard * shard_stride + lt * kTilePixels + w];
     }
 }
 
-void launch_assemble(const LaunchCfg& cfg, const ScreenDev& screen, const float4* gathered, uint32_t shard_count, float4* image)
+void launch_assemble(const LaunchCfg& cfg, const ScreenDev& screen, const float4* gathered, uint32_t shard_count, float4* image,
+                     size_t shard_stride)
 {
     uint32_t g = (screen.tile_count * kTilePixels + kBlock - 1) / kBlock;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_assemble, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, screen, gathered, shard_count, image);
+    hipLaunchKernelGGL(k_assemble, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, screen, gathered, shard_count,
+                       shard_stride ? shard_stride : (size_t)screen.pixels_padded, image);
 }
 
 // rt_primary_visibility.hlsl:46: (uv, asfloat(InstanceID), asfloat(PrimitiveIndex)); a miss keeps uv = 0, ids = ~0u (:41-43)

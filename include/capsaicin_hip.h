@@ -246,6 +246,19 @@ typedef struct CapPostSettings
  * across tile borders.  Asynchronous on the context stream.  The result (current_frame_output(), cpp:320-324) is read with
  * cap_post_readback. */
 int cap_post_frame(CapContext* ctx, const CapPostSettings* settings, uint32_t frame_count, const CapCameraData* prev_camera);
+/* Sharded contexts: the chain runs on ONE rank on the gathered ray-pass outputs (the note on the post-process chain in the
+ * multi-GPU design: 5x5 .. 7x7 neighbourhoods with strides up to 14 px cross every tile border).  Per frame:
+ *   every rank   cap_render(.., CAP_RENDER_AOV); cap_resolve_aov_tiles(ctx, buf)            buf: cap_aov_tile_buffer_floats floats
+ *   one gather of the rank buffers to the root (rank-major, like cap_resolve_tiles / cap_assemble_tiles)
+ *   root         cap_post_frame_gathered(ctx, settings, frame_count, prev_camera, gathered, shard_count)
+ * The buffer holds the four planes the chain reads (indirect, direct, albedo, normal/depth of the AOV frame), plane-major, each
+ * in tile order.  The root's context must have the same resolution, camera and shard_count; its own render outputs are not
+ * used.  CAP_RENDER_GBUFFER_FEEDBACK and lowres_indirect stay with unsharded contexts (they would need the previous output
+ * broadcast back to every rank). */
+int cap_aov_tile_buffer_floats(CapContext* ctx, size_t* out_floats);
+int cap_resolve_aov_tiles(CapContext* ctx, float* device_dst);
+int cap_post_frame_gathered(CapContext* ctx, const CapPostSettings* settings, uint32_t frame_count, const CapCameraData* prev_camera,
+                            const float* device_gathered, uint32_t shard_count);
 /* zero-fills the histories (a new sequence; also implied by cap_set_resolution) */
 int cap_post_reset(CapContext* ctx);
 /* dst: width*height*4 floats (host) */

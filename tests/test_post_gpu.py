@@ -197,3 +197,65 @@ def test_post_chain_reset_and_errors(native_lib, bluenoise, cornell_path):
     with pytest.raises(capi.CapError, match="unsharded"):
         r.post_frame(s, 0, cam)
     r.close()
+
+
+@pytest.mark.parametrize("count", [2, 3, 8])
+def test_post_chain_on_gathered_shards(native_lib, bluenoise, cornell_path, count):
+    """on sharded contexts the chain runs on one rank on the gathered ray-pass outputs.  Every shard renders its
+    tiles, packs the four chain inputs (cap_resolve_aov_tiles), the buffers are concatenated rank-major (what one gather delivers)
+    and the root runs cap_post_frame_gathered: bit-identical to the unsharded render + cap_post_frame, frame after frame."""
+    import torch
+    w, h, D = 150, 101, 2
+    geo = capi.Geometry(cornell_path)
+    r = capi.Renderer(0)
+    r.upload_geometry(geo)
+    r.upload_bluenoise(bluenoise)
+    r.build_bvh()
+    r.set_resolution(w, h)
+    base = capi.cornell_camera(w, h)
+    cams = [base] * 2 + [moved(base, 0.02 * k, 0.01 * k, -0.03 * k) for k in range(1, 4)]
+    s = capi.PostSettings()
+
+    def sequence(sharded):
+        out, prev = [], cams[0]
+        r.post_reset()
+        for f, cam in enumerate(cams):
+            r.set_camera(cam)
+            if not sharded:
+                r.set_shard(0, 1)
+                r.render(f, 1, D, capi.RENDER_AOV)
+                r.post_frame(s, f, prev)
+            else:
+                bufs = []
+                for idx in range(count):
+                    r.set_shard(idx, count)
+                    r.render(f, 1, D, capi.RENDER_AOV)
+                    n = r.aov_tile_buffer_floats()
+                    assert n == 4 * r.tile_buffer_floats()
+                    t = torch.empty(n, dtype=torch.float32, device="cuda")
+                    torch.cuda.synchronize()  # the renderer runs on its own stream
+                    r.resolve_aov_tiles(t.data_ptr())
+                    r.sync()
+                    bufs.append(t)
+                gathered = torch.cat(bufs)
+                torch.cuda.synchronize()
+                r.post_frame_gathered(s, f, prev, gathered.data_ptr(), count)
+            out.append(r.post_readback())
+            prev = cam
+        return out
+
+    want = sequence(False)
+    got = sequence(True)
+    for f, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(bits(a), bits(b)), "frame %d: %d pixels differ" % (f, int((bits(a) != bits(b)).any(-1).sum()))
+    # error paths: a plain cap_post_frame refuses the sharded context; the gathered form refuses a wrong shard count
+    with pytest.raises(capi.CapError):
+        r.post_frame(s, len(cams), cams[-1])
+    with pytest.raises(capi.CapError):
+        r.post_frame_gathered(s, len(cams), cams[-1], gathered_ptr_of(got), count + 1)
+    r.close()
+
+
+def gathered_ptr_of(_):
+    import torch
+    return torch.zeros(16, dtype=torch.float32, device="cuda").data_ptr()

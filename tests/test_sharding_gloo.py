@@ -35,15 +35,30 @@ def _worker(rank, world, port, width, height, q):
         g = obj_oracle.load_geometry(os.path.join(ROOT, "assets", "cornell_box.obj"))
         sc = O.Scene(g["positions"], g["normals"], g["texcoords"], g["indices"], g["meshes"])
         cam = O.make_camera((-0.01, 0.995, 3.4), (0, 0, -1), (-1, 0, 0), (0, 1, 0), 0.036, 0.036 * height / width, 0.035)
-        full = sc.render_frame(cam, bn, width, height, 3, 2)["combined"]
+        frame = sc.render_frame(cam, bn, width, height, 3, 2)
+        full = frame["combined"]
         # this rank "renders" only its shard: everything outside its tiles is discarded before the exchange
         mine = torch.from_numpy(tiles.extract(full, rank, world).copy())
         assert mine.shape[0] == tiles.padded_pixels(width, height, world)
         gathered = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
         dist.gather(mine, gathered, dst=0)  # the single data-path collective of a frame
+        ok = True
         if rank == 0:
             img = tiles.assemble([t.numpy() for t in gathered], width, height)
-            q.put(bool(np.array_equal(img.view(np.uint32), full.view(np.uint32))))
+            ok = bool(np.array_equal(img.view(np.uint32), full.view(np.uint32)))
+        # reconstruction chain on sharded renders: the four chain inputs travel plane-major in one buffer per rank
+        # (cap_resolve_aov_tiles), one gather, and the root assembles them and runs the chain (cap_post_frame_gathered)
+        planes = ("indirect", "direct", "albedo", "normal_depth")
+        mine4 = torch.from_numpy(np.stack([tiles.extract(frame[k], rank, world) for k in planes]).copy())
+        gathered4 = [torch.zeros_like(mine4) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine4, gathered4, dst=0)
+        if rank == 0:
+            asm = {k: tiles.assemble([t.numpy()[i] for t in gathered4], width, height) for i, k in enumerate(planes)}
+            ok = ok and all(np.array_equal(asm[k].view(np.uint32), np.ascontiguousarray(frame[k]).view(np.uint32)) for k in planes)
+            a = O.PostChain(width, height).frame(O.PostSettings(), 3, cam, cam, dict(frame, **asm))
+            b = O.PostChain(width, height).frame(O.PostSettings(), 3, cam, cam, frame)
+            ok = ok and bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+            q.put(ok)
         dist.barrier()
     finally:
         dist.destroy_process_group()
