@@ -45,7 +45,7 @@ struct BvhDev
     const float4* nodes4;      // wide view: per internal node the four grandchild boxes, SoA, 128 B (bvh.hip k_node4)
     uint32_t*     stack_spill; // kSpillEntries words per thread of the persistent grid: stack entries beyond the LDS part
     uint32_t      spill_threads;  // threads the spill area is sized for
-    uint32_t      wide_ok;        // the wide kernels' stack bound 3 * ceil(depth / 2) fits 32 LDS + kSpillEntries entries
+    uint32_t      wide_ok;        // the wide kernels' stack bound 3 * ceil(depth / 2) fits kWideLdsEntries + kSpillEntries entries
     const float4* tris;        // 64-B intersection records in leaf order (.w of the 4th float4 = global triangle id)
     const float4* tris_by_id;  // the same records in global triangle id order (exhaustive small-scene kernels)
     // exhaustive loop order: fan pairs (triangles id, id + 1 sharing v0 and the edge v0->v2), 20 floats each
