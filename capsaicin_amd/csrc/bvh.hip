@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void k_tri_setup(BvhBuildArgs a)
     float          lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (g < a.tri_count)
     {
-        const uint2    id  = a.tri_ids[g];
+        const uint4    id  = a.tri_ids[g];
         const uint4    mo  = a.mesh_offsets[id.x];
         const uint32_t io  = mo.y + 3u * id.y;
         const uint32_t i0 = mo.x + a.indices[io], i1 = mo.x + a.indices[io + 1], i2 = mo.x + a.indices[io + 2];

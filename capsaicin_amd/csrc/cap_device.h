@@ -159,7 +159,8 @@ struct MaterialDev
 struct SceneDev
 {
     const float4*     shade_tris;  // 6 per triangle
-    const uint2*      tri_ids;     // (instance, primitive) per global triangle  (tlas_system.cpp:40-58)
+    const uint4*      tri_ids;     // (instance, primitive, texture index of the instance's mesh, -) per global triangle
+                                   // (tlas_system.cpp:40-58; the texture index spares the shading a dependent load)
     const uint32_t*   mesh_texture;  // texture index per mesh (MeshComponent::material_index)
     const TextureDev* textures;
     uint32_t          texture_count;

@@ -76,7 +76,7 @@ struct BvhBuildArgs
     const float*    normals;
     const float*    texcoords;
     const uint32_t* indices;
-    const uint2*    tri_ids;        // (instance, primitive) per global triangle
+    const uint4*    tri_ids;        // (instance, primitive, texture index, -) per global triangle
     const uint4*    mesh_offsets;   // per mesh: (first_vertex_offset, first_index_offset, -, -)
     uint32_t        tri_count;
     // outputs

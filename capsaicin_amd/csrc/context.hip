@@ -106,7 +106,7 @@ struct CapContext
     // scene (GeometryStorage layout, asset_load_system.h:16-27)
     DevBuf<float>    positions, normals, texcoords;
     DevBuf<uint32_t> indices;
-    DevBuf<uint2>    tri_ids;
+    DevBuf<uint4>    tri_ids;
     DevBuf<uint4>    mesh_offsets;
     DevBuf<uint32_t> mesh_texture;
     uint32_t         vertex_count = 0, index_count = 0, mesh_count = 0, tri_count = 0;
@@ -458,7 +458,7 @@ int cap_scene_upload(CapContext* c, const float* positions, const float* normals
     if ((vertex_count && (!positions || !normals || !texcoords)) || (index_count && !indices) || (mesh_count && !meshes))
         return fail(CAP_ERR_INVALID_ARG, "cap_scene_upload: NULL array with non-zero count");
     // validate the descriptors on the host: the kernels index with them unchecked
-    std::vector<uint2> tri_ids;
+    std::vector<uint4> tri_ids;
     std::vector<uint4> mesh_offsets(mesh_count);
     std::vector<uint32_t> mesh_texture(mesh_count);
     for (uint32_t m = 0; m < mesh_count; ++m)
@@ -473,7 +473,7 @@ int cap_scene_upload(CapContext* c, const float* positions, const float* normals
                 return fail(CAP_ERR_INVALID_ARG, "mesh %u: index %u out of range", m, indices[d.first_index_offset + k]);
         mesh_offsets[m] = make_uint4(d.first_vertex_offset, d.first_index_offset, 0, 0);
         mesh_texture[m] = d.texture_index;
-        for (uint32_t p = 0; p < d.index_count / 3; ++p) tri_ids.push_back(make_uint2(m, p));
+        for (uint32_t p = 0; p < d.index_count / 3; ++p) tri_ids.push_back(make_uint4(m, p, d.texture_index, 0u));
     }
     if (tri_ids.size() >= (1u << 30)) return fail(CAP_ERR_UNSUPPORTED, "too many triangles");
     HIP_TRY(hipSetDevice(c->device));
@@ -492,7 +492,7 @@ int cap_scene_upload(CapContext* c, const float* positions, const float* normals
         HIP_TRY(hipMemcpy(c->texcoords.p, texcoords, sizeof(float) * 2 * vertex_count, hipMemcpyHostToDevice));
     }
     if (index_count) HIP_TRY(hipMemcpy(c->indices.p, indices, sizeof(uint32_t) * index_count, hipMemcpyHostToDevice));
-    if (!tri_ids.empty()) HIP_TRY(hipMemcpy(c->tri_ids.p, tri_ids.data(), sizeof(uint2) * tri_ids.size(), hipMemcpyHostToDevice));
+    if (!tri_ids.empty()) HIP_TRY(hipMemcpy(c->tri_ids.p, tri_ids.data(), sizeof(uint4) * tri_ids.size(), hipMemcpyHostToDevice));
     if (mesh_count)
     {
         HIP_TRY(hipMemcpy(c->mesh_offsets.p, mesh_offsets.data(), sizeof(uint4) * mesh_count, hipMemcpyHostToDevice));

@@ -1515,10 +1515,11 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
             // scene.h:52-61 GetMaterial
             v3       kd   = mk3(a.scene.kd_untextured, a.scene.kd_untextured, a.scene.kd_untextured);
             uint32_t inst = 0;
-            if (a.scene.texture_count != 0 || (FIRST && slot == a.aov_slot))  // wave-uniform: untextured scenes skip two dependent loads
+            if (a.scene.texture_count != 0 || (FIRST && slot == a.aov_slot))  // wave-uniform: untextured scenes skip the dependent load
             {
-                inst               = a.scene.tri_ids[gid].x;
-                const uint32_t tex = a.scene.mesh_texture[inst];
+                const uint4 id     = a.scene.tri_ids[gid];  // .z = mesh_texture[instance], stored per triangle: one load, not two in a row
+                inst               = id.x;
+                const uint32_t tex = id.z;
                 if (tex != kInvalidId && tex < a.scene.texture_count)
                 {
                     const float tu = mix(s0.w, s2.w, s4.w), tv = mix(s1.w, s3.w, s5.w);
@@ -1890,12 +1891,19 @@ void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext, bool fe
         else
             hipLaunchKernelGGL((k_shade<true, false>), dim3(gx, args.n_slots), dim3(kBlock), 0, cfg.stream, args);
     }
-    else if (ext)
-        hipLaunchKernelGGL((k_shade<false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
-    else if (feedback)
-        hipLaunchKernelGGL((k_shade<false, false, true>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
     else
-        hipLaunchKernelGGL((k_shade<false, false>), dim3(queue_grid(cfg, args.max_count)), dim3(kBlock), 0, cfg.stream, args);
+    {
+        // static chunk assignment: the grid must be resident at once (resident_grid())
+        const uint32_t want = queue_grid(cfg, args.max_count);
+        if (ext)
+            hipLaunchKernelGGL((k_shade<false, true>), dim3(resident_grid<k_shade<false, true, false>>(cfg, want)), dim3(kBlock), 0, cfg.stream, args);
+        else if (feedback)
+            hipLaunchKernelGGL((k_shade<false, false, true>), dim3(resident_grid<k_shade<false, false, true>>(cfg, want)), dim3(kBlock), 0,
+                               cfg.stream, args);
+        else
+            hipLaunchKernelGGL((k_shade<false, false>), dim3(resident_grid<k_shade<false, false, false>>(cfg, want)), dim3(kBlock), 0, cfg.stream,
+                               args);
+    }
 }
 
 // Fused stage of the small-scene path: closest-hit (exhaustive, wave-uniform) + shading of the vertex it finds, in one pass over
@@ -2002,7 +2010,7 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
             float4 g = make_float4(0.f, 0.f, u2f(kInvalidId), u2f(kInvalidId));
             if (gid != kInvalidId)
             {
-                const uint2 id = a.scene.tri_ids[gid];
+                const uint4 id = a.scene.tri_ids[gid];
                 g              = make_float4(u, v, u2f(id.x), u2f(id.y));
             }
             a.planes.aov_geo[i] = g;
@@ -2184,7 +2192,7 @@ __global__ __launch_bounds__(kBlock) void k_geo_aov(SceneDev scene, const float4
             out[pl] = make_float4(0.f, 0.f, u2f(kInvalidId), u2f(kInvalidId));
         else
         {
-            const uint2 id = scene.tri_ids[gid];
+            const uint4 id = scene.tri_ids[gid];
             out[pl]        = make_float4(h.x, h.y, u2f(id.x), u2f(id.y));
         }
     }
