@@ -113,7 +113,8 @@ def test_duplicate_centroids_and_flat_scene(native_lib, bluenoise):
 
 
 @pytest.mark.parametrize("build", [1, 2])
-@pytest.mark.parametrize("seed,ntri,w,h,D", [(11, 1, 48, 48, 2), (12, 2, 48, 48, 2), (13, 300, 96, 96, 3), (14, 5000, 128, 96, 4)])
+@pytest.mark.parametrize("seed,ntri,w,h,D", [(11, 1, 48, 48, 2), (12, 2, 48, 48, 2), (13, 300, 96, 96, 3), (14, 5000, 128, 96, 4),
+                                            (15, 700, 61, 37, 3)])  # the last: partial tiles (idle lanes in the camera-ray packets)
 def test_triangle_soup_parity(native_lib, bluenoise, seed, ntri, w, h, D, build):
     from oracle import cap_oracle as O
     pos, nrm, uv, idx, meshes = soup(seed, ntri)
