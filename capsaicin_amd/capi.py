@@ -106,6 +106,9 @@ SYMBOLS = {
     "cap_aov_tile_buffer_floats": (_i, [_vp, C.POINTER(C.c_size_t)]),
     "cap_resolve_aov_tiles": (_i, [_vp, _vp]),
     "cap_post_frame_gathered": (_i, [_vp, C.POINTER(PostSettings), _u32, C.POINTER(CameraData), _vp, _u32]),
+    "cap_feedback_buffer_floats": (_i, [_vp, C.POINTER(C.c_size_t)]),
+    "cap_feedback_export": (_i, [_vp, _vp]),
+    "cap_feedback_import": (_i, [_vp, _vp, _u32]),
     "cap_post_reset": (_i, [_vp]),
     "cap_post_readback": (_i, [_vp, _vp]),
     "cap_obj_load": (_i, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
@@ -366,6 +369,17 @@ class Renderer:
     def post_frame_gathered(self, settings, frame_count, prev_camera, device_gathered, shard_count):
         _check(lib().cap_post_frame_gathered(self.ctx, C.byref(settings), frame_count, C.byref(prev_camera), C.c_void_p(device_gathered),
                                              shard_count), "cap_post_frame_gathered")
+
+    def feedback_buffer_floats(self):
+        n = C.c_size_t()
+        _check(lib().cap_feedback_buffer_floats(self.ctx, C.byref(n)), "cap_feedback_buffer_floats")
+        return n.value
+
+    def feedback_export(self, device_ptr):
+        _check(lib().cap_feedback_export(self.ctx, C.c_void_p(device_ptr)), "cap_feedback_export")
+
+    def feedback_import(self, device_ptr, frame_count):
+        _check(lib().cap_feedback_import(self.ctx, C.c_void_p(device_ptr), frame_count), "cap_feedback_import")
 
     def resolve_tiles(self, device_ptr):
         _check(lib().cap_resolve_tiles(self.ctx, C.c_void_p(device_ptr)), "cap_resolve_tiles")

@@ -842,7 +842,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         // the branch reads the previous frame's reconstruction output: one frame per call, the whole image on this context
         if (ext) return fail(CAP_ERR_UNSUPPORTED, "cap_render: CAP_RENDER_GBUFFER_FEEDBACK is defined for the reference shading model only");
         if (n_frames != 1) return fail(CAP_ERR_INVALID_ARG, "cap_render: CAP_RENDER_GBUFFER_FEEDBACK renders one frame per call (n_frames is %u)", n_frames);
-        if (c->screen.shard_count != 1) return fail(CAP_ERR_UNSUPPORTED, "cap_render: CAP_RENDER_GBUFFER_FEEDBACK needs an unsharded context");
+        // sharded contexts: the previous frame's output reaches the non-root ranks through cap_feedback_import
         if (!c->prev_camera_ready) return fail(CAP_ERR_STATE, "cap_render: CAP_RENDER_GBUFFER_FEEDBACK needs cap_prev_camera_set");
         if (c->post_w != c->screen.width || c->post_h != c->screen.height)
             if (int e = cap_post_reset(c)) return e;  // first frame: cleared histories, every vertex is a disocclusion
@@ -1206,6 +1206,42 @@ int cap_post_frame_gathered(CapContext* c, const CapPostSettings* s, uint32_t fr
     const float4*  g = reinterpret_cast<const float4*>(device_gathered);
     for (int k = 0; k < 4; ++k) launch_assemble(cfg, c->screen, g + (size_t)k * Ppad, shard_count, c->post_in[k].p, (size_t)4 * Ppad);
     return run_post_chain(c, s, frame_count, prev_camera);
+}
+
+int cap_feedback_buffer_floats(CapContext* c, size_t* out_floats)
+{
+    if (!c || !out_floats) return fail(CAP_ERR_INVALID_ARG, "cap_feedback_buffer_floats: NULL argument");
+    if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_feedback_buffer_floats: resolution not set");
+    *out_floats = (size_t)c->screen.width * c->screen.height * 4 * 2;
+    return CAP_OK;
+}
+
+int cap_feedback_export(CapContext* c, float* device_dst)
+{
+    if (!c || !device_dst) return fail(CAP_ERR_INVALID_ARG, "cap_feedback_export: NULL argument");
+    if (c->post_last_dst < 0 || c->post_w != c->screen.width || c->post_h != c->screen.height)
+        return fail(CAP_ERR_STATE, "cap_feedback_export: the chain has not run at this resolution");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)c->post_w * c->post_h;
+    float4*      dst  = reinterpret_cast<float4*>(device_dst);
+    HIP_TRY(hipMemcpyAsync(dst, c->post_chist[c->post_last_dst].p, sizeof(float4) * npix, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dst + npix, c->post_prev_nd.p, sizeof(float4) * npix, hipMemcpyDeviceToDevice, c->stream));
+    return CAP_OK;
+}
+
+int cap_feedback_import(CapContext* c, const float* device_src, uint32_t frame_count)
+{
+    if (!c || !device_src) return fail(CAP_ERR_INVALID_ARG, "cap_feedback_import: NULL argument");
+    if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_feedback_import: resolution not set");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->post_w != c->screen.width || c->post_h != c->screen.height)
+        if (int e = cap_post_reset(c)) return e;
+    const size_t  npix = (size_t)c->post_w * c->post_h;
+    const float4* src  = reinterpret_cast<const float4*>(device_src);
+    // what cap_render(frame_count + 1, CAP_RENDER_GBUFFER_FEEDBACK) reads: combined_history[(frame_count + 2) % 2] and the previous normal/depth
+    HIP_TRY(hipMemcpyAsync(c->post_chist[frame_count % 2].p, src, sizeof(float4) * npix, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->post_prev_nd.p, src + npix, sizeof(float4) * npix, hipMemcpyDeviceToDevice, c->stream));
+    return CAP_OK;
 }
 
 int cap_post_frame(CapContext* c, const CapPostSettings* s, uint32_t frame_count, const CapCameraData* prev_camera)

@@ -75,8 +75,9 @@ enum
     CAP_RENDER_EXT_MATERIALS = 1u << 1, /* EXT shading model (materials uploaded with cap_materials_upload) */
     CAP_RENDER_STAGE_TIMERS  = 1u << 2, /* bracket every kernel with hipEvents (fills CapStats::ms_<stage>) */
     /* RaytracingOptions::gbuffer_feedback (raytracing_system.h:26, rt_indirect.hlsl:116-145): a path vertex of bounce >= 1
-     * that the previous frame saw takes that frame's cap_post_frame output and ends the path.  One frame per call, unsharded
-     * context, reference shading model; needs cap_prev_camera_set and cap_post_frame after every frame. */
+     * that the previous frame saw takes that frame's cap_post_frame output and ends the path.  One frame per call, reference
+     * shading model (sharded contexts: cap_feedback_export / _import carry the previous output to every rank); needs
+     * cap_prev_camera_set and cap_post_frame after every frame. */
     CAP_RENDER_GBUFFER_FEEDBACK = 1u << 3,
     /* RaytracingOptions::lowres_indirect (raytracing_system.h:24; LOWRES_INDIRECT, rt_indirect.hlsl:53-59): only the pixel at
      * sp_offset = ((frame % 4) / 2, (frame % 4) % 2) of every 2x2 block gets an indirect sample.  One frame per call, unsharded
@@ -259,6 +260,14 @@ int cap_aov_tile_buffer_floats(CapContext* ctx, size_t* out_floats);
 int cap_resolve_aov_tiles(CapContext* ctx, float* device_dst);
 int cap_post_frame_gathered(CapContext* ctx, const CapPostSettings* settings, uint32_t frame_count, const CapCameraData* prev_camera,
                             const float* device_gathered, uint32_t shard_count);
+/* CAP_RENDER_GBUFFER_FEEDBACK on sharded contexts: the next frame's indirect pass reads the chain's output and the normal/depth
+ * image of this frame (rt_indirect.hlsl:116-145), which only the root has.  After the chain of frame f the root exports the two
+ * images (cap_feedback_buffer_floats floats: width*height*4 each, output first), ONE broadcast carries them to the other ranks,
+ * and those import them before cap_render(f + 1, .., CAP_RENDER_GBUFFER_FEEDBACK).  Frame 0 needs nothing (cleared histories
+ * everywhere). */
+int cap_feedback_buffer_floats(CapContext* ctx, size_t* out_floats);
+int cap_feedback_export(CapContext* ctx, float* device_dst);
+int cap_feedback_import(CapContext* ctx, const float* device_src, uint32_t frame_count);
 /* zero-fills the histories (a new sequence; also implied by cap_set_resolution) */
 int cap_post_reset(CapContext* ctx);
 /* dst: width*height*4 floats (host) */

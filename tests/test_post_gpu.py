@@ -259,3 +259,73 @@ def test_post_chain_on_gathered_shards(native_lib, bluenoise, cornell_path, coun
 def gathered_ptr_of(_):
     import torch
     return torch.zeros(16, dtype=torch.float32, device="cuda").data_ptr()
+
+
+def test_gbuffer_feedback_on_shards(native_lib, bluenoise, cornell_path):
+    """The reference's default loop (feedback on) over two sharded contexts: per frame both render their tiles with the feedback
+    branch, ONE gather brings the chain inputs to the root, the root runs the chain and exports its output + normal/depth, ONE
+    broadcast carries them to the other rank (cap_feedback_import).  Bit-identical to the unsharded loop, frame after frame."""
+    import torch
+    w, h, D, count = 120, 90, 3, 2
+    geo = capi.Geometry(cornell_path)
+    base = capi.cornell_camera(w, h)
+    cams = [base] * 3 + [moved(base, 0.03 * k, 0.0, -0.05 * k) for k in range(1, 3)] + [moved(base, 0.06, 0.0, -0.1)]
+    gs = capi.PostSettings()
+    flags = capi.RENDER_AOV | capi.RENDER_GBUFFER_FEEDBACK
+
+    def make(idx, n):
+        r = capi.Renderer(0)
+        r.upload_geometry(geo)
+        r.upload_bluenoise(bluenoise)
+        r.build_bvh()
+        r.set_resolution(w, h)
+        r.set_shard(idx, n)
+        return r
+
+    ref = make(0, 1)
+    want, prev, rays_want = [], cams[0], []
+    for f, cam in enumerate(cams):
+        ref.set_camera(cam)
+        ref.set_prev_camera(prev)
+        ref.stats_reset()
+        ref.render(f, 1, D, flags)
+        ref.post_frame(gs, f, prev)
+        want.append(ref.post_readback())
+        s = ref.stats()
+        rays_want.append((s.rays_primary, s.rays_extension, s.rays_shadow))
+        prev = cam
+    ref.close()
+
+    ranks = [make(i, count) for i in range(count)]
+    prev = cams[0]
+    for f, cam in enumerate(cams):
+        bufs, rays = [], np.zeros(3, np.int64)
+        for r in ranks:
+            r.set_camera(cam)
+            r.set_prev_camera(prev)
+            r.stats_reset()
+            r.render(f, 1, D, flags)
+            t = torch.empty(r.aov_tile_buffer_floats(), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            r.resolve_aov_tiles(t.data_ptr())
+            r.sync()
+            s = r.stats()
+            rays += (s.rays_primary, s.rays_extension, s.rays_shadow)
+            bufs.append(t)
+        gathered = torch.cat(bufs)
+        torch.cuda.synchronize()
+        root = ranks[0]
+        root.post_frame_gathered(gs, f, prev, gathered.data_ptr(), count)
+        got = root.post_readback()
+        assert np.array_equal(bits(got), bits(want[f])), "frame %d: %d pixels differ" % (f, int((bits(got) != bits(want[f])).any(-1).sum()))
+        assert tuple(int(x) for x in rays) == rays_want[f]  # the feedback branch ended the same paths on both halves
+        fb = torch.empty(root.feedback_buffer_floats(), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        root.feedback_export(fb.data_ptr())
+        root.sync()
+        for r in ranks[1:]:
+            r.feedback_import(fb.data_ptr(), f)  # the broadcast's receiving end
+            r.sync()
+        prev = cam
+    for r in ranks:
+        r.close()
