@@ -854,7 +854,6 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         // the half-resolution indirect image only exists per frame (2x2 interleave over four frames): nothing to accumulate
         if (ext) return fail(CAP_ERR_UNSUPPORTED, "cap_render: CAP_RENDER_LOWRES_INDIRECT is defined for the reference shading model only");
         if (n_frames != 1) return fail(CAP_ERR_INVALID_ARG, "cap_render: CAP_RENDER_LOWRES_INDIRECT renders one frame per call (n_frames is %u)", n_frames);
-        if (c->screen.shard_count != 1) return fail(CAP_ERR_UNSUPPORTED, "cap_render: CAP_RENDER_LOWRES_INDIRECT needs an unsharded context");
         if ((c->screen.width | c->screen.height) & 1u) return fail(CAP_ERR_INVALID_ARG, "cap_render: CAP_RENDER_LOWRES_INDIRECT needs even width and height (%ux%u)", c->screen.width, c->screen.height);
     }
 
@@ -1177,7 +1176,6 @@ int cap_resolve_aov_tiles(CapContext* c, float* device_dst)
 {
     if (!c || !device_dst) return fail(CAP_ERR_INVALID_ARG, "cap_resolve_aov_tiles: NULL argument");
     if (!c->aov_valid) return fail(CAP_ERR_STATE, "cap_resolve_aov_tiles: no frame rendered with CAP_RENDER_AOV");
-    if (c->aov_lowres) return fail(CAP_ERR_UNSUPPORTED, "cap_resolve_aov_tiles: the frame was rendered with CAP_RENDER_LOWRES_INDIRECT");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t Ppad  = c->screen.pixels_padded;
     const size_t   off   = (size_t)(c->last_slots ? c->last_slots - 1 : 0) * Ppad;
@@ -1196,7 +1194,9 @@ int cap_post_frame_gathered(CapContext* c, const CapPostSettings* s, uint32_t fr
     if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_post_frame_gathered: resolution not set");
     if (shard_count != c->screen.shard_count)
         return fail(CAP_ERR_INVALID_ARG, "cap_post_frame_gathered: shard_count %u != context's %u", shard_count, c->screen.shard_count);
-    if (s->lowres_indirect) return fail(CAP_ERR_UNSUPPORTED, "cap_post_frame_gathered: lowres_indirect needs an unsharded context");
+    const bool lowres = s->lowres_indirect != 0;
+    if (lowres && ((c->screen.width | c->screen.height) & 1u))
+        return fail(CAP_ERR_INVALID_ARG, "cap_post_frame_gathered: lowres_indirect needs even width and height (%ux%u)", c->screen.width, c->screen.height);
     if (!(s->eaw_luma_sigma > 0.0f) || !(s->gather_luma_sigma > 0.0f)) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame_gathered: luma sigmas must be > 0");
     HIP_TRY(hipSetDevice(c->device));
     if (c->post_w != c->screen.width || c->post_h != c->screen.height)
@@ -1204,7 +1204,15 @@ int cap_post_frame_gathered(CapContext* c, const CapPostSettings* s, uint32_t fr
     const uint32_t Ppad = c->screen.pixels_padded;
     LaunchCfg      cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
     const float4*  g = reinterpret_cast<const float4*>(device_gathered);
-    for (int k = 0; k < 4; ++k) launch_assemble(cfg, c->screen, g + (size_t)k * Ppad, shard_count, c->post_in[k].p, (size_t)4 * Ppad);
+    for (int k = lowres ? 1 : 0; k < 4; ++k) launch_assemble(cfg, c->screen, g + (size_t)k * Ppad, shard_count, c->post_in[k].p, (size_t)4 * Ppad);
+    if (lowres)
+    {
+        // output_indirect_ is the (W/2, H/2) image of the pixels at this frame's interleave offset, as in cap_post_frame
+        HIP_TRY(c->image_tmp.ensure((size_t)c->screen.width * c->screen.height));
+        launch_assemble(cfg, c->screen, g, shard_count, c->image_tmp.p, (size_t)4 * Ppad);
+        launch_decimate2x(c->stream, c->image_tmp.p, c->screen.width, c->screen.height, (frame_count % 4u) / 2u, (frame_count % 4u) % 2u,
+                          c->post_in[0].p);
+    }
     return run_post_chain(c, s, frame_count, prev_camera);
 }
 

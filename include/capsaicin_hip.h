@@ -80,8 +80,8 @@ enum
      * cap_prev_camera_set and cap_post_frame after every frame. */
     CAP_RENDER_GBUFFER_FEEDBACK = 1u << 3,
     /* RaytracingOptions::lowres_indirect (raytracing_system.h:24; LOWRES_INDIRECT, rt_indirect.hlsl:53-59): only the pixel at
-     * sp_offset = ((frame % 4) / 2, (frame % 4) % 2) of every 2x2 block gets an indirect sample.  One frame per call, unsharded
-     * context, even width and height, reference shading model; the frame is not added to the accumulation buffer.  Read the
+     * sp_offset = ((frame % 4) / 2, (frame % 4) % 2) of every 2x2 block gets an indirect sample.  One frame per call, even width
+     * and height, reference shading model; the frame is not added to the accumulation buffer.  Read the
      * (W/2, H/2) image with CAP_BUF_INDIRECT_LOWRES or hand it to cap_post_frame (settings.lowres_indirect = 1). */
     CAP_RENDER_LOWRES_INDIRECT = 1u << 4
 };
@@ -254,8 +254,8 @@ int cap_post_frame(CapContext* ctx, const CapPostSettings* settings, uint32_t fr
  *   root         cap_post_frame_gathered(ctx, settings, frame_count, prev_camera, gathered, shard_count)
  * The buffer holds the four planes the chain reads (indirect, direct, albedo, normal/depth of the AOV frame), plane-major, each
  * in tile order.  The root's context must have the same resolution, camera and shard_count; its own render outputs are not
- * used.  CAP_RENDER_GBUFFER_FEEDBACK and lowres_indirect stay with unsharded contexts (they would need the previous output
- * broadcast back to every rank). */
+ * used (with settings.lowres_indirect every rank renders with CAP_RENDER_LOWRES_INDIRECT and frame_count selects the 2x2
+ * interleave offset, as in cap_post_frame). */
 int cap_aov_tile_buffer_floats(CapContext* ctx, size_t* out_floats);
 int cap_resolve_aov_tiles(CapContext* ctx, float* device_dst);
 int cap_post_frame_gathered(CapContext* ctx, const CapPostSettings* settings, uint32_t frame_count, const CapCameraData* prev_camera,

@@ -199,13 +199,13 @@ def test_post_chain_reset_and_errors(native_lib, bluenoise, cornell_path):
     r.close()
 
 
-@pytest.mark.parametrize("count", [2, 3, 8])
-def test_post_chain_on_gathered_shards(native_lib, bluenoise, cornell_path, count):
+@pytest.mark.parametrize("count,lowres", [(2, False), (3, False), (8, False), (3, True)])
+def test_post_chain_on_gathered_shards(native_lib, bluenoise, cornell_path, count, lowres):
     """on sharded contexts the chain runs on one rank on the gathered ray-pass outputs.  Every shard renders its
     tiles, packs the four chain inputs (cap_resolve_aov_tiles), the buffers are concatenated rank-major (what one gather delivers)
     and the root runs cap_post_frame_gathered: bit-identical to the unsharded render + cap_post_frame, frame after frame."""
     import torch
-    w, h, D = 150, 101, 2
+    w, h, D = (152, 100, 2) if lowres else (150, 101, 2)  # the half-resolution indirect pass needs even sizes
     geo = capi.Geometry(cornell_path)
     r = capi.Renderer(0)
     r.upload_geometry(geo)
@@ -214,7 +214,8 @@ def test_post_chain_on_gathered_shards(native_lib, bluenoise, cornell_path, coun
     r.set_resolution(w, h)
     base = capi.cornell_camera(w, h)
     cams = [base] * 2 + [moved(base, 0.02 * k, 0.01 * k, -0.03 * k) for k in range(1, 4)]
-    s = capi.PostSettings()
+    s = capi.PostSettings(lowres_indirect=1) if lowres else capi.PostSettings()
+    aov = capi.RENDER_AOV | (capi.RENDER_LOWRES_INDIRECT if lowres else 0)
 
     def sequence(sharded):
         out, prev = [], cams[0]
@@ -223,13 +224,13 @@ def test_post_chain_on_gathered_shards(native_lib, bluenoise, cornell_path, coun
             r.set_camera(cam)
             if not sharded:
                 r.set_shard(0, 1)
-                r.render(f, 1, D, capi.RENDER_AOV)
+                r.render(f, 1, D, aov)
                 r.post_frame(s, f, prev)
             else:
                 bufs = []
                 for idx in range(count):
                     r.set_shard(idx, count)
-                    r.render(f, 1, D, capi.RENDER_AOV)
+                    r.render(f, 1, D, aov)
                     n = r.aov_tile_buffer_floats()
                     assert n == 4 * r.tile_buffer_floats()
                     t = torch.empty(n, dtype=torch.float32, device="cuda")
