@@ -330,3 +330,39 @@ def test_gbuffer_feedback_on_shards(native_lib, bluenoise, cornell_path):
         prev = cam
     for r in ranks:
         r.close()
+
+
+def test_sharded_chain_error_paths(native_lib, bluenoise, cornell_path):
+    """Call-order and argument errors of the sharded-chain entry points come back as status + message, never as a fault."""
+    import torch
+    r = capi.Renderer(0)
+    r.upload_geometry(capi.Geometry(cornell_path))
+    r.upload_bluenoise(bluenoise)
+    r.build_bvh()
+    with pytest.raises(capi.CapError, match="resolution"):
+        r.aov_tile_buffer_floats()
+    with pytest.raises(capi.CapError, match="resolution"):
+        r.feedback_buffer_floats()
+    r.set_resolution(64, 48)
+    cam = capi.cornell_camera(64, 48)
+    r.set_camera(cam)
+    r.set_shard(1, 2)
+    buf = torch.zeros(max(r.aov_tile_buffer_floats(), r.feedback_buffer_floats()), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(capi.CapError, match="CAP_RENDER_AOV"):
+        r.resolve_aov_tiles(buf.data_ptr())  # nothing rendered yet
+    r.render(0, 1, 1)                        # rendered, but without the AOV planes
+    with pytest.raises(capi.CapError, match="CAP_RENDER_AOV"):
+        r.resolve_aov_tiles(buf.data_ptr())
+    with pytest.raises(capi.CapError, match="chain has not run"):
+        r.feedback_export(buf.data_ptr())
+    with pytest.raises(capi.CapError, match="NULL"):
+        r.resolve_aov_tiles(0)
+    with pytest.raises(capi.CapError, match="NULL"):
+        r.feedback_import(0, 0)
+    s = capi.PostSettings(lowres_indirect=1)
+    r.set_resolution(63, 48)
+    r.set_shard(0, 2)
+    with pytest.raises(capi.CapError, match="even width"):
+        r.post_frame_gathered(s, 0, cam, buf.data_ptr(), 2)
+    r.close()
