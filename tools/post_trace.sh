@@ -11,7 +11,7 @@ import csv, glob, re, collections
 f = glob.glob("$OUT/prof_post/**/*kernel_trace.csv", recursive=True)[0]
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    d[re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void cap::", "")[:50]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    d[re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void cap::", "")[:50]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:14]:
     print("%-52s %5d calls  %9.1f us total  %8.1f us avg" % (k, len(v), sum(v), sum(v) / len(v)))
 PY
