@@ -371,7 +371,9 @@ struct PairScaled
     TriScaled a, b;
     uint32_t  id;
 };
-__device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* base, uint32_t k)
+// PRE: (d.nA, d.nB) were computed elsewhere with the same dot3() (k_trace_any's per-frame table) and come in as ddn_pre
+template <bool PRE = false>
+__device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* base, uint32_t k, const float2 ddn_pre = float2{0.f, 0.f})
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(4))) const RawPair ConstPair;
@@ -387,7 +389,7 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
     const float e2q = dot3(e2, q);  // U of the first triangle, V (before its negation) of the second
     PairScaled  o;
     {
-        const float    ddn = dot3(r.d, na);
+        const float    ddn = PRE ? ddn_pre.x : dot3(r.d, na);
         const uint32_t s   = f2u(ddn) & 0x80000000u;
         o.a.det = fabsf(ddn);
         o.a.U   = u2f(f2u(e2q) ^ (s ^ 0x80000000u));
@@ -395,7 +397,7 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
         o.a.T   = u2f(f2u(dot3(tvec, na)) ^ (s ^ 0x80000000u));
     }
     {
-        const float    ddn = dot3(r.d, nb);
+        const float    ddn = PRE ? ddn_pre.y : dot3(r.d, nb);
         const uint32_t s   = f2u(ddn) & 0x80000000u;
         o.b.det = fabsf(ddn);
         o.b.U   = u2f(f2u(dot3(e3, q)) ^ (s ^ 0x80000000u));
@@ -502,7 +504,9 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const floa
 }
 
 // det == 0 needs no test: then U = V = 0 is the only way past the first three conditions and 0 < T < 0 rejects.
-__device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r)
+// PRE: ddn_row is this lane's row of the (frame slot, pair) table of d.n values (see k_trace_any)
+template <bool PRE = false>
+__device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r, const float2* ddn_row = nullptr)
 {
     auto occl = [&](const TriScaled& s) {
         return (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det) & (s.T > r.tmin * s.det) & (s.T < r.tmax * s.det);
@@ -512,7 +516,7 @@ __device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r)
 #pragma unroll 2
     for (uint32_t k = 0; k < np; ++k)
     {
-        const PairScaled p = pair_scaled(r, bvh.fan_pairs, k);
+        const PairScaled p = PRE ? pair_scaled<true>(r, bvh.fan_pairs, k, ddn_row[k]) : pair_scaled<false>(r, bvh.fan_pairs, k);
         hit |= occl(p.a) | occl(p.b);
     }
     const uint32_t ns = bvh.fan_single_count;
@@ -537,10 +541,10 @@ __device__ __forceinline__ void trace_closest_any_size(const BvhDev& bvh, const 
         traverse_closest<STACK>(bvh, r, stack, t, u, v, gid);
 }
 template <int STACK>
-__device__ __forceinline__ bool trace_any_any_size(const BvhDev& bvh, const Ray& r, uint32_t* stack)
+__device__ __forceinline__ bool trace_any_any_size(const BvhDev& bvh, const Ray& r, uint32_t* stack, const float2* ddn_row = nullptr)
 {
     if constexpr (STACK == 0)
-        return exhaustive_any(bvh, r);
+        return ddn_row ? exhaustive_any<true>(bvh, r, ddn_row) : exhaustive_any<false>(bvh, r);  // wave-uniform choice
     else
         return traverse_any<STACK>(bvh, r, stack);
 }
@@ -735,17 +739,37 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_closes
 // Entry formats.  RMW (EXT model, next-event rays): (origin, tmin) (direction, tmax) (contribution, path id), 48 B.
 // !RMW (reference model): (origin, path id) (contribution, -), 32 B; direction = the light of the path's frame (LDS copy of the
 // batch's frame constants), tmin / tmax = kRayEps / kRayFar (lighting.h:39-47).
+// rows of (d.nA, d.nB) per frame slot in k_trace_any's table of fan-pair determinants
+constexpr uint32_t kDdnRow = kExhaustiveMax / 2;
 template <int STACK, bool RMW>
 __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded, uint32_t n_slots,
                                                       uint64_t* guard, uint32_t* work, const FrameConst* frames)
 {
     __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
     __shared__ float4   lds_light[RMW ? 1 : kMaxFrameSlots];
+    // Reference model on the small-scene path: every shadow ray of a frame has the frame's light direction, so the determinants
+    // d.n of the fan pairs depend on (frame slot, pair) only.  They are computed once per workgroup -- the same dot3() on the same
+    // operands, the same bits -- and the pair loop reads them from LDS instead of spending six vector instructions per pair.
+    constexpr bool      DDN = STACK == 0 && !RMW;
+    __shared__ float2   lds_ddn[DDN ? kMaxFrameSlots * kDdnRow : 1];
     uint32_t*           stack    = lds_stack + threadIdx.x;
+    const bool          use_ddn  = DDN && bvh.fan_pair_count <= kDdnRow && n_slots <= kMaxFrameSlots;
     if (!RMW)
     {
         for (uint32_t k = threadIdx.x; k < n_slots && k < kMaxFrameSlots; k += kBlock)
             lds_light[k] = make_float4(frames[k].light_dir[0], frames[k].light_dir[1], frames[k].light_dir[2], 0.f);
+        if (use_ddn)
+        {
+            const uint32_t np = bvh.fan_pair_count;
+            const float*   fp = reinterpret_cast<const float*>(bvh.fan_pairs);
+            for (uint32_t e = threadIdx.x; e < n_slots * np; e += kBlock)
+            {
+                const uint32_t slot = e / np, k = e - slot * np;
+                const v3       d    = mk3(frames[slot].light_dir[0], frames[slot].light_dir[1], frames[slot].light_dir[2]);
+                const float*   rec  = fp + 20 * (size_t)k;  // (v0, e1, e2, e3, nA, nB, id, 0)
+                lds_ddn[slot * kDdnRow + k] = make_float2(dot3(d, mk3(rec[12], rec[13], rec[14])), dot3(d, mk3(rec[15], rec[16], rec[17])));
+            }
+        }
         __syncthreads();
     }
     // Memory round trips a chunk starts with, in order: (1) the grab issued one chunk ago (its wait also covers the previous
@@ -799,8 +823,9 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_any(Bv
                 const float4 L = lds_light[good ? (pid >> kPidShift) : 0u];
                 r = make_ray(mk3(a.x, a.y, a.z), mk3(L.x, L.y, L.z), kRayEps, good ? kRayFar : 0.0f);  // malformed entry: empty interval
             }
+            const float2* ddn_row = use_ddn ? lds_ddn + (good ? (pid >> kPidShift) : 0u) * kDdnRow : nullptr;
             if (STACK == 0) __builtin_amdgcn_s_setprio(0);
-            const bool occluded = trace_any_any_size<STACK>(bvh, r, stack);
+            const bool occluded = trace_any_any_size<STACK>(bvh, r, stack, ddn_row);
             if (STACK == 0) __builtin_amdgcn_s_setprio(3);
             if (!occluded)
             {
