@@ -371,9 +371,7 @@ struct PairScaled
     TriScaled a, b;
     uint32_t  id;
 };
-// PRE: (d.nA, d.nB) were computed elsewhere with the same dot3() (k_trace_any's per-frame table) and come in as ddn_pre
-template <bool PRE = false>
-__device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* base, uint32_t k, const float2 ddn_pre = float2{0.f, 0.f})
+__device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* base, uint32_t k)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(4))) const RawPair ConstPair;
@@ -389,7 +387,7 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
     const float e2q = dot3(e2, q);  // U of the first triangle, V (before its negation) of the second
     PairScaled  o;
     {
-        const float    ddn = PRE ? ddn_pre.x : dot3(r.d, na);
+        const float    ddn = dot3(r.d, na);
         const uint32_t s   = f2u(ddn) & 0x80000000u;
         o.a.det = fabsf(ddn);
         o.a.U   = u2f(f2u(e2q) ^ (s ^ 0x80000000u));
@@ -397,7 +395,7 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
         o.a.T   = u2f(f2u(dot3(tvec, na)) ^ (s ^ 0x80000000u));
     }
     {
-        const float    ddn = PRE ? ddn_pre.y : dot3(r.d, nb);
+        const float    ddn = dot3(r.d, nb);
         const uint32_t s   = f2u(ddn) & 0x80000000u;
         o.b.det = fabsf(ddn);
         o.b.U   = u2f(f2u(dot3(e3, q)) ^ (s ^ 0x80000000u));
@@ -503,10 +501,55 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const floa
     }
 }
 
+// Everything of the occlusion test that depends on the ray's DIRECTION and the triangle only: sign mask of d.n, |d.n| and the two
+// interval bounds tmin * |d.n|, tmax * |d.n|.  The reference model's shadow rays of one frame share the direction (the frame's
+// light) and tmin / tmax are constants, so k_trace_any computes these once per (frame slot, fan pair) and workgroup -- the same
+// operations on the same operands as pair_scaled() + the occlusion test, hence the same bits -- and the pair loop reads them from
+// LDS: ten vector instructions fewer per pair.
+struct PairPre
+{
+    float4 a, b;  // per triangle: (asfloat(sign mask), det, tmin * det, tmax * det)
+};
+__device__ __forceinline__ float4 tri_pre(const v3 d, const v3 n, float tmin, float tmax)
+{
+    const float    ddn = dot3(d, n);
+    const uint32_t s   = f2u(ddn) & 0x80000000u;
+    const float    det = fabsf(ddn);
+    return make_float4(u2f(s), det, tmin * det, tmax * det);
+}
+// pair k of the record list against a ray whose direction-dependent part comes from the table
+__device__ __forceinline__ bool pair_occludes_pre(const Ray& r, const float4* base, uint32_t k, const float4 pa, const float4 pb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const RawPair ConstPair;
+    const RawPair p = ((const ConstPair*)base)[k];
+#else
+    RawPair p;
+    for (int i = 0; i < 20; ++i) p.f[i] = reinterpret_cast<const float*>(base)[20 * k + i];
+#endif
+    const v3 v0 = mk3(p.f[0], p.f[1], p.f[2]), e1 = mk3(p.f[3], p.f[4], p.f[5]), e2 = mk3(p.f[6], p.f[7], p.f[8]),
+             e3 = mk3(p.f[9], p.f[10], p.f[11]), na = mk3(p.f[12], p.f[13], p.f[14]), nb = mk3(p.f[15], p.f[16], p.f[17]);
+    const v3    tvec = r.o - v0;
+    const v3    q    = cross3(tvec, r.d);
+    const float e2q  = dot3(e2, q);
+    bool        hit;
+    {
+        const uint32_t s = f2u(pa.x);
+        const float    U = u2f(f2u(e2q) ^ (s ^ 0x80000000u)), V = u2f(f2u(dot3(e1, q)) ^ s), T = u2f(f2u(dot3(tvec, na)) ^ (s ^ 0x80000000u));
+        hit = (U >= 0.0f) & (V >= 0.0f) & (U + V <= pa.y) & (T > pa.z) & (T < pa.w);
+    }
+    {
+        const uint32_t s = f2u(pb.x);
+        const float    U = u2f(f2u(dot3(e3, q)) ^ (s ^ 0x80000000u)), V = u2f(f2u(e2q) ^ s), T = u2f(f2u(dot3(tvec, nb)) ^ (s ^ 0x80000000u));
+        hit |= (U >= 0.0f) & (V >= 0.0f) & (U + V <= pb.y) & (T > pb.z) & (T < pb.w);
+    }
+    return hit;
+}
+
 // det == 0 needs no test: then U = V = 0 is the only way past the first three conditions and 0 < T < 0 rejects.
-// PRE: ddn_row is this lane's row of the (frame slot, pair) table of d.n values (see k_trace_any)
+// PRE: pre_row is this lane's row of the (frame slot, pair) table (see PairPre)
 template <bool PRE = false>
-__device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r, const float2* ddn_row = nullptr)
+__device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r, const float4* pre_row = nullptr)
 {
     auto occl = [&](const TriScaled& s) {
         return (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det) & (s.T > r.tmin * s.det) & (s.T < r.tmax * s.det);
@@ -516,8 +559,13 @@ __device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r, 
 #pragma unroll 2
     for (uint32_t k = 0; k < np; ++k)
     {
-        const PairScaled p = PRE ? pair_scaled<true>(r, bvh.fan_pairs, k, ddn_row[k]) : pair_scaled<false>(r, bvh.fan_pairs, k);
-        hit |= occl(p.a) | occl(p.b);
+        if (PRE)
+            hit |= pair_occludes_pre(r, bvh.fan_pairs, k, pre_row[2 * k], pre_row[2 * k + 1]);
+        else
+        {
+            const PairScaled p = pair_scaled(r, bvh.fan_pairs, k);
+            hit |= occl(p.a) | occl(p.b);
+        }
     }
     const uint32_t ns = bvh.fan_single_count;
 #pragma unroll 2
@@ -541,10 +589,10 @@ __device__ __forceinline__ void trace_closest_any_size(const BvhDev& bvh, const 
         traverse_closest<STACK>(bvh, r, stack, t, u, v, gid);
 }
 template <int STACK>
-__device__ __forceinline__ bool trace_any_any_size(const BvhDev& bvh, const Ray& r, uint32_t* stack, const float2* ddn_row = nullptr)
+__device__ __forceinline__ bool trace_any_any_size(const BvhDev& bvh, const Ray& r, uint32_t* stack, const float4* pre_row = nullptr)
 {
     if constexpr (STACK == 0)
-        return ddn_row ? exhaustive_any<true>(bvh, r, ddn_row) : exhaustive_any<false>(bvh, r);  // wave-uniform choice
+        return pre_row ? exhaustive_any<true>(bvh, r, pre_row) : exhaustive_any<false>(bvh, r);  // wave-uniform choice
     else
         return traverse_any<STACK>(bvh, r, stack);
 }
@@ -739,21 +787,27 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_closes
 // Entry formats.  RMW (EXT model, next-event rays): (origin, tmin) (direction, tmax) (contribution, path id), 48 B.
 // !RMW (reference model): (origin, path id) (contribution, -), 32 B; direction = the light of the path's frame (LDS copy of the
 // batch's frame constants), tmin / tmax = kRayEps / kRayFar (lighting.h:39-47).
-// rows of (d.nA, d.nB) per frame slot in k_trace_any's table of fan-pair determinants
-constexpr uint32_t kDdnRow = kExhaustiveMax / 2;
+// k_trace_any's table of PairPre entries lives in dynamic LDS (pre_table_bytes(), passed at launch; 0 = no table): rows of
+// 2 * pairs + 1 float4 per frame slot -- the extra one shifts the banks, so that lanes reading the same pair of different frame
+// slots do not collide.  8 KB for the headline's 16-frame batches, 34 KB for a 64-frame batch of a sharded run.
+constexpr uint32_t kPreTableMaxBytes = 40u << 10;
+static inline uint32_t pre_table_bytes(uint32_t n_slots, uint32_t pairs)
+{
+    const uint64_t b = (uint64_t)n_slots * (2u * pairs + 1u) * sizeof(float4);
+    return (pairs && n_slots <= kMaxFrameSlots && b <= kPreTableMaxBytes) ? (uint32_t)b : 0u;
+}
 template <int STACK, bool RMW>
 __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_any(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded, uint32_t n_slots,
-                                                      uint64_t* guard, uint32_t* work, const FrameConst* frames)
+                                                      uint64_t* guard, uint32_t* work, const FrameConst* frames, uint32_t pre_bytes)
 {
+    extern __shared__ float4 lds_pre[];
     __shared__ uint32_t lds_stack[(STACK ? STACK : 1) * (STACK ? kBlock : 1)];
     __shared__ float4   lds_light[RMW ? 1 : kMaxFrameSlots];
-    // Reference model on the small-scene path: every shadow ray of a frame has the frame's light direction, so the determinants
-    // d.n of the fan pairs depend on (frame slot, pair) only.  They are computed once per workgroup -- the same dot3() on the same
-    // operands, the same bits -- and the pair loop reads them from LDS instead of spending six vector instructions per pair.
+    // reference model on the small-scene path: the direction-dependent part of the pair tests per (frame slot, pair), see PairPre
     constexpr bool      DDN = STACK == 0 && !RMW;
-    __shared__ float2   lds_ddn[DDN ? kMaxFrameSlots * kDdnRow : 1];
     uint32_t*           stack    = lds_stack + threadIdx.x;
-    const bool          use_ddn  = DDN && bvh.fan_pair_count <= kDdnRow && n_slots <= kMaxFrameSlots;
+    const uint32_t      pre_row  = 2u * bvh.fan_pair_count + 1u;  // float4 per frame slot
+    const bool          use_ddn  = DDN && pre_bytes != 0u;
     if (!RMW)
     {
         for (uint32_t k = threadIdx.x; k < n_slots && k < kMaxFrameSlots; k += kBlock)
@@ -767,7 +821,8 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_any(Bv
                 const uint32_t slot = e / np, k = e - slot * np;
                 const v3       d    = mk3(frames[slot].light_dir[0], frames[slot].light_dir[1], frames[slot].light_dir[2]);
                 const float*   rec  = fp + 20 * (size_t)k;  // (v0, e1, e2, e3, nA, nB, id, 0)
-                lds_ddn[slot * kDdnRow + k] = make_float2(dot3(d, mk3(rec[12], rec[13], rec[14])), dot3(d, mk3(rec[15], rec[16], rec[17])));
+                lds_pre[slot * pre_row + 2 * k]     = tri_pre(d, mk3(rec[12], rec[13], rec[14]), kRayEps, kRayFar);
+                lds_pre[slot * pre_row + 2 * k + 1] = tri_pre(d, mk3(rec[15], rec[16], rec[17]), kRayEps, kRayFar);
             }
         }
         __syncthreads();
@@ -823,9 +878,9 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_any(Bv
                 const float4 L = lds_light[good ? (pid >> kPidShift) : 0u];
                 r = make_ray(mk3(a.x, a.y, a.z), mk3(L.x, L.y, L.z), kRayEps, good ? kRayFar : 0.0f);  // malformed entry: empty interval
             }
-            const float2* ddn_row = use_ddn ? lds_ddn + (good ? (pid >> kPidShift) : 0u) * kDdnRow : nullptr;
+            const float4* row = use_ddn ? lds_pre + (good ? (pid >> kPidShift) : 0u) * pre_row : nullptr;
             if (STACK == 0) __builtin_amdgcn_s_setprio(0);
-            const bool occluded = trace_any_any_size<STACK>(bvh, r, stack, ddn_row);
+            const bool occluded = trace_any_any_size<STACK>(bvh, r, stack, row);
             if (STACK == 0) __builtin_amdgcn_s_setprio(3);
             if (!occluded)
             {
@@ -1230,8 +1285,9 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
     const BvhDev bw = for_grid(bvh, grid.x);
     // shadow rays share one direction per frame and retire early: the plain per-chunk kernel beats the refill variant here
     // (8.3 vs 10.5 ms on the 262 k-triangle scene when it was tried)
+    const uint32_t pre = (cfg.stack_entries == 0 && !mostly_unoccluded) ? pre_table_bytes(n_slots, bvh.fan_pair_count) : 0u;
 #define CAP_LAUNCH_ANY(S, R) \
-    hipLaunchKernelGGL((k_trace_any<S, R>), grid, dim3(kBlock), 0, cfg.stream, bw, q, target, pixels_padded, n_slots, guard, work, frames)
+    hipLaunchKernelGGL((k_trace_any<S, R>), grid, dim3(kBlock), pre, cfg.stream, bw, q, target, pixels_padded, n_slots, guard, work, frames, pre)
     if (cfg.stack_entries == 0)
     {
         if (mostly_unoccluded) CAP_LAUNCH_ANY(0, true); else CAP_LAUNCH_ANY(0, false);
