@@ -371,7 +371,11 @@ struct PairScaled
     TriScaled a, b;
     uint32_t  id;
 };
-__device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* base, uint32_t k)
+// ORG: every ray of the launch has the same origin (camera rays), so tvec = o - v0 and T = tvec.n of both triangles are the same
+// for every ray; org_tab holds them per pair -- (tvec, tvec.nA) (tvec.nB, -, -, -), computed once per workgroup with the operations
+// below -- and the loop reads them from LDS (one address for the whole wave) instead of spending nine vector instructions.
+template <bool ORG = false>
+__device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* base, uint32_t k, const float4* org_tab = nullptr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(4))) const RawPair ConstPair;
@@ -382,7 +386,15 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
 #endif
     const v3 v0 = mk3(p.f[0], p.f[1], p.f[2]), e1 = mk3(p.f[3], p.f[4], p.f[5]), e2 = mk3(p.f[6], p.f[7], p.f[8]),
              e3 = mk3(p.f[9], p.f[10], p.f[11]), na = mk3(p.f[12], p.f[13], p.f[14]), nb = mk3(p.f[15], p.f[16], p.f[17]);
-    const v3 tvec = r.o - v0;
+    v3    tvec;
+    float tna, tnb;
+    if (ORG)
+    {
+        const float4 c0 = org_tab[2 * k], c1 = org_tab[2 * k + 1];
+        tvec = mk3(c0.x, c0.y, c0.z), tna = c0.w, tnb = c1.x;
+    }
+    else
+        tvec = r.o - v0, tna = dot3(tvec, na), tnb = dot3(tvec, nb);
     const v3 q    = cross3(tvec, r.d);
     const float e2q = dot3(e2, q);  // U of the first triangle, V (before its negation) of the second
     PairScaled  o;
@@ -392,7 +404,7 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
         o.a.det = fabsf(ddn);
         o.a.U   = u2f(f2u(e2q) ^ (s ^ 0x80000000u));
         o.a.V   = u2f(f2u(dot3(e1, q)) ^ s);
-        o.a.T   = u2f(f2u(dot3(tvec, na)) ^ (s ^ 0x80000000u));
+        o.a.T   = u2f(f2u(tna) ^ (s ^ 0x80000000u));
     }
     {
         const float    ddn = dot3(r.d, nb);
@@ -400,7 +412,7 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
         o.b.det = fabsf(ddn);
         o.b.U   = u2f(f2u(dot3(e3, q)) ^ (s ^ 0x80000000u));
         o.b.V   = u2f(f2u(e2q) ^ s);
-        o.b.T   = u2f(f2u(dot3(tvec, nb)) ^ (s ^ 0x80000000u));
+        o.b.T   = u2f(f2u(tnb) ^ (s ^ 0x80000000u));
     }
     o.id = f2u(p.f[18]);
     return o;
@@ -415,8 +427,9 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
 // a tree instead of a sequential compare chain (measured faster: more independent instructions for the scheduler to
 // interleave); "(t, id) lexicographic minimum" is associative, so the tree gives the winner of the sequential rule.
 // rec_tab: where the winner's record is re-read from (bvh.tris_by_id, or its LDS copy).
+template <bool ORG = false>
 __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const float4* rec_tab, const Ray& r, float& best_t, float& best_u,
-                                                   float& best_v, uint32_t& best_gid)
+                                                   float& best_v, uint32_t& best_gid, const float4* org_tab = nullptr)
 {
     best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
     auto cand = [&](const TriScaled& s) {
@@ -450,7 +463,7 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const floa
     uint32_t       k  = 0;
     for (; k + 2 <= np; k += 2)
     {
-        const PairScaled p0 = pair_scaled(r, bvh.fan_pairs, k), p1 = pair_scaled(r, bvh.fan_pairs, k + 1);
+        const PairScaled p0 = pair_scaled<ORG>(r, bvh.fan_pairs, k, org_tab), p1 = pair_scaled<ORG>(r, bvh.fan_pairs, k + 1, org_tab);
         float            m01, m23;
         uint32_t         i01, i23;
         pair_cand(p0, m01, i01);
@@ -464,7 +477,7 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const floa
     }
     if (k < np)
     {
-        const PairScaled p0 = pair_scaled(r, bvh.fan_pairs, k);
+        const PairScaled p0 = pair_scaled<ORG>(r, bvh.fan_pairs, k, org_tab);
         float            m;
         uint32_t         im;
         pair_cand(p0, m, im);
@@ -2011,11 +2024,25 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
     __shared__ FrameConst lds_frames[kMaxFrameSlots];
     __shared__ float4     lds_shade[LDS ? 6 * kExhaustiveMax : 1];
     __shared__ float4     lds_rec[LDS ? 4 * kExhaustiveMax : 1];
+    constexpr bool        ORG = FIRST && LDS;  // camera rays of a small scene: per-pair origin terms from a table (pair_scaled<ORG>)
+    __shared__ float4     lds_org[ORG ? kExhaustiveMax : 1];
     if (LDS)
     {
         const uint32_t n = bvh.tri_count <= kExhaustiveMax ? bvh.tri_count : kExhaustiveMax;
         for (uint32_t k = threadIdx.x; k < 6 * n; k += kBlock) lds_shade[k] = a.scene.shade_tris[k];
         for (uint32_t k = threadIdx.x; k < 4 * n; k += kBlock) lds_rec[k] = bvh.tris_by_id[k];
+        if (ORG)
+        {
+            const v3     o  = mk3(a.cam.position[0], a.cam.position[1], a.cam.position[2]);
+            const float* fp = reinterpret_cast<const float*>(bvh.fan_pairs);
+            for (uint32_t k = threadIdx.x; k < bvh.fan_pair_count && 2 * k + 1 < kExhaustiveMax; k += kBlock)
+            {
+                const float* rec  = fp + 20 * (size_t)k;  // (v0, e1, e2, e3, nA, nB, id, 0)
+                const v3     tvec = o - mk3(rec[0], rec[1], rec[2]);
+                lds_org[2 * k]     = make_float4(tvec.x, tvec.y, tvec.z, dot3(tvec, mk3(rec[12], rec[13], rec[14])));
+                lds_org[2 * k + 1] = make_float4(dot3(tvec, mk3(rec[15], rec[16], rec[17])), 0.f, 0.f, 0.f);
+            }
+        }
     }
     stage_frames(a, lds_frames);  // ends with the workgroup barrier
     const float4* shade_tab = LDS ? lds_shade : a.scene.shade_tris;
@@ -2081,7 +2108,7 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
         // phases issue ahead of other waves' loops, so more memory operations are in flight per SIMD (closest 18.1 -> 17.5 ms;
         // the opposite assignment: no gain).
         __builtin_amdgcn_s_setprio(0);
-        exhaustive_closest(bvh, rec_tab, r, t, u, v, gid);
+        exhaustive_closest<ORG>(bvh, rec_tab, r, t, u, v, gid, lds_org);
         __builtin_amdgcn_s_setprio(3);
         STAMP(st, 1, true);  // triangle loop + winner's record
         const ShadePre pre = shade_prefetch<EXT, FIRST, CARRY>(a, lds_frames, active, pid, carried_r1, carried_r2);
