@@ -119,6 +119,7 @@ SYMBOLS = {
     "cap_geometry_materials": (_i, [_vp, _vp]),
     "cap_scene_upload_geometry": (_i, [_vp, _vp]),
     "cap_host_sah_build": (_i, [_vp, _u32, _vp, _vp, C.POINTER(_u32)]),
+    "cap_host_wide_build": (_i, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp]),
 }
 
 _LIB = None
@@ -228,6 +229,18 @@ def host_sah_build(tri_lo, tri_hi):
     depth = C.c_uint32()
     _check(lib().cap_host_sah_build(_p(boxes), n, _p(nodes), _p(order), C.byref(depth)), "cap_host_sah_build")
     return nodes[:max(n - 1, 0)], order, int(depth.value)
+
+
+def host_wide_build(nodes, n, scene_lo, scene_hi):
+    """Binary tree (host_sah_build's nodes) -> compressed 8-wide view: (wide nodes [count, 20] uint32, tri_src, depth, top)."""
+    nodes = np.ascontiguousarray(nodes, np.float32)
+    lo, hi = np.ascontiguousarray(scene_lo, np.float32), np.ascontiguousarray(scene_hi, np.float32)
+    wide = np.zeros((max(n, 1), 20), np.uint32)
+    src = np.zeros(max(n, 1), np.uint32)
+    info = np.zeros(3, np.uint32)
+    _check(lib().cap_host_wide_build(_p(nodes) if n > 1 else None, n, _p(lo), _p(hi), _p(wide), wide.shape[0], _p(src), _p(info)),
+           "cap_host_wide_build")
+    return wide[:int(info[0])], src[:n], int(info[1]), int(info[2])
 
 
 class Renderer:

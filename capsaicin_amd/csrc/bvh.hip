@@ -357,7 +357,20 @@ __global__ __launch_bounds__(kBlock) void k_gather_sorted(BvhBuildArgs a)
     const uint32_t g = a.leaf_tri[i];
     for (int k = 0; k < 4; ++k) a.tris_sorted[4 * (size_t)i + k] = a.tri_raw[4 * (size_t)g + k];
 }
+// Intersection records in the leaf order of the compressed 8-wide view (cap_wide.h): record i = leaf-order record tri_src[i].
+__global__ __launch_bounds__(kBlock) void k_gather_wide(const uint32_t* tri_src, const float4* tris_sorted, uint32_t n, float4* tris8)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = tri_src[i];
+    for (int k = 0; k < 4; ++k) tris8[4 * (size_t)i + k] = tris_sorted[4 * (size_t)s + k];
+}
 }  // namespace
+
+void launch_gather_wide(hipStream_t stream, const uint32_t* tri_src, const float4* tris_sorted, uint32_t n, float4* tris8)
+{
+    if (n) hipLaunchKernelGGL(k_gather_wide, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, tri_src, tris_sorted, n, tris8);
+}
 
 size_t bvh_radix_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 

@@ -55,6 +55,11 @@ struct BvhDev
     uint32_t      fan_pair_count, fan_single_count;
     int32_t       root;       // 0, or ~0 for a single triangle
     uint32_t      tri_count;  // 0 -> every ray misses
+    // compressed 8-wide view (cap_wide.h): 5 x float4 per node, breadth-first; 64-B intersection records in its own leaf order
+    const float4* nodes8;
+    const float4* tris8;
+    uint32_t      wide8_ok;   // built, and its depth fits the pair stacks of the wide kernels (LDS part + spill slice)
+    uint32_t      wide8_top;  // leading nodes a workgroup may stage in LDS (<= kWideTopNodes)
 };
 
 struct TextureDev

@@ -22,6 +22,8 @@ void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraD
                           const FrameConst* frames, uint32_t n_slots, float4* hits, uint32_t* work);
 // Closest hit for the extension-ray queue (rt_indirect.hlsl:173).
 void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits);
+// The same on the compressed 8-wide view of the tree (trace8.hip; needs bvh.wide8_ok).  work: kQueueClasses zeroed chunk-grab counters.
+void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work);
 // Any hit for the shadow-ray queue (lighting.h:48-61); unoccluded rays add contrib to target[plane index].
 // guard: 4 x uint64 {shaded vertices, malformed path ids seen by shade, by trace_any, last offender}
 // work: kQueueClasses zeroed chunk-grab counters for this launch (exhaustive path; may be NULL for the LBVH kernels)
@@ -102,6 +104,10 @@ void   launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a);
 // `leaf_tri` have been uploaded: intersection records into leaf order + the wide view.
 void launch_bvh_setup(hipStream_t stream, const BvhBuildArgs& a);
 void launch_bvh_finish_host(hipStream_t stream, const BvhBuildArgs& a);
+
+// Compressed 8-wide view (wide_builder.cpp builds the nodes on the host): intersection records into its leaf order.
+void     launch_gather_wide(hipStream_t stream, const uint32_t* tri_src, const float4* tris_sorted, uint32_t n, float4* tris8);
+uint32_t wide8_stack_pairs();  // (g_base, g_mask) entries a lane of the wide kernels can hold: the tree's depth - 1 must fit
 
 // ---- reconstruction chain (post.hip): Gather -> Accumulate -> BlurDisocclusion -> Blur -> Combine -> TAA ----
 struct PostSettingsDev  // SettingsComponent subset, gui_system.h:20-37

@@ -17,6 +17,8 @@
 
 #include "cap_kernels.h"
 #include "sah_builder.h"
+#include "wide_builder.h"
+#include "cap_wide.h"
 
 using namespace cap;
 
@@ -134,6 +136,10 @@ struct CapContext
     // BVH
     DevBuf<float4>   shade_tris, tris_sorted, nodes, tri_raw, tri_box;
     DevBuf<float4>   nodes4;                  // wide view of the tree, 8 float4 per internal node (bvh.hip k_node4)
+    DevBuf<float4>   nodes8, tris8;           // compressed 8-wide view (cap_wide.h) and its intersection records
+    DevBuf<uint32_t> wide_src;                // scratch: leaf-order index per wide-order record
+    uint32_t         wide8_depth = 0, wide8_top = 0, wide8_nodes = 0;
+    float            wide8_ms = 0.f;
     DevBuf<uint32_t> stack_spill;             // traversal-stack entries beyond the LDS part, per thread of the persistent grid
     DevBuf<float4>   fan_pairs, fan_singles;  // exhaustive path: fan-pair records (5 float4) and the unpaired triangles (4 float4)
     uint32_t         fan_pair_count = 0, fan_single_count = 0;
@@ -328,6 +334,11 @@ BvhDev bvh_dev(const CapContext* c)
     b.spill_threads = (uint32_t)(c->stack_spill.n / kSpillEntries);
     static const bool binary_only = getenv("CAP_BVH_BINARY") != nullptr;  // A/B switch: binary traversal kernels only
     b.wide_ok = !binary_only && c->stack_spill.p && c->tri_count >= 2 && 3u * ((c->bvh_info.max_depth + 1u) / 2u) <= kWideLdsEntries + kSpillEntries;
+    static const bool no_wide8 = getenv("CAP_NO_WIDE8") != nullptr;  // A/B switch: the 4-wide / binary kernels of round 1
+    b.nodes8 = c->nodes8.p, b.tris8 = c->tris8.p;
+    b.wide8_ok  = !no_wide8 && c->stack_spill.p && c->wide8_nodes != 0 && c->wide8_depth <= wide8_stack_pairs() + 1u &&
+                 c->wide8_depth <= kWideLdsEntries / 2u + kSpillEntries / 2u + 1u;
+    b.wide8_top = c->wide8_top;
     b.fan_pairs = c->fan_pairs.p, b.fan_singles = c->fan_singles.p;
     b.fan_pair_count = c->fan_pair_count, b.fan_single_count = c->fan_single_count;
     b.tri_count = c->tri_count;
@@ -642,6 +653,7 @@ int cap_bvh_build(CapContext* c)
     const bool sah = n >= 2 && (c->bvh_build_mode == CAP_BVH_BUILD_SAH || (c->bvh_build_mode == CAP_BVH_BUILD_AUTO && n > kExhaustiveMax));
     const auto wall0 = std::chrono::steady_clock::now();
     uint32_t   host_depth = 0;
+    std::vector<float> bnodes_host;  // the binary tree on the host, for the collapse into the compressed 8-wide view
     if (sah)
     {
         launch_bvh_setup(c->stream, a);
@@ -655,6 +667,7 @@ int cap_bvh_build(CapContext* c)
         HIP_TRY(hipMemcpy(c->nodes.p, tree.nodes.data(), sizeof(float) * tree.nodes.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->leaf_tri.p, tree.order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
         launch_bvh_finish_host(c->stream, a);
+        bnodes_host.swap(tree.nodes);
     }
     else
         launch_bvh_build(c->stream, a);
@@ -682,6 +695,33 @@ int cap_bvh_build(CapContext* c)
     if (bi.max_depth > 64)
         return fail(CAP_ERR_UNSUPPORTED, "LBVH depth %u exceeds the 64-entry traversal stack", bi.max_depth);
     bi.stack_entries = bi.max_depth <= 32 ? 32 : 64;
+    // Compressed 8-wide view of the same tree (cap_wide.h) for the extension- and shadow-ray kernels of scenes the exhaustive
+    // kernels do not take: collapsed on the host from the binary nodes (read back when the device built them).
+    c->wide8_nodes = c->wide8_depth = c->wide8_top = 0;
+    if (n >= 1)
+    {
+        const auto w0 = std::chrono::steady_clock::now();
+        if (n >= 2 && bnodes_host.empty())
+        {
+            bnodes_host.resize(16 * (size_t)(n - 1));
+            HIP_TRY(hipMemcpy(bnodes_host.data(), c->nodes.p, sizeof(float) * bnodes_host.size(), hipMemcpyDeviceToHost));
+        }
+        WideTree wt;
+        build_wide_tree(n >= 2 ? bnodes_host.data() : nullptr, n, bi.bounds_lo, bi.bounds_hi, wt);
+        const size_t wn = wt.nodes.size() / kWideNodeWords;
+        HIP_TRY(c->nodes8.ensure(5 * std::max<size_t>(wn + 1, kWideTopNodes)));
+        HIP_TRY(c->tris8.ensure(4 * (size_t)n));
+        HIP_TRY(c->wide_src.ensure(n));
+        HIP_TRY(hipMemcpy(c->nodes8.p, wt.nodes.data(), sizeof(uint32_t) * wt.nodes.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->wide_src.p, wt.tri_src.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+        launch_gather_wide(c->stream, c->wide_src.p, c->tris_sorted.p, n, c->tris8.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->wide8_nodes = (uint32_t)wn, c->wide8_depth = wt.depth, c->wide8_top = wt.top_nodes;
+        c->wide8_ms    = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        if (getenv("CAP_TRACE_LAUNCHES"))
+            fprintf(stderr, "[cap] wide view: %zu nodes, depth %u, top %u, %.1f ms\n", wn, wt.depth, wt.top_nodes, c->wide8_ms);
+    }
     // Exhaustive path (cap_set_traversal): triangles that come in fans (k, k + 1 share v0 and the edge v0->v2, as every
     // triangulated quad of an OBJ face does) are stored as one record, so the kernels compute tvec, q and the shared edge's dot
     // product once for both.  Same per-triangle arithmetic, same results; the pairing only depends on bit-equal vertices.
@@ -975,7 +1015,10 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             if (!fused && b < D)
             {
                 StageTimer t(c, ST_CLOSEST, st);
-                launch_trace_closest(cfg, bvh, sa.out, max_count, c->hits.p);
+                if (bvh.wide8_ok)  // bounce b + 1's slot of the fused kernels' grab counters is free on this path
+                    launch_trace_closest8(cfg, bvh, sa.out, max_count, c->hits.p, work_shade + (b + 1) * per_queue);
+                else
+                    launch_trace_closest(cfg, bvh, sa.out, max_count, c->hits.p);
                 ++c->stats.launches_trace_closest;
             }
         }

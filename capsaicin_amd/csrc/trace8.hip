@@ -1,0 +1,225 @@
+// trace8.hip — closest hit for the extension-ray queue (rt_indirect.hlsl:173; the driver's TraceRay in the reference) on the
+// compressed 8-wide view of the tree (cap_wide.h), gfx950.
+//
+// One ray per lane, persistent waves.  What this kernel is built around (profiles/r01_tree_path.txt: the 4-wide kernel kept the
+// CU's texture-address path busy 64 % of the launch and the vector ALU 38 %, with 11..35 % of the lanes doing useful work):
+//   * bytes per lane and step: 80 B for eight child boxes (five 16-B loads) instead of 112 B for four;
+//   * one stack entry per visited node (the rest of its node group, 8 B) instead of up to three: the LDS part of the stack is 8
+//     entries x 8 B per lane (16 KB per workgroup), deeper entries go to the thread's spill slice;
+//   * lane refill from a per-wave ray buffer in LDS: a wave's next 64-ray chunk is loaded into registers one chunk ahead (its
+//     chunk index comes from the class's work counter, grabbed one chunk ahead as in the fused kernels) and parked in LDS when
+//     the previous chunk has been handed out, so a lane that retires takes its next ray with two ds_reads instead of making the
+//     whole wave wait for a global round trip -- which is what allows refilling at 16 idle lanes instead of 28;
+//   * while-while: per iteration the wave runs either the node step (lanes with a node due) or the triangle step, whichever has
+//     enough lanes; the other lanes wait, so an iteration pays for one of the two bodies.
+// The hit rule (minimum t, ties to the lower triangle id; DESIGN.md "Intersection contract") is visit-order independent and the
+// boxes are conservative (wide_builder.cpp), so the records written are bit-identical to every other traversal of the build.
+#include "cap_kernels.h"
+#include "cap_wide_trace.h"
+
+namespace cap
+{
+#ifndef CAP_W8_LDS
+#define CAP_W8_LDS 8  // LDS stack entries (8 B) per lane
+#endif
+#ifndef CAP_W8_BLOCKS
+#define CAP_W8_BLOCKS 6  // workgroups per CU the kernel is register-allocated for
+#endif
+#ifndef CAP_W8_REFILL
+#define CAP_W8_REFILL 16  // refill once this many lanes are idle
+#endif
+constexpr int      kW8Lds       = CAP_W8_LDS;
+// pair-stack capacity the host checks the wide tree's depth against (LDS part + the thread's spill slice)
+constexpr uint32_t kW8StackPairs = (uint32_t)kW8Lds + kSpillEntries / 2u;
+
+// Diagnostic build only (make EXTRA=-DCAP_W8_COUNT): lane- and wave-level step counts of the closest-hit kernel, read by
+// tools/w8_counts.py: [0] node steps (lanes), [1] triangle tests (lanes), [2] node-phase iterations (waves), [3] triangle-phase
+// iterations (waves), [4] rays, [5] loop iterations (waves), [6] stack pushes, [7] spilled pushes
+#ifdef CAP_W8_COUNT
+__device__ unsigned long long g_w8_counts[8];
+#define W8_COUNT(i, v) (cnt[i] += (v))
+#else
+#define W8_COUNT(i, v) ((void)0)
+#endif
+
+__global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev bvh, RayQueue q, float4* hits, uint32_t* work, uint32_t refill_idle)
+{
+    __shared__ uint2  lds_stack[kW8Lds * kBlock];
+    __shared__ float4 lds_rays[2 * kBlock];  // per wave: 64 x (origin, tmin) then 64 x (direction, tmax)
+    const uint32_t lane = threadIdx.x & 63u;
+    float4* const  rbuf = lds_rays + (threadIdx.x >> 6) * 128u;
+    const uint32_t my_class = wave_global_id() % kQueueClasses;
+    uint32_t       n_class  = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.count[my_class * kCounterStride]);
+    n_class                 = n_class < q.class_capacity ? n_class : q.class_capacity;
+
+    // ---- feed: chunk j of this wave's class, one chunk ahead in registers (pa, pb), the current one in LDS (rbuf) ----
+    uint32_t grab   = grab_issue(work, my_class);
+    uint32_t pend_n = 0, pend_base = 0, buf_n = 0, buf_pos = 0, buf_base = 0;
+    float4   pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+    auto     fetch = [&]() {  // wave-uniform
+        const uint32_t start = grab_value(grab) * 64u;
+        pend_n               = 0;
+        if (start >= n_class) return;  // past the end of this class's sub-queue: the feed has ended
+        pend_n    = n_class - start < 64u ? n_class - start : 64u;
+        pend_base = my_class * q.class_capacity + start;
+        if (lane < pend_n) pa = q.org_tmin[pend_base + lane], pb = q.dir_tmax[pend_base + lane];
+        grab = grab_issue(work, my_class);
+    };
+    fetch();
+
+    WideStack<kW8Lds> st{lds_stack + threadIdx.x, wide_spill_of_thread(bvh), 0};
+    bool              alive = false;
+    Ray               r     = make_ray(mk3(0, 0, 0), mk3(0, 0, 1), 0.f, 0.f);
+    WideRay           w     = make_wide_ray(r.o, r.d);
+    WideCursor        c;
+    wide_cursor_root(c);
+    float    best_t = 0.f, best_u = 0.f, best_v = 0.f;
+    uint32_t best_gid = kInvalidId, out = 0;
+#ifdef CAP_W8_COUNT
+    unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    while (true)
+    {
+        W8_COUNT(5, lane == 0 ? 1 : 0);
+        unsigned long long m_alive = __ballot(alive);
+        if (64u - (uint32_t)__popcll(m_alive) >= refill_idle)
+        {
+            // hand rays to idle lanes: the rest of the parked chunk, then (once) the start of the next one
+            for (int rep = 0; rep < 2; ++rep)
+            {
+                if (buf_pos >= buf_n)
+                {
+                    if (pend_n == 0) break;
+                    if (lane < pend_n) rbuf[lane] = pa, rbuf[64u + lane] = pb;
+                    buf_n = pend_n, buf_pos = 0, buf_base = pend_base;
+                    fetch();
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const unsigned long long idle = ~m_alive;
+                const uint32_t n_idle = (uint32_t)__popcll(idle), avail = buf_n - buf_pos;
+                const uint32_t take   = avail < n_idle ? avail : n_idle;
+                const uint32_t rank   = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!alive && rank < take)
+                {
+                    const uint32_t e = buf_pos + rank;
+                    const float4   a = rbuf[e], b = rbuf[64u + e];
+                    r      = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
+                    w      = make_wide_ray(r.o, r.d);
+                    best_t = r.tmax, best_u = 0.f, best_v = 0.f, best_gid = kInvalidId;
+                    out    = buf_base + e;
+                    wide_cursor_root(c);
+                    st.sp = 0, alive = true;
+                    W8_COUNT(4, 1);
+                }
+                buf_pos += take;
+                m_alive = __ballot(alive);
+                if (m_alive == ~0ull) break;
+            }
+        }
+        if (m_alive == 0ull)
+        {
+            if (buf_pos >= buf_n && pend_n == 0) break;  // feed ended and every lane retired
+            continue;
+        }
+        // invariant: an alive lane has a triangle or a node due.  ONE load sequence serves both kinds of lane: a divergent 16-B
+        // load costs the CU's texture-address path the same ~29 cycles whether 10 or 64 lanes take part (it works in quads of
+        // lanes, and the lanes of either kind are scattered over all quads), and those cycles are what bounds this kernel
+        // (measured: three extra 16-B loads per node step cost 1.8 ms; serving 45 % of the node steps from an LDS copy of the
+        // top levels, lane by lane, saved nothing).  So a lane with a triangle due fetches its 64-B record with the first four
+        // of the five loads a node lane needs, and both tests run on what arrived.
+        const bool     tri_lane = alive && c.t_hits != 0u, node_lane = alive && c.t_hits == 0u;
+        const float4*  src      = bvh.nodes8;
+        if (tri_lane)
+        {
+            src = bvh.tris8 + 4 * (size_t)wide_pick_triangle(c);
+            W8_COUNT(1, 1);
+        }
+        else if (node_lane)
+        {
+            bool           rest;
+            const uint32_t node = wide_pick_child(c, w.octinv, rest);
+            W8_COUNT(0, 1);
+            W8_COUNT(6, rest ? 1 : 0);
+            if (rest) st.push(c.g_base, c.g_mask);
+            src = bvh.nodes8 + 5 * (size_t)node;
+        }
+        W8_COUNT(2, lane == 0 ? 1 : 0);
+        WideNode nd;
+        nd.h0 = nd.h1 = nd.q2 = nd.q3 = nd.q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (alive) nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2], nd.q3 = src[3];
+        if (node_lane) nd.q4 = src[4];
+        if (tri_lane)
+        {
+            float t, u, v;
+            if (tri_test(r, nd.h0, nd.h1, nd.q2, t, u, v))
+            {
+                const uint32_t gid = f2u(nd.q3.x);
+                if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+            }
+        }
+        if (node_lane) wide_node_test(nd, w, r.tmin, best_t, c);
+        // a lane with nothing due takes the next node group off its stack, or retires
+        if (alive && c.t_hits == 0u && (c.g_mask >> 24) == 0u)
+        {
+            if (st.sp == 0)
+            {
+                hits[out] = make_float4(best_u, best_v, u2f(best_gid), best_t);
+                alive     = false;
+            }
+            else
+                st.pop(c);
+        }
+    }
+#ifdef CAP_W8_COUNT
+    for (int i = 0; i < 8; ++i)
+    {
+        unsigned long long v = cnt[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0 && v) atomicAdd(&g_w8_counts[i], v);
+    }
+#endif
+}
+
+#ifdef CAP_W8_COUNT
+extern "C" int cap_debug_w8_counts(unsigned long long* out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w8_counts), sizeof(g_w8_counts));
+    if (e == hipSuccess && reset)
+    {
+        unsigned long long z[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_w8_counts), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
+
+// no geometry: every queued ray misses
+__global__ __launch_bounds__(kBlock) void k_trace_closest8_empty(RayQueue q, float4* hits)
+{
+    const uint32_t slots = (q.class_capacity >> 6) * kQueueClasses;
+    for (uint32_t cs = wave_global_id(); cs < slots; cs += wave_total())
+    {
+        uint32_t i, klass;
+        if (queue_chunk(q.count, q.class_capacity, cs, threadIdx.x & 63u, i, klass)) hits[i] = make_float4(0.f, 0.f, u2f(kInvalidId), 0.f);
+    }
+}
+
+uint32_t wide8_stack_pairs() { return kW8StackPairs; }
+
+void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work)
+{
+    uint32_t g = (max_count + kBlock - 1) / kBlock;
+    static const uint32_t per_cu = getenv("CAP_W8_GRID") ? (uint32_t)atoi(getenv("CAP_W8_GRID")) : (uint32_t)CAP_W8_BLOCKS;  // A/B switch
+    uint32_t cap = cfg.cu_count ? cfg.cu_count * per_cu : cfg.grid_blocks;
+    if ((uint64_t)cap * kBlock > bvh.spill_threads) cap = bvh.spill_threads / kBlock;  // every thread owns a spill slice
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    if (bvh.tri_count == 0)
+    {
+        hipLaunchKernelGGL(k_trace_closest8_empty, dim3(g), dim3(kBlock), 0, cfg.stream, q, hits);
+        return;
+    }
+    static const uint32_t refill = getenv("CAP_W8_REFILL") ? (uint32_t)atoi(getenv("CAP_W8_REFILL")) : (uint32_t)CAP_W8_REFILL;
+    hipLaunchKernelGGL(k_trace_closest8, dim3(g), dim3(kBlock), 0, cfg.stream, bvh, q, hits, work, refill);
+}
+}  // namespace cap

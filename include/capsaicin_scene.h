@@ -54,6 +54,15 @@ int cap_scene_upload_geometry(CapContext* ctx, const CapGeometry* g);
  * ~leaf position); order: n triangle ids in leaf order; depth: internal nodes on the longest root-to-leaf path. */
 int cap_host_sah_build(const float* tri_boxes, uint32_t n, float* nodes, uint32_t* order, uint32_t* depth);
 
+/* Host-side collapse of that binary tree into the compressed 8-wide view the extension- and shadow-ray kernels walk
+ * (capsaicin_amd/csrc/cap_wide.h; replaces, with the build above, the driver's acceleration-structure build behind
+ * blas_system.cpp:65 / tlas_system.cpp:72), callable without a GPU.  nodes: the n - 1 binary nodes as above (NULL when n < 2);
+ * scene_lo / scene_hi: bounds of all triangles.  wide_nodes: room for wide_capacity nodes of 20 uint32 each (n nodes always
+ * suffice); tri_src: n entries, wide-order triangle record i = leaf position tri_src[i]; info: {node count, depth, leading
+ * nodes that form the top levels}.  CAP_ERR_INVALID_ARG when the capacity is too small. */
+int cap_host_wide_build(const float* nodes, uint32_t n, const float* scene_lo, const float* scene_hi, uint32_t* wide_nodes,
+                        uint32_t wide_capacity, uint32_t* tri_src, uint32_t* info);
+
 #ifdef __cplusplus
 }
 #endif

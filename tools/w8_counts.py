@@ -1,0 +1,45 @@
+"""Step counts of the wide closest-hit kernel on the 262 k-triangle scene (diagnostic build: make -C capsaicin_amd/csrc -B
+EXTRA=-DCAP_W8_COUNT).  python tools/w8_counts.py  -> per-ray node steps / triangle tests, lane utilisation of the two phases,
+and the traversal bytes (B) of SURVEY.md 8d per ray."""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from capsaicin_amd import capi  # noqa: E402
+
+
+def main():
+    lib = capi.lib()
+    if not hasattr(lib, "cap_debug_w8_counts"):
+        raise SystemExit("needs the diagnostic build: make -C capsaicin_amd/csrc -B EXTRA=-DCAP_W8_COUNT")
+    r = capi.Renderer(0)
+    cam = bench.load_sponza_class(r)
+    r.upload_bluenoise(capi.load_bluenoise())
+    r.build_bvh()
+    r.set_resolution(bench.WIDTH, bench.HEIGHT)
+    r.set_camera(cam)
+    out = (ctypes.c_ulonglong * 8)()
+    r.render(0, 16, bench.DEPTH, 0)
+    r.sync()
+    lib.cap_debug_w8_counts(out, 1)
+    r.stats_reset()
+    r.accum_reset()
+    r.render(0, 16, bench.DEPTH, 0)
+    r.sync()
+    s = r.stats()
+    lib.cap_debug_w8_counts(out, 1)
+    nodes, tris, it_node, it_tri, rays, iters, pushes, spills = (int(x) for x in out)
+    res = {"rays": rays, "rays_extension": int(s.rays_extension), "node_steps_per_ray": nodes / rays, "triangle_tests_per_ray": tris / rays,
+           "lanes_per_node_iteration": nodes / max(1, it_node), "lanes_per_triangle_iteration": tris / max(1, it_tri),
+           "node_iterations": it_node, "triangle_iterations": it_tri, "loop_iterations": iters,
+           "pushes_per_ray": pushes / rays, "spilled_push_fraction": spills / max(1, pushes),
+           "traversal_bytes_per_ray": 80 * nodes / rays + 64 * tris / rays}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
