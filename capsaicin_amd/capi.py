@@ -175,17 +175,41 @@ def load_bluenoise(path=None):
     return np.fromfile(path, np.uint8).reshape(256, 256, 4)
 
 
-def cornell_camera(width, height):
-    """The Cornell-box view fixed by SURVEY.md 8d (basis from input_system.cpp:134-141, aspect rule camera_system.cpp:10-17)."""
+_SCENE_CONFIG = None
+
+
+def scene_config():
+    """assets/scene_config.json: the scene constants of the benchmark workloads that the reference does not fix."""
+    global _SCENE_CONFIG
+    if _SCENE_CONFIG is None:
+        import json
+        cfg = json.load(open(os.path.join(os.path.dirname(_PKG), "assets", "scene_config.json")))
+        cfg["cornell_ggx"] = {k: v for k, v in cfg["cornell_ggx"].items() if not k.startswith("_")}
+        _SCENE_CONFIG = cfg
+    return _SCENE_CONFIG
+
+
+def camera_from_config(c, width, height):
+    """CameraData from a config entry; right / up by the reference's own formulas when absent (input_system.cpp:134-141)."""
     cam = CameraData()
-    cam.position[:] = (-0.01, 0.995, 3.4)
-    cam.forward[:] = (0.0, 0.0, -1.0)
-    cam.right[:] = (-1.0, 0.0, 0.0)
-    cam.up[:] = (0.0, 1.0, 0.0)
-    cam.focal_length = 0.035
-    cam.sensor_size[0] = 0.036
-    cam.sensor_size[1] = np.float32(0.036) * (np.float32(height) / np.float32(width))
+    f = np.float64(c["forward"])
+    f /= np.linalg.norm(f)
+    right = np.float64(c["right"]) if "right" in c else -np.cross(f, (0.0, 1.0, 0.0))
+    right /= np.linalg.norm(right)
+    up = np.float64(c["up"]) if "up" in c else np.cross(f, right)
+    cam.position[:] = c["position"]
+    cam.forward[:] = f
+    cam.right[:] = right
+    cam.up[:] = up
+    cam.focal_length = c["focal_length"]
+    cam.sensor_size[0] = c["sensor_x"]
+    cam.sensor_size[1] = np.float32(c["sensor_x"]) * (np.float32(height) / np.float32(width))  # camera_system.cpp:10-17
     return cam
+
+
+def cornell_camera(width, height):
+    """The Cornell-box view fixed by SURVEY.md 8d (assets/scene_config.json)."""
+    return camera_from_config(scene_config()["cornell_camera"], width, height)
 
 
 class Geometry:

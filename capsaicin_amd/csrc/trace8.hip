@@ -33,8 +33,8 @@ constexpr int      kW8Lds       = CAP_W8_LDS;
 constexpr uint32_t kW8StackPairs = (uint32_t)kW8Lds + kSpillEntries / 2u;
 
 // Diagnostic build only (make EXTRA=-DCAP_W8_COUNT): lane- and wave-level step counts of the closest-hit kernel, read by
-// tools/w8_counts.py: [0] node steps (lanes), [1] triangle tests (lanes), [2] node-phase iterations (waves), [3] triangle-phase
-// iterations (waves), [4] rays, [5] loop iterations (waves), [6] stack pushes, [7] spilled pushes
+// tools/w8_counts.py: [0] node steps (lanes), [1] triangle tests (lanes), [2] load sequences (wave iterations with live lanes),
+// [3] node steps on the first kWideTopNodes nodes, [4] rays, [5] loop iterations (waves), [6] stack pushes, [7] spilled pushes
 #ifdef CAP_W8_COUNT
 __device__ unsigned long long g_w8_counts[8];
 #define W8_COUNT(i, v) (cnt[i] += (v))
@@ -140,6 +140,8 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
             const uint32_t node = wide_pick_child(c, w.octinv, rest);
             W8_COUNT(0, 1);
             W8_COUNT(6, rest ? 1 : 0);
+            W8_COUNT(7, (rest && st.sp >= kW8Lds) ? 1 : 0);
+            W8_COUNT(3, node < kWideTopNodes ? 1 : 0);
             if (rest) st.push(c.g_base, c.g_mask);
             src = bvh.nodes8 + 5 * (size_t)node;
         }

@@ -944,9 +944,9 @@ void shade_pixel_ext(const Scene& sc, const OracleCamera& cam, const uint8_t* bn
 
 void render_rows(const Scene& sc, const OracleCamera& cam, const uint8_t* bn, uint32_t w, uint32_t h, uint32_t frame,
                  uint32_t bounces, bool use_bvh, bool ext, uint32_t row0, uint32_t row_step, OracleFrameOutputs* out, uint64_t rays[3],
-                 const Feedback* fb, bool lowres)
+                 const Feedback* fb, bool lowres, uint32_t row_end)
 {
-    for (uint32_t y = row0; y < h; y += row_step)
+    for (uint32_t y = row0; y < row_end; y += row_step)
         for (uint32_t x = 0; x < w; ++x)
         {
             PixelOut po;
@@ -1019,10 +1019,14 @@ void* oracle_scene_create(const OracleScene* s)
 
 void oracle_scene_destroy(void* h) { delete (Scene*)h; }
 
+// rows [y0, y1) of the frame are rendered (the whole frame: 0, h); pixels outside keep what the output buffers held
 static int render_frame_impl(void* scene, const OracleCamera* cam, const uint8_t* bn, uint32_t w, uint32_t h, uint32_t frame_count,
-                             uint32_t num_bounces, uint32_t flags, uint32_t num_threads, OracleFrameOutputs* out, const Feedback* fb)
+                             uint32_t num_bounces, uint32_t flags, uint32_t num_threads, OracleFrameOutputs* out, const Feedback* fb,
+                             uint32_t y0 = 0, uint32_t y1 = ~0u)
 {
     if (!scene || !cam || !bn || !out || !w || !h) return 1;
+    y1 = std::min(y1, h);
+    if (y0 >= y1) return 1;
     const Scene& sc = *(const Scene*)scene;
     bool     bvh = (flags & ORACLE_FLAG_USE_BVH) != 0;
     bool     ext = (flags & ORACLE_FLAG_EXT_MATERIALS) != 0;
@@ -1030,13 +1034,13 @@ static int render_frame_impl(void* scene, const OracleCamera* cam, const uint8_t
     if (ext && fb) return 3;                                        // the feedback branch belongs to the reference model
     const bool lowres = (flags & ORACLE_FLAG_LOWRES_INDIRECT) != 0;
     if (lowres && (ext || (w & 1u) || (h & 1u))) return 4;          // half-resolution indirect: reference model, even extents
-    uint32_t nt  = std::max(1u, std::min(num_threads, h));
+    uint32_t nt  = std::max(1u, std::min(num_threads, y1 - y0));
     std::vector<uint64_t> rays(3 * (size_t)nt, 0);
     std::vector<std::thread> th;
     for (uint32_t t = 1; t < nt; ++t)
-        th.emplace_back(render_rows, std::cref(sc), std::cref(*cam), bn, w, h, frame_count, num_bounces, bvh, ext, t, nt, out,
-                        rays.data() + 3 * t, fb, lowres);
-    render_rows(sc, *cam, bn, w, h, frame_count, num_bounces, bvh, ext, 0, nt, out, rays.data(), fb, lowres);
+        th.emplace_back(render_rows, std::cref(sc), std::cref(*cam), bn, w, h, frame_count, num_bounces, bvh, ext, y0 + t, nt, out,
+                        rays.data() + 3 * t, fb, lowres, y1);
+    render_rows(sc, *cam, bn, w, h, frame_count, num_bounces, bvh, ext, y0, nt, out, rays.data(), fb, lowres, y1);
     for (auto& t : th) t.join();
     out->rays[0] = out->rays[1] = out->rays[2] = 0;
     for (uint32_t t = 0; t < nt; ++t)
@@ -1048,6 +1052,13 @@ int oracle_render_frame(void* scene, const OracleCamera* cam, const uint8_t* bn,
                         uint32_t num_bounces, uint32_t flags, uint32_t num_threads, OracleFrameOutputs* out)
 {
     return render_frame_impl(scene, cam, bn, w, h, frame_count, num_bounces, flags, num_threads, out, nullptr);
+}
+
+// Rows [y0, y1) only: oracle crops of frames too large to restate whole in a test (BASELINE configs 3 and 5).
+int oracle_render_frame_rows(void* scene, const OracleCamera* cam, const uint8_t* bn, uint32_t w, uint32_t h, uint32_t frame_count,
+                             uint32_t num_bounces, uint32_t flags, uint32_t num_threads, uint32_t y0, uint32_t y1, OracleFrameOutputs* out)
+{
+    return render_frame_impl(scene, cam, bn, w, h, frame_count, num_bounces, flags, num_threads, out, nullptr, y0, y1);
 }
 
 int oracle_render_frame_feedback(void* scene, const OracleCamera* cam, const OracleCamera* prev_cam, const uint8_t* bn, uint32_t w,

@@ -119,6 +119,10 @@ int oracle_render_frame(void* scene, const OracleCamera* cam, const uint8_t* blu
 /* The same frame with the G-buffer feedback branch on (RaytracingOptions::gbuffer_feedback, raytracing_system.h:26;
  * rt_indirect.hlsl:116-145): prev_normal_depth and color_history are the previous frame's gbuffer_normal_depth and
  * reconstruction output (W*H*4 floats each, zero-filled before the first frame).  Reference shading model only. */
+/* rows [y0, y1) only; pixels outside keep what the output buffers held, rays[] counts the rendered rows */
+int oracle_render_frame_rows(void* scene, const OracleCamera* cam, const uint8_t* bluenoise_rgba8, uint32_t width, uint32_t height,
+                             uint32_t frame_count, uint32_t num_bounces, uint32_t flags, uint32_t num_threads, uint32_t y0, uint32_t y1,
+                             OracleFrameOutputs* out);
 int oracle_render_frame_feedback(void* scene, const OracleCamera* cam, const OracleCamera* prev_cam, const uint8_t* bluenoise_rgba8,
                                  uint32_t width, uint32_t height, uint32_t frame_count, uint32_t num_bounces, uint32_t flags,
                                  uint32_t num_threads, const float* prev_normal_depth, const float* color_history,

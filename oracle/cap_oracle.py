@@ -63,6 +63,7 @@ def lib():
         L.oracle_scene_create.argtypes = [C.POINTER(SceneDesc)]
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
         L.oracle_render_frame.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_uint32] * 6 + [C.POINTER(FrameOutputs)]
+        L.oracle_render_frame_rows.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_uint32] * 8 + [C.POINTER(FrameOutputs)]
         L.oracle_render_frame_feedback.argtypes = ([C.c_void_p, C.POINTER(Camera), C.POINTER(Camera), C.c_void_p] + [C.c_uint32] * 6 +
                                                    [C.c_void_p, C.c_void_p, C.POINTER(FrameOutputs)])
         L.oracle_render_accumulate.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p, C.c_void_p]
@@ -134,8 +135,9 @@ class Scene:
             lib().oracle_scene_destroy(self.h)
             self.h = None
 
-    def render_frame(self, cam, bluenoise, width, height, frame_count, num_bounces, flags=0, threads=1, feedback=None):
-        """feedback = (prev_cam, prev_normal_depth, color_history) turns the G-buffer feedback branch on (rt_indirect.hlsl:116-145)."""
+    def render_frame(self, cam, bluenoise, width, height, frame_count, num_bounces, flags=0, threads=1, feedback=None, rows=None):
+        """feedback = (prev_cam, prev_normal_depth, color_history) turns the G-buffer feedback branch on (rt_indirect.hlsl:116-145).
+        rows = (y0, y1): only those rows are rendered (the rest of every plane stays zero; rays counts the rendered rows)."""
         names = ("gbuffer_geo", "direct", "albedo", "normal_depth", "indirect", "combined")
         bufs = {n: np.zeros((height, width, 4), np.float32) for n in names}
         out = FrameOutputs()
@@ -151,6 +153,9 @@ class Scene:
             assert pnd.shape == hist.shape == (height, width, 4)
             rc = lib().oracle_render_frame_feedback(self.h, C.byref(cam), C.byref(prev_cam), _p(bn), width, height, frame_count, num_bounces,
                                                     flags, threads, _p(pnd), _p(hist), C.byref(out))
+        elif rows is not None:
+            rc = lib().oracle_render_frame_rows(self.h, C.byref(cam), _p(bn), width, height, frame_count, num_bounces, flags, threads,
+                                                int(rows[0]), int(rows[1]), C.byref(out))
         else:
             rc = lib().oracle_render_frame(self.h, C.byref(cam), _p(bn), width, height, frame_count, num_bounces, flags, threads, C.byref(out))
         if rc:

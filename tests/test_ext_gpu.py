@@ -33,9 +33,9 @@ def test_ext_cornell_parity(native_lib, bluenoise, tmp_path, ggx):
     from oracle import cap_oracle as O
     geo, mats = cornell_with_materials(tmp_path)
     if ggx:  # BASELINE configs[1]/[4]: "Lambert+GGX": make the two boxes and the back wall glossy
-        for m, (rough, ks) in {1: (0.25, 0.6), 6: (0.45, 0.4), 3: (0.15, 0.8)}.items():
-            mats[m, 3] = rough
-            mats[m, 4:7] = ks
+        for m, (rough, ks) in capi.scene_config()["cornell_ggx"].items():
+            mats[int(m), 3] = rough
+            mats[int(m), 4:7] = ks
     w, h, D = 96, 80, 5
     r = capi.Renderer(0)
     r.upload_geometry(geo)

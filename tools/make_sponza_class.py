@@ -200,7 +200,10 @@ def write(out_dir, scale=1.0, tex_size=1024):
 
 def camera():
     """Viewpoint used by tests and the extra bench line: inside the hall, looking down its length."""
-    return dict(position=(-10.5, 2.2, 0.6), forward=(0.98058068, 0.19611614, 0.0), focal_length=0.022)
+    import json
+    cfg = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "scene_config.json")))
+    c = cfg["sponza_class"]["camera"]
+    return dict(position=tuple(c["position"]), forward=tuple(c["forward"]), focal_length=c["focal_length"])
 
 
 if __name__ == "__main__":

@@ -32,11 +32,12 @@ def main():
     r.sync()
     s = r.stats()
     lib.cap_debug_w8_counts(out, 1)
-    nodes, tris, it_node, it_tri, rays, iters, pushes, spills = (int(x) for x in out)
+    nodes, tris, seqs, top, rays, iters, pushes, spills = (int(x) for x in out)
     res = {"rays": rays, "rays_extension": int(s.rays_extension), "node_steps_per_ray": nodes / rays, "triangle_tests_per_ray": tris / rays,
-           "lanes_per_node_iteration": nodes / max(1, it_node), "lanes_per_triangle_iteration": tris / max(1, it_tri),
-           "node_iterations": it_node, "triangle_iterations": it_tri, "loop_iterations": iters,
-           "pushes_per_ray": pushes / rays, "spilled_push_fraction": spills / max(1, pushes),
+           "lanes_per_load_sequence": (nodes + tris) / max(1, seqs), "load_sequences": seqs, "loop_iterations": iters,
+           "node_steps_on_top_levels": top / max(1, nodes), "pushes_per_ray": pushes / rays,
+           "spilled_push_fraction": spills / max(1, pushes),
+           # nodes visited x node size + triangles tested x record size
            "traversal_bytes_per_ray": 80 * nodes / rays + 64 * tris / rays}
     print(json.dumps(res))
 
