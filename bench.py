@@ -23,6 +23,58 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 64, 8
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.3 TB/s is the measured achievable stream rate
 BYTES_CLOSEST, BYTES_ANY, BYTES_VERTEX = 48, 36, 144  # SURVEY.md 8d algorithmic queue-stream bytes per ray / shaded vertex
+# vector-instruction issue peak: one wave64 instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz (MI355X_MICROARCH.md)
+VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0
+KERNEL_SOURCES = ("kernels.hip", "trace8.hip", "cap_trace.h", "cap_wide_trace.h", "cap_device.h", "cap_math.h", "context.hip",
+                  "wide_builder.cpp", "sah_builder.cpp")
+
+
+def kernel_source_sha():
+    """Hash of the sources the profiled kernels are built from: committed counter files are only quoted while it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "capsaicin_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def committed_counters(key):
+    """Per-launch HBM bytes / vector instructions of one kernel from the newest profiles/rNN_traffic.json (PMC passes of this very
+    command, tools/make_traffic.py; counters cannot be collected from inside the timed process).  None when the kernel sources
+    have changed since the passes were taken."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        tj = json.load(open(files[-1]))
+        if tj.get("source_sha256") != kernel_source_sha():
+            return None, os.path.relpath(files[-1], ROOT) + " (stale: kernel sources changed since)"
+        return tj["kernels"].get(key), os.path.relpath(files[-1], ROOT)
+    except Exception:  # a malformed file must not break the bench line
+        return None, None
+
+
+def roofline_object(kernel_name, counters_key, kernel_bytes, launches, kernel_ms, rays, extra=None, quote_counters=True):
+    """The `roofline` object of the bench contract for one kernel: achieved = algorithmic bytes per launch / average launch
+    duration (HIP events on the render stream).  `bound` names the limiter the counters show; the HBM fraction stays `frac`."""
+    avg_ms = kernel_ms / launches
+    bytes_per_launch = kernel_bytes / launches
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    pmc, src = committed_counters(counters_key) if quote_counters else (None, None)
+    traffic = pmc["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 if pmc else None
+    valu = None
+    if pmc and pmc.get("valu_insts_per_launch"):
+        valu = {"wave_insts_per_launch": pmc["valu_insts_per_launch"], "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
+                "issue_frac": pmc["valu_insts_per_launch"] / (avg_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S}
+    o = {"bound": "valu", "bound_note": "vector-instruction issue (+ exposed latency), not HBM: see `valu` and DESIGN.md 5; "
+                                        "achieved / peak / frac are the contract's algorithmic HBM bytes against the 8 TB/s peak",
+         "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_source": src, "valu": valu, "avg_launch_ms": avg_ms, "launches": int(launches),
+         "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_ray": kernel_bytes / max(1, rays),
+         "rays_per_launch": rays / launches, "kernel_mrays_per_s": rays / (kernel_ms * 1e-3) / 1e6}
+    if extra:
+        o.update(extra)
+    return o
 
 
 def cpu_baseline(budget_s=12.0):
@@ -209,37 +261,22 @@ def main():
         roofline = None
         if rank == 0 and sp.launches_trace_closest:
             fused = sp.launches_shade == 0
-            avg_ms = sp.ms_trace_closest / sp.launches_trace_closest
+            SH_ENTRY = 32  # reference-model shadow entry: (origin, path id) + (contribution, -); see DESIGN.md "Data layout"
             if fused:
                 # k_trace_shade (bounce >= 1): reads one 48-B queue entry (ray 32 + throughput/path id 16) per extension ray,
-                # writes one 48-B extension entry and one 48-B shadow entry per ray it emits (DESIGN.md "algorithmic bytes")
+                # writes one 48-B extension entry and one 32-B shadow entry per ray it emits (DESIGN.md "algorithmic bytes")
                 ext_out = sp.rays_extension - sp.rays_extension_bounce0
                 sh_out = sp.rays_shadow - sp.rays_shadow_bounce0
-                SH_ENTRY = 32  # reference-model shadow entry: (origin, path id) + (contribution, -); see DESIGN.md "Data layout"
                 kernel_bytes = 48 * sp.rays_extension + 48 * ext_out + SH_ENTRY * sh_out
-                kernel_name = "k_trace_shade<bounce>=1> (exhaustive closest hit + shading, fused)"
+                kernel_name, key = "k_trace_shade<bounce>=1> (exhaustive closest hit + shading, fused)", "headline"
                 # + bounce-0 kernel (3 planes + its queue writes), any-hit (16-B origin read per ray, 16-B contribution read and 12 B
                 # added per unoccluded ray: counted as 16 + 12 per ray, an upper bound), resolve (48 B per path)
                 all_bytes = kernel_bytes + 48 * sp.rays_extension_bounce0 + SH_ENTRY * sp.rays_shadow_bounce0 + 48 * sp.rays_primary + \
                     (16 + 12) * sp.rays_shadow + 48 * sp.rays_primary
             else:
                 kernel_bytes = BYTES_CLOSEST * sp.rays_extension
-                kernel_name = "k_trace_closest"
+                kernel_name, key = "k_trace_closest8", "tree"
                 all_bytes = BYTES_CLOSEST * sp.rays_extension + 16 * sp.rays_primary + BYTES_ANY * sp.rays_shadow + BYTES_VERTEX * sp.shaded_vertices
-            bytes_per_launch = kernel_bytes / sp.launches_trace_closest
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            # HBM bytes per launch of this kernel from the committed PMC passes of the same workload (profiles/*_traffic.json;
-            # counters cannot be collected from inside the timed process), over the launch duration measured live above
-            traffic, traffic_src = None, None
-            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-            if tfiles and args.spp == SPP and args.scene == "cornell" and world == 1:
-                try:
-                    tj = json.load(open(tfiles[-1]))
-                    # sp covers exactly one step
-                    traffic = tj["hbm_bytes_per_step"] / sp.launches_trace_closest / (avg_ms * 1e-3) / 1e9
-                    traffic_src = os.path.relpath(tfiles[-1], ROOT)
-                except Exception:  # a malformed file must not break the bench line
-                    traffic = None
             # the empirical stream peak of this box, measured in the same run (1 GiB float copy, read + write)
             empirical = None
             if world == 1:
@@ -258,19 +295,18 @@ def main():
                     del src_t, dst_t
                 except Exception:
                     empirical = None
-            roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "empirical_stream_peak": empirical, "frac_of_empirical": (achieved / empirical) if empirical else None,
-                        "avg_launch_ms": avg_ms, "launches": int(sp.launches_trace_closest),
-                        "algorithmic_bytes_per_launch": bytes_per_launch, "bytes_per_ray": kernel_bytes / max(1, sp.rays_extension),
-                        "rays_per_launch": sp.rays_extension / sp.launches_trace_closest,
-                        "kernel_mrays_per_s": sp.rays_extension / (sp.ms_trace_closest * 1e-3) / 1e6,
-                        "whole_step_queue_stream_gbs": all_bytes / (sp.ms_total * 1e-3) / 1e9,
-                        "stage_ms": {"primary": sp.ms_primary, "trace_closest": sp.ms_trace_closest, "trace_any": sp.ms_trace_any,
-                                     "shade": sp.ms_shade, "resolve": sp.ms_resolve, "total": sp.ms_total}}
+            quote = args.spp == SPP and world == 1 and (args.scene == "cornell") == fused
+            roofline = roofline_object(kernel_name, key, kernel_bytes, sp.launches_trace_closest, sp.ms_trace_closest, sp.rays_extension,
+                                       quote_counters=quote)
+            roofline.update({"empirical_stream_peak": empirical,
+                             "frac_of_empirical": (roofline["achieved"] / empirical) if empirical else None,
+                             "whole_step_queue_stream_gbs": all_bytes / (sp.ms_total * 1e-3) / 1e9,
+                             "stage_ms": {"primary": sp.ms_primary, "trace_closest": sp.ms_trace_closest, "trace_any": sp.ms_trace_any,
+                                          "shade": sp.ms_shade, "resolve": sp.ms_resolve, "total": sp.ms_total}})
 
-        # Informational second line of the same workload with the EXT shading model (no reference counterpart): the Cornell box
-        # with its MTL colours, GGX on the two boxes and the back wall, the emissive lamp sampled by next-event estimation.
+        # Second line of the same workload with the EXT shading model (no reference counterpart) -- the literal "Lambert+GGX" of
+        # BASELINE configs[1]: the Cornell box with its MTL colours, GGX on the two boxes and the back wall
+        # (assets/scene_config.json), the emissive lamp sampled by next-event estimation.
         ext_variant = None
         if args.scene == "cornell" and world == 1:
             import shutil
@@ -280,8 +316,8 @@ def main():
             open(os.path.join(tmp, "c.obj"), "w").write(txt)
             shutil.copy(os.path.join(ROOT, "assets", "cornell_box.mtl"), os.path.join(tmp, "cornell_box.mtl"))
             mats = capi.Geometry(os.path.join(tmp, "c.obj")).materials()
-            for m, (rough, ks) in {1: (0.25, 0.6), 6: (0.45, 0.4), 3: (0.15, 0.8)}.items():
-                mats[m, 3], mats[m, 4:7] = rough, ks
+            for m, (rough, ks) in capi.scene_config()["cornell_ggx"].items():
+                mats[int(m), 3], mats[int(m), 4:7] = rough, ks
             r.upload_materials(mats)
             step(capi.RENDER_EXT_MATERIALS)
             fence()
@@ -293,13 +329,25 @@ def main():
             edt = time.perf_counter() - t0
             es = r.stats()
             erays = es.rays_primary + es.rays_extension + es.rays_shadow
+            r.stats_reset()
+            step(capi.RENDER_EXT_MATERIALS | capi.RENDER_STAGE_TIMERS)
+            fence()
+            ep = r.stats()
+            # EXT entries: extension 48 B, next-event shadow entry 48 B (origin/tmin, direction/tmax, contribution/path id)
+            ebytes = 48 * ep.rays_extension + 48 * (ep.rays_extension - ep.rays_extension_bounce0) + 48 * (ep.rays_shadow - ep.rays_shadow_bounce0)
             ext_variant = {"workload": "cornell_box.obj + cornell_box.mtl %dx%d %dspp depth=%d, Lambert+GGX, emissive lamp + NEE (EXT model)" %
                                        (WIDTH, HEIGHT, args.spp, DEPTH),
                            "value": erays / edt / 1e6, "unit": "Mrays/s", "ms_per_step": edt / args.steps * 1e3,
                            "rays_per_step": {"primary": es.rays_primary / args.steps, "extension": es.rays_extension / args.steps,
-                                             "shadow": es.rays_shadow / args.steps}}
+                                             "shadow": es.rays_shadow / args.steps},
+                           "roofline": roofline_object("k_trace_shade<bounce>=1, EXT> (exhaustive closest hit + GGX/NEE shading, fused)", "ext",
+                                                       ebytes, ep.launches_trace_closest, ep.ms_trace_closest, ep.rays_extension,
+                                                       quote_counters=args.spp == SPP),
+                           "stage_ms": {"primary": ep.ms_primary, "trace_closest": ep.ms_trace_closest, "trace_any": ep.ms_trace_any,
+                                        "resolve": ep.ms_resolve, "total": ep.ms_total}}
 
-        # the general path (tree traversal, textures) on the BASELINE configs[3] stand-in, 16 spp: extra line, N = 1 only
+        # the general path (tree traversal, textures) on the BASELINE configs[3] stand-in, 16 spp: extra line, N = 1 only.
+        # These are the BVH-traversal-bound frames of the north star: its roofline object is for the closest-hit kernel.
         tree_variant = None
         if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant:
             try:
@@ -320,10 +368,32 @@ def main():
                 tdt = time.perf_counter() - t0
                 ts = r2.stats()
                 trays = ts.rays_primary + ts.rays_extension + ts.rays_shadow
+                r2.stats_reset()
+                r2.accum_reset()
+                r2.render(0, 16, DEPTH, capi.RENDER_STAGE_TIMERS)
+                r2.sync()
+                tp = r2.stats()
+                # (A) queue stream: 32-B ray read + 16-B hit written per ray; (B) traversal bytes per ray = nodes
+                # visited x 80 B + triangles tested x 64 B from the instrumented build (tools/w8_counts.py), committed with the
+                # counter passes
+                pmc, _ = committed_counters("tree")
+                trav = pmc.get("traversal_bytes_per_ray") if pmc else None
+                troof = roofline_object("k_trace_closest8 (extension rays, compressed 8-wide tree)", "tree", BYTES_CLOSEST * tp.rays_extension,
+                                        tp.launches_trace_closest, tp.ms_trace_closest, tp.rays_extension)
+                troof["bound_note"] = ("texture-address path + vector-instruction issue + exposed latency (DESIGN.md 5): the nodes and "
+                                       "triangles a ray touches come from L2 / Infinity Cache, not HBM; achieved / frac = queue-stream bytes "
+                                       "(A), achieved_with_traversal_bytes = (A + B) requested bytes, traffic = measured HBM bytes")
+                if trav:
+                    ab = (BYTES_CLOSEST + trav) * tp.rays_extension / (tp.ms_trace_closest * 1e-3) / 1e9
+                    troof.update({"traversal_bytes_per_ray": trav, "achieved_with_traversal_bytes": ab,
+                                  "frac_with_traversal_bytes": ab / HBM_PEAK_GBS})
                 tree_variant = {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d 16spp depth=%d, reference shading" %
                                             (bi2.triangle_count, WIDTH, HEIGHT, DEPTH),
                                 "value": trays / tdt / 1e6, "unit": "Mrays/s", "ms_per_step": tdt / 2 * 1e3,
-                                "bvh": {"build": "host SAH", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)}}
+                                "bvh": {"build": "host SAH + 8-wide collapse", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
+                                "roofline": troof,
+                                "stage_ms": {"primary": tp.ms_primary, "trace_closest": tp.ms_trace_closest, "trace_any": tp.ms_trace_any,
+                                             "shade": tp.ms_shade, "resolve": tp.ms_resolve, "total": tp.ms_total}}
                 r2.close()
             except Exception as exc:  # the extra line must never cost the contract line
                 tree_variant = {"error": str(exc)}

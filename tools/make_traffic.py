@@ -1,35 +1,56 @@
 #!/usr/bin/env python3
-"""profiles/rNN_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/prof.sh (gpurun_out/prof_pmc_*).
-Usage: python tools/make_traffic.py r01   (after copying the run's bench line to profiles/r01_bench.json).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950."""
-import csv, glob, json, os, sys
+"""profiles/rNN_traffic.json from the PMC passes of tools/prof.sh (gpurun_out/prof_pmc_*): per-launch HBM bytes (FETCH_SIZE doubled
+as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE) and vector instructions of the three kernels bench.py prices, plus
+the hash of the kernel sources the passes were taken on (bench.py quotes the numbers only while it matches).
+Usage: python tools/make_traffic.py r02 [w8_counts.json]   -- the optional file is the output line of tools/w8_counts.py."""
+import csv
+import glob
+import json
+import os
+import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KERNEL = "k_trace_shade<false, false, false, true>"
+sys.path.insert(0, root)
+import bench  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+KERNELS = {"headline": "k_trace_shade<false, false, false, true>", "ext": "k_trace_shade<false, true, false, true>",
+           "tree": "k_trace_closest8"}
 
 
-def total(counter):
-    f = glob.glob(os.path.join(root, "gpurun_out", "prof_pmc_" + counter, "**", "*counter_collection.csv"), recursive=True)[0]
+def total(pass_glob, counter, kernel):
+    fs = glob.glob(os.path.join(root, "gpurun_out", pass_glob, "**", "*counter_collection.csv"), recursive=True)
+    if not fs:
+        return 0.0, 0
     s, n = 0.0, 0
-    for r in csv.DictReader(open(f)):
-        if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
+    for r in csv.DictReader(open(fs[0])):
+        if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
             s += float(r["Counter_Value"])
             n += 1
     return s, n
 
 
-fetch, n = total("FETCH_SIZE")
-write, n2 = total("WRITE_SIZE")
-assert n == n2 and n > 0
-# launches per step of this kernel: (bounces) x batches -- read from the committed bench line
-bench = json.load(open(os.path.join(root, "profiles", tag + "_bench.json")))
-lps = int(bench["roofline"]["launches"])  # per step
-steps = n / lps
-hbm = (2.0 * fetch + write) * 1024.0
-out = {"kernel": "cap::" + KERNEL, "dispatches": n, "launches_per_step": lps, "steps_profiled": steps, "FETCH_SIZE_KB_sum": fetch,
-       "WRITE_SIZE_KB_sum": write, "hbm_bytes_per_step": hbm / steps, "hbm_bytes_per_launch": hbm / n,
-       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 2 --warmup 1 "
-                 "--no-cpu-baseline --no-tree-variant` (tools/prof.sh); counters are KiB summed over the kernel's dispatches; FETCH_SIZE "
-                 "doubled as MI355X_MICROARCH.md prescribes for gfx950; full output in profiles/%s_rocprofv3_summary.txt" % tag}
+out = {"source_sha256": bench.kernel_source_sha(), "kernels": {},
+       "method": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ block, each in its own run, no trace options) of `python3 "
+                 "bench.py --steps 2 --warmup 1 --no-cpu-baseline` (tools/prof.sh); counters summed over the kernel's dispatches and "
+                 "divided by their number; FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for "
+                 "gfx950; per-kernel table in profiles/%s_rocprofv3_summary.txt" % tag}
+for key, name in KERNELS.items():
+    fetch, n = total("prof_pmc_FETCH_SIZE", "FETCH_SIZE", name)
+    write, n2 = total("prof_pmc_WRITE_SIZE", "WRITE_SIZE", name)
+    valu, n3 = total("prof_pmc_SQ_WAVES*", "SQ_INSTS_VALU", name)
+    if not n:
+        continue
+    assert n == n2, (key, n, n2)
+    k = {"kernel": "cap::" + name, "dispatches": n, "FETCH_SIZE_KB_sum": fetch, "WRITE_SIZE_KB_sum": write,
+         "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / n}
+    if n3:
+        k["valu_insts_per_launch"] = valu / n3
+    out["kernels"][key] = k
+if len(sys.argv) > 2 and "tree" in out["kernels"]:
+    c = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+    out["kernels"]["tree"].update({"traversal_bytes_per_ray": c["traversal_bytes_per_ray"], "node_steps_per_ray": c["node_steps_per_ray"],
+                                   "triangle_tests_per_ray": c["triangle_tests_per_ray"],
+                                   "traversal_bytes_source": "tools/w8_counts.py on the diagnostic build (EXTRA=-DCAP_W8_COUNT)"})
 json.dump(out, open(os.path.join(root, "profiles", tag + "_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

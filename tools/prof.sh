@@ -1,16 +1,19 @@
 #!/bin/bash
 # Profiling recipe for the GPU box (run through gpurun): kernel trace + stats, then PMC passes (separate runs; never with
-# --sys-trace).  Outputs under gpurun_out/prof_*; copy the summaries worth keeping into profiles/.
+# --sys-trace) over the bench command itself (headline + EXT + tree-path variants).  Outputs under gpurun_out/prof_*;
+# tools/make_traffic.py and tools/prof_summary.py condense them into profiles/.
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
-ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tree-variant ${BENCH_EXTRA}"
+ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_EXTRA}"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python3 $ARGS > $OUT/prof_kt.log 2>&1 || exit 1
+rm -rf $OUT/prof_kt $OUT/prof_pmc_*
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python3 $ARGS > $OUT/prof_kt.log 2>&1 || exit 1
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
-            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
+            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
+            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $pass --output-format csv -d $OUT/prof_pmc_$tag -- python3 $ARGS > $OUT/prof_pmc_$tag.log 2>&1 || echo "pass failed: $pass"
+  timeout -k 10 400 rocprofv3 --pmc $pass --output-format csv -d $OUT/prof_pmc_$tag -- python3 $ARGS > $OUT/prof_pmc_$tag.log 2>&1 || echo "pass failed: $pass"
+  echo "pass done: $pass" >> $OUT/prof_progress.log
 done
 echo done
