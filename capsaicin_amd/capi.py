@@ -40,10 +40,10 @@ class Stats(C.Structure):
                 ("ms_resolve", C.c_double), ("launches_trace_closest", C.c_uint64), ("launches_trace_any", C.c_uint64),
                 ("launches_shade", C.c_uint64), ("rays_extension_bounce0", C.c_uint64), ("rays_shadow_bounce0", C.c_uint64),
                 ("guard_shade", C.c_uint64), ("guard_trace_any", C.c_uint64), ("guard_last", C.c_uint64), ("ms_post", C.c_double),
-                ("post_frames", C.c_uint64)]
+                ("post_frames", C.c_uint64), ("ms_direct", C.c_double), ("ms_post_pass", C.c_double * 5)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n == "ms_post_pass" else getattr(self, n)) for n, _ in self._fields_}
 
 
 class BvhInfo(C.Structure):

@@ -129,6 +129,10 @@ struct PostChainArgs
     float4 *indirect_history[2], *moments_history[2], *combined_history[2], *prev_normal_depth;
     // scratch
     float4 *indirect_temp, *temp[2], *normals;  // normals: decoded (n.xyz, depth) of this frame
+    // called on the host before pass p's launches, p = 0..4: Spatial gather, Temporal upscale, EAW, Combine illumination, TAA,
+    // and with p = 5 after the last launch (per-pass timestamps like the reference's AllocateTimestampQueryPair); may be null
+    void (*mark)(void* user, int pass);
+    void* mark_user;
 };
 // The frame's output is combined_history[frame_count % 2] (raytracing_system.cpp:320-324).
 void launch_post_chain(hipStream_t stream, const PostChainArgs& a);

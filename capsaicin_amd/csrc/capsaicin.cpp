@@ -315,15 +315,24 @@ std::string TimingsReport()
 {
     CapStats s;
     check(cap_stats_get(world().ctx, &s), "TimingsReport");
+    // the reference's timestamp labels (gui_system.cpp:94-104 prints what the passes named with AllocateTimestampQueryPair:
+    // raytracing_system.cpp:1024, 1099, 1207 and the reconstruction passes).  The wavefront passes map onto them as follows:
+    // camera rays -> "RaytracePrimaryVisibility" (the fused small-scene kernel also shades the camera vertex there), the camera
+    // vertex's shading and shadow rays -> "RT Direct lighting", everything of bounce >= 1 -> "RT Indirect diffuse".
+    const double indirect = s.ms_shade + s.ms_trace_closest + s.ms_trace_any - s.ms_direct;
     std::ostringstream o;
     o << "RaytracePrimaryVisibility: " << s.ms_primary << " ms\n"
-      << "RT Direct lighting + RT Indirect diffuse (shade): " << s.ms_shade << " ms\n"
-      << "RT Indirect diffuse (closest-hit traversal): " << s.ms_trace_closest << " ms\n"
-      << "RT shadow rays (any-hit traversal): " << s.ms_trace_any << " ms\n"
+      << "RT Direct lighting: " << s.ms_direct << " ms\n"
+      << "RT Indirect diffuse: " << indirect << " ms\n"
+      << "Spatial gather: " << s.ms_post_pass[0] << " ms\n"
+      << "Temporal upscale: " << s.ms_post_pass[1] << " ms\n"
+      << "EAW: " << s.ms_post_pass[2] << " ms\n"
+      << "Combine illumination: " << s.ms_post_pass[3] << " ms\n"
+      << "TAA: " << s.ms_post_pass[4] << " ms\n"
       << "Accumulate: " << s.ms_resolve << " ms\n"
-      << "Spatial gather + Temporal accumulation + EAW denoise + Combine + TAA: " << s.ms_post << " ms over " << s.post_frames << " frames\n"
-      << "total: " << s.ms_total << " ms over " << s.frames << " frames, rays primary/extension/shadow = " << s.rays_primary << "/"
-      << s.rays_extension << "/" << s.rays_shadow << "\n";
+      << "total: " << s.ms_total << " ms ray passes over " << s.frames << " frames, " << s.ms_post << " ms reconstruction over "
+      << s.post_frames << " frames, rays primary/extension/shadow = " << s.rays_primary << "/" << s.rays_extension << "/" << s.rays_shadow
+      << "\n";
     return o.str();
 }
 }  // namespace capsaicin

@@ -5,10 +5,12 @@
 // The product path is HIP only: every entry point that needs the GPU fails with CAP_ERR_HIP when no device or
 // kernel is available; there is no CPU fallback.
 #include <algorithm>
+#include <array>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -88,13 +90,17 @@ enum StageId
     ST_SHADE,
     ST_RESOLVE,
     ST_POST,
-    ST_COUNT
+    ST_COUNT,
+    ST_DIRECT,      // "RT Direct lighting": second label of the bounce-0 shading / shadow-ray spans
+    ST_POST_PASS0,  // .. ST_POST_PASS0 + 4: "Spatial gather", "Temporal upscale", "EAW", "Combine illumination", "TAA"
+    ST_NONE = -1
 };
 
 struct TimedSpan
 {
     hipEvent_t a, b;
     int        stage;
+    int        also = ST_NONE;  // a span may count under a second label
 };
 }  // namespace
 
@@ -177,6 +183,7 @@ struct CapContext
     // statistics
     CapStats               stats{};
     std::vector<TimedSpan> spans;
+    std::vector<std::array<hipEvent_t, 6>> post_marks;  // pass-boundary events of every cap_post_frame since the last sync
     std::vector<hipEvent_t> event_pool;
     struct PendingCounters
     {
@@ -199,21 +206,35 @@ int sync_and_collect(CapContext* c)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess)
         {
-            switch (sp.stage)
-            {
-            case ST_PRIMARY: c->stats.ms_primary += ms; break;
-            case ST_CLOSEST: c->stats.ms_trace_closest += ms; break;
-            case ST_ANY: c->stats.ms_trace_any += ms; break;
-            case ST_SHADE: c->stats.ms_shade += ms; break;
-            case ST_RESOLVE: c->stats.ms_resolve += ms; break;
-            case ST_POST: c->stats.ms_post += ms; break;
-            case ST_COUNT: c->stats.ms_total += ms; break;
-            }
+            for (int stage : {sp.stage, sp.also})
+                switch (stage)
+                {
+                case ST_PRIMARY: c->stats.ms_primary += ms; break;
+                case ST_CLOSEST: c->stats.ms_trace_closest += ms; break;
+                case ST_ANY: c->stats.ms_trace_any += ms; break;
+                case ST_SHADE: c->stats.ms_shade += ms; break;
+                case ST_RESOLVE: c->stats.ms_resolve += ms; break;
+                case ST_POST: c->stats.ms_post += ms; break;
+                case ST_COUNT: c->stats.ms_total += ms; break;
+                case ST_DIRECT: c->stats.ms_direct += ms; break;
+                default:
+                    if (stage >= ST_POST_PASS0 && stage < ST_POST_PASS0 + 5) c->stats.ms_post_pass[stage - ST_POST_PASS0] += ms;
+                }
         }
         c->event_pool.push_back(sp.a);
         c->event_pool.push_back(sp.b);
     }
     c->spans.clear();
+    for (auto& m : c->post_marks)
+    {
+        for (int pass = 0; pass < 5; ++pass)
+        {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, m[pass], m[pass + 1]) == hipSuccess) c->stats.ms_post_pass[pass] += ms, c->stats.ms_post += ms;
+        }
+        for (hipEvent_t e : m) c->event_pool.push_back(e);
+    }
+    c->post_marks.clear();
     for (auto& pc : c->pending)
     {
         const uint32_t D = pc.second;
@@ -261,10 +282,11 @@ struct StageTimer
     CapContext* c;
     TimedSpan   sp;
     bool        on;
-    StageTimer(CapContext* ctx, int stage, bool enabled = true) : c(ctx), on(enabled)
+    StageTimer(CapContext* ctx, int stage, bool enabled = true, int also = ST_NONE) : c(ctx), on(enabled)
     {
         if (!on) return;
         sp.stage = stage;
+        sp.also  = also;
         sp.a     = get_event(c);
         sp.b     = get_event(c);
         (void)hipEventRecord(sp.a, c->stream);
@@ -486,7 +508,8 @@ int cap_scene_upload(CapContext* c, const float* positions, const float* normals
         mesh_texture[m] = d.texture_index;
         for (uint32_t p = 0; p < d.index_count / 3; ++p) tri_ids.push_back(make_uint4(m, p, d.texture_index, 0u));
     }
-    if (tri_ids.size() >= (1u << 30)) return fail(CAP_ERR_UNSUPPORTED, "too many triangles");
+    // the traversal-leaf code keeps the first sorted triangle in kLeafCountShift bits (cap_leaf.h)
+    if (tri_ids.size() > kLeafFirstMask) return fail(CAP_ERR_UNSUPPORTED, "too many triangles: %zu (limit %u)", tri_ids.size(), kLeafFirstMask);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(c->positions.ensure(3 * (size_t)vertex_count));
@@ -938,7 +961,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     const SceneDev  scene = scene_dev(c);
     const CameraDev cam   = camera_dev(c->camera);
     const uint32_t  D     = num_bounces;
-    StageTimer* total = new StageTimer(c, ST_COUNT);
+    std::unique_ptr<StageTimer> total(new StageTimer(c, ST_COUNT));  // its destructor closes the span on every exit path
 
     for (uint32_t done = 0; done < n_frames; done += slots)
     {
@@ -1001,12 +1024,12 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             }
             else
             {
-                StageTimer t(c, ST_SHADE, st);
+                StageTimer t(c, ST_SHADE, st, b == 0 ? ST_DIRECT : ST_NONE);
                 launch_shade(cfg, sa, ext, feedback);
                 ++c->stats.launches_shade;
             }
             {
-                StageTimer t(c, ST_ANY, st);
+                StageTimer t(c, ST_ANY, st, b == 0 ? ST_DIRECT : ST_NONE);
                 launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p,
                                  work_any + b * per_queue, /* next-event estimation: most shadow rays reach the light */ ext, frames);
                 ++c->stats.launches_trace_any;
@@ -1059,13 +1082,12 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         // the next batch reuses counters/frames: serialise on the stream (already), and bound the event backlog
         if (c->spans.size() > 4096)
         {
-            delete total;
-            total = nullptr;
+            total.reset();
             if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
-            total = new StageTimer(c, ST_COUNT);
+            total.reset(new StageTimer(c, ST_COUNT));
         }
     }
-    delete total;
+    total.reset();
     return CAP_OK;
 }
 
@@ -1131,7 +1153,7 @@ int cap_stats_reset(CapContext* c)
     HIP_TRY(hipSetDevice(c->device));
     if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
     c->stats = CapStats{};
-    if (c->shaded_counter.p) HIP_TRY(hipMemset(c->shaded_counter.p, 0, 4 * sizeof(uint64_t)));
+    if (c->shaded_counter.p) HIP_TRY(hipMemsetAsync(c->shaded_counter.p, 0, 4 * sizeof(uint64_t), c->stream));  // ordered on the context's stream
     return CAP_OK;
 }
 
@@ -1197,10 +1219,20 @@ static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t fram
         a.indirect_history[k] = c->post_ihist[k].p, a.moments_history[k] = c->post_mhist[k].p, a.combined_history[k] = c->post_chist[k].p,
         a.temp[k] = c->post_temp[k].p;
     a.prev_normal_depth = c->post_prev_nd.p, a.indirect_temp = c->post_itemp.p, a.normals = c->post_normals.p;
+    // one timestamp per pass boundary, like the reference's AllocateTimestampQueryPair per pass (raytracing_system.cpp:1023-1035)
+    struct Marks
     {
-        StageTimer t(c, ST_POST);
-        launch_post_chain(c->stream, a);
-    }
+        CapContext* c;
+        hipEvent_t  e[6];
+    } marks{c, {}};
+    a.mark_user = &marks;
+    a.mark      = [](void* user, int pass) {
+        Marks* m   = static_cast<Marks*>(user);
+        m->e[pass] = get_event(m->c);
+        (void)hipEventRecord(m->e[pass], m->c->stream);
+    };
+    launch_post_chain(c->stream, a);
+    c->post_marks.push_back({marks.e[0], marks.e[1], marks.e[2], marks.e[3], marks.e[4], marks.e[5]});
     HIP_TRY(hipGetLastError());
     ++c->stats.post_frames;
     c->post_last_dst = (int)(frame_count % 2);

@@ -427,6 +427,10 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     uint32_t cg = (W * H + kBlock - 1) / kBlock;  // grid of the streaming (stencil-free) kernels
     if (cg > 4096) cg = 4096;
     if (cg == 0) cg = 1;
+    auto mark = [&](int pass) {
+        if (a.mark) a.mark(a.mark_user, pass);
+    };
+    mark(0);
     if (a.settings.gather || a.settings.denoise)
         hipLaunchKernelGGL(k_decode_normals, dim3(cg), block, 0, stream, a.normal_depth, a.normals, W * H);
     // SpatialGather (cpp:1541-1604); with lowres_indirect the input, the grid and indirect_temp are (W/2, H/2)
@@ -442,10 +446,12 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     else
         (void)hipMemcpyAsync(a.indirect_temp, a.indirect, sizeof(float4) * (size_t)IW * IH, hipMemcpyDeviceToDevice, stream);
     // IntegrateTemporally (cpp:1283-1342)
+    mark(1);
     hipLaunchKernelGGL(k_accumulate, grid, block, 0, stream, a.settings, a.frame_count, a.camera, a.prev_camera,
                        Img{a.indirect_temp, IW, IH}, img(a.normal_depth), img(a.indirect_history[src]), img(a.moments_history[src]), img(a.prev_normal_depth),
                        a.indirect_history[dst], a.moments_history[dst]);
     // Denoise (cpp:1437-1538)
+    mark(2);
     if (a.settings.denoise)
     {
         hipLaunchKernelGGL(k_blur_disocclusion, grid, block, 0, stream, a.settings, img(a.indirect_history[dst]), img(a.normals),
@@ -461,12 +467,15 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     else
         (void)hipMemcpyAsync(a.temp[0], a.indirect_history[dst], bytes, hipMemcpyDeviceToDevice, stream);
     // CombineIllumination (cpp:1400-1435)
+    mark(3);
     hipLaunchKernelGGL(k_combine, dim3(cg), block, 0, stream, a.temp[0], a.albedo, a.direct, W * H);
     // ApplyTAA (cpp:1344-1398)
+    mark(4);
     hipLaunchKernelGGL(k_taa, grid, block, 0, stream, a.settings, a.camera, a.prev_camera, img(a.temp[0]), img(a.normal_depth),
                        img(a.combined_history[src]), a.combined_history[dst]);
     // CopyGBuffer of the next frame (cpp:955-1009)
     (void)hipMemcpyAsync(a.prev_normal_depth, a.normal_depth, bytes, hipMemcpyDeviceToDevice, stream);
+    mark(5);
 }
 
 void launch_decimate2x(hipStream_t stream, const float4* full, uint32_t width, uint32_t height, uint32_t ox, uint32_t oy, float4* out)

@@ -124,6 +124,10 @@ typedef struct CapStats
     uint64_t guard_last;      /* (queue index or bounce) << 32 | path id of the last offender */
     double   ms_post;         /* reconstruction chain, "Spatial gather" .. "TAA" (cap_post_frame), always timed */
     uint64_t post_frames;
+    /* The reference's remaining timestamp labels (gui_system.cpp:94-104 lists what AllocateTimestampQueryPair named). */
+    double   ms_direct;       /* "RT Direct lighting": shading of the camera vertex + its shadow rays (part of ms_primary on the fused
+                                 small-scene path, of ms_shade / ms_trace_any otherwise; CAP_RENDER_STAGE_TIMERS) */
+    double   ms_post_pass[5]; /* "Spatial gather", "Temporal upscale", "EAW", "Combine illumination", "TAA" (sum = ms_post) */
 } CapStats;
 
 typedef struct CapBvhInfo

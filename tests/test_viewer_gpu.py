@@ -1,0 +1,111 @@
+"""The C++ host layer above the C ABI: capsaicin_amd/csrc/capsaicin.{h,cpp} keeps the reference's nine entry
+points (src/core/include/capsaicin.h:25-36) and system order (src/core/src/capsaicin.cpp:38-62); csrc/viewer_main.cpp is the
+headless src/viewer/main.cpp:50-107.  The viewer runs as a child process, exactly as a user would start it, and its PPM is
+compared with the oracle's frames pushed through the composite blit (gamma 1 / 2.2 and vertical flip, simple.hlsl:40-46):
+ * accumulate mode: plain mean of N frames;
+ * --realtime --move: the reference's own per-frame pipeline (ray passes with G-buffer feedback -> reconstruction chain), camera
+   translated every frame (the scripted stand-in for input_system.cpp:49-148).
+The per-pass timing table must carry the reference's timestamp labels (gui_system.cpp:94-104; raytracing_system.cpp:1024, 1099,
+1207 and the reconstruction passes)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from capsaicin_amd import capi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VIEWER = os.path.join(ROOT, "capsaicin_amd", "capsaicin_viewer")
+LABELS = ("RaytracePrimaryVisibility", "RT Direct lighting", "RT Indirect diffuse", "Spatial gather", "Temporal upscale", "EAW",
+          "Combine illumination", "TAA")
+
+
+def read_ppm(path):
+    d = open(path, "rb").read()
+    parts = d.split(b"\n", 3)
+    assert parts[0] == b"P6" and parts[2] == b"255"
+    w, h = (int(x) for x in parts[1].split())
+    return np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)
+
+
+def blit(img):
+    """CompositeSystem's fullscreen pass (simple.hlsl:40-46): pow(c, 1 / 2.2), v flipped; 8-bit UNORM round-to-nearest."""
+    v = np.power(np.maximum(img[..., :3].astype(np.float32), np.float32(0)), np.float32(1.0 / 2.2), dtype=np.float32)
+    q = np.minimum(np.float32(255), np.floor(v * np.float32(255) + np.float32(0.5))).astype(np.uint8)
+    return q[::-1]
+
+
+def run_viewer(args, tmp_path):
+    out = str(tmp_path / "frame.ppm")
+    env = dict(os.environ, CAPSAICIN_ASSETS=os.path.join(ROOT, "assets"))
+    p = subprocess.run([VIEWER, "--scene", os.path.join(ROOT, "assets", "cornell_box.obj"), "--out", out] + [str(a) for a in args],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return read_ppm(out), p.stderr
+
+
+def same_up_to_one_code(got, want, what):
+    """libm's powf and numpy's may differ in the last ulp, which moves a value sitting on an 8-bit rounding boundary by one code."""
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1, "%s: max code difference %d" % (what, int(diff.max()))
+    assert (diff != 0).mean() < 1e-3, "%s: %.4f %% of the values differ" % (what, 100.0 * float((diff != 0).mean()))
+
+
+def oracle_scene(cornell_path):
+    from oracle import cap_oracle as O
+    from oracle import obj_oracle
+    g = obj_oracle.load_geometry(cornell_path)
+    return O, O.Scene(g["positions"], g["normals"], g["texcoords"], g["indices"], g["meshes"])
+
+
+def ocam_of(O, cam):
+    return O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1],
+                         cam.focal_length)
+
+
+def test_accumulate_mode(native_lib, bluenoise, cornell_path, tmp_path):
+    assert os.path.exists(VIEWER), "capsaicin_viewer is built by capsaicin_amd/csrc/Makefile"
+    O, sc = oracle_scene(cornell_path)
+    w, h, n, D = 136, 80, 5, 2
+    got, log = run_viewer(["--width", w, "--height", h, "--frames", n, "--bounces", D], tmp_path)
+    cam = capi.cornell_camera(w, h)  # the viewer's built-in Cornell view is assets/scene_config.json's
+    acc, rays = sc.render_accumulate(ocam_of(O, cam), bluenoise, w, h, 0, n, D, threads=8)
+    mean = acc[..., :3] / np.float32(n)
+    same_up_to_one_code(got, blit(mean), "accumulated frame")
+    for label in LABELS:
+        assert label + ":" in log, "TimingsReport lacks the reference's label %r" % label
+    # the ray counters of the session, as printed
+    assert "rays primary/extension/shadow = %d/%d/%d" % rays in log
+
+
+@pytest.mark.parametrize("feedback", [True, False])
+def test_realtime_pipeline_with_camera_motion(native_lib, bluenoise, cornell_path, tmp_path, feedback):
+    O, sc = oracle_scene(cornell_path)
+    w, h, n, D = 120, 88, 6, 2
+    move = (0.02, 0.0, -0.03)
+    args = ["--width", w, "--height", h, "--frames", n, "--bounces", D, "--realtime", "--move"] + list(move)
+    got, log = run_viewer(args + ([] if feedback else ["--no-feedback"]), tmp_path)
+    chain = O.PostChain(w, h)
+    s = O.PostSettings()
+    base = capi.cornell_camera(w, h)
+    prev_nd = np.zeros((h, w, 4), np.float32)
+    hist = np.zeros((h, w, 4), np.float32)
+    prev = None
+    want = None
+    for f in range(n):
+        cam = capi.CameraData.from_buffer_copy(bytes(base))
+        for k in range(3):  # the viewer adds `move` to the float position after every Render()
+            p = np.float32(base.position[k])
+            for _ in range(f):
+                p = np.float32(p + np.float32(move[k]))
+            cam.position[k] = p
+        prev = prev if prev is not None else cam  # the first frame has no predecessor (camera_system.cpp:104-118)
+        fb = (ocam_of(O, prev), prev_nd, hist) if feedback else None
+        ref = sc.render_frame(ocam_of(O, cam), bluenoise, w, h, f, D, threads=8, feedback=fb)
+        want = chain.frame(s, f, ocam_of(O, cam), ocam_of(O, prev), ref)
+        prev, prev_nd, hist = cam, ref["normal_depth"], want
+    same_up_to_one_code(got, blit(want), "frame %d of the realtime loop" % (n - 1))
+    for label in LABELS:
+        assert label + ":" in log
