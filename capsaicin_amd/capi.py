@@ -118,6 +118,15 @@ SYMBOLS = {
     "cap_geometry_warning": (C.c_char_p, [_vp]),
     "cap_geometry_materials": (_i, [_vp, _vp]),
     "cap_scene_upload_geometry": (_i, [_vp, _vp]),
+    "cap_comm_unique_id": (_i, [_vp]),
+    "cap_comm_init_rank": (_i, [_vp, _vp, _u32, _u32]),
+    "cap_comm_gather_frame": (_i, [_vp]),
+    "cap_comm_init_all": (_i, [_vp, _u32]),
+    "cap_comm_gather_frame_all": (_i, [_vp, _u32]),
+    "cap_comm_image": (_i, [_vp, C.POINTER(C.c_void_p)]),
+    "cap_comm_readback": (_i, [_vp, _vp]),
+    "cap_comm_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
+    "cap_comm_destroy": (_i, [_vp]),
     "cap_host_sah_build": (_i, [_vp, _u32, _vp, _vp, C.POINTER(_u32)]),
     "cap_host_wide_build": (_i, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp]),
 }
@@ -265,6 +274,23 @@ def host_wide_build(nodes, n, scene_lo, scene_hi):
     _check(lib().cap_host_wide_build(_p(nodes) if n > 1 else None, n, _p(lo), _p(hi), _p(wide), wide.shape[0], _p(src), _p(info)),
            "cap_host_wide_build")
     return wide[:int(info[0])], src[:n], int(info[1]), int(info[2])
+
+
+def comm_unique_id():
+    """128-byte RCCL id made by rank 0; the caller carries it to the other ranks."""
+    buf = (C.c_uint8 * 128)()
+    _check(lib().cap_comm_unique_id(C.cast(buf, C.c_void_p)), "cap_comm_unique_id")
+    return bytes(buf)
+
+
+def comm_init_all(renderers):
+    arr = (C.c_void_p * len(renderers))(*[r.ctx for r in renderers])
+    _check(lib().cap_comm_init_all(C.cast(arr, C.c_void_p), len(renderers)), "cap_comm_init_all")
+
+
+def comm_gather_frame_all(renderers):
+    arr = (C.c_void_p * len(renderers))(*[r.ctx for r in renderers])
+    _check(lib().cap_comm_gather_frame_all(C.cast(arr, C.c_void_p), len(renderers)), "cap_comm_gather_frame_all")
 
 
 class Renderer:
@@ -423,3 +449,29 @@ class Renderer:
 
     def assemble_tiles(self, device_src, shard_count, device_image):
         _check(lib().cap_assemble_tiles(self.ctx, C.c_void_p(device_src), shard_count, C.c_void_p(device_image)), "cap_assemble_tiles")
+
+    # ---- the exchange below Python: RCCL gather of tile radiance + assembly on rank 0 (cap_comm_*) ----
+    def comm_init_rank(self, unique_id, rank, nranks):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().cap_comm_init_rank(self.ctx, C.cast(buf, C.c_void_p), rank, nranks), "cap_comm_init_rank")
+
+    def comm_gather_frame(self):
+        _check(lib().cap_comm_gather_frame(self.ctx), "cap_comm_gather_frame")
+
+    def comm_image_ptr(self):
+        p = C.c_void_p()
+        _check(lib().cap_comm_image(self.ctx, C.byref(p)), "cap_comm_image")
+        return p.value
+
+    def comm_readback(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        _check(lib().cap_comm_readback(self.ctx, _p(out)), "cap_comm_readback")
+        return out
+
+    def comm_info(self):
+        r, n, u = _u32(), _u32(), _u32()
+        _check(lib().cap_comm_info(self.ctx, C.byref(r), C.byref(n), C.byref(u)), "cap_comm_info")
+        return int(r.value), int(n.value), bool(u.value)
+
+    def comm_destroy(self):
+        _check(lib().cap_comm_destroy(self.ctx), "cap_comm_destroy")

@@ -59,6 +59,7 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out)
 // reference, a vendored third-party header that is not re-implemented).
 bool decode_ppm(const std::vector<uint8_t>& d, std::vector<uint8_t>* rgba, uint32_t* w, uint32_t* h)
 {
+    if (d.size() < 2 || d[0] != 'P' || d[1] != '6') return false;
     size_t pos = 0;
     auto   token = [&]() {
         std::string t;
@@ -91,6 +92,11 @@ bool decode_ppm(const std::vector<uint8_t>& d, std::vector<uint8_t>* rgba, uint3
     return true;
 }
 
+bool decode_image(const std::vector<uint8_t>& d, std::vector<uint8_t>* rgba, uint32_t* w, uint32_t* h)
+{
+    return decode_ppm(d, rgba, w, h);
+}
+
 struct World
 {
     // components
@@ -102,7 +108,9 @@ struct World
     RenderSessionParams session;
     bool                session_active = false;
     uint32_t            frame_count    = 0;
-    // GPU side
+    // GPU side: one context per shard this process renders (ctx == ctxs[0]: the root of a single-process multi-GPU session)
+    std::vector<CapContext*> ctxs;
+    bool                     exchange = false;  // a gather + assembly ends every Render()
     CapContext* ctx        = nullptr;
     bool        tlas_built = false;  // tlas_system.cpp:111-121 `built` flag: the structure is built once
     std::string assets_dir;
@@ -136,19 +144,16 @@ void run_asset_load(World& w)
         if (*cap_geometry_warning(geo)) warn(cap_geometry_warning(geo));
         CapGeometryView v;
         check(cap_geometry_view(geo, &v), "AssetLoadSystem");
-        check(cap_scene_upload_geometry(w.ctx, geo), "AssetLoadSystem");
+        for (CapContext* c : w.ctxs) check(cap_scene_upload_geometry(c, geo), "AssetLoadSystem");  // the scene is replicated per GPU
         for (uint32_t t = 0; t < v.texture_count; ++t)
         {
             const std::string    full = w.assets_dir + "textures/" + cap_geometry_texture_name(geo, t);
             std::vector<uint8_t> file, rgba;
             uint32_t             tw = 0, th = 0;
-            if (read_file(full, &file) && decode_ppm(file, &rgba, &tw, &th))
-                check(cap_texture_upload(w.ctx, t, rgba.data(), tw, th), "TextureSystem");
-            else
-            {
-                warn("TextureSystem: texture " + full + " missing");  // texture_system.cpp:50-56
-                check(cap_texture_upload(w.ctx, t, nullptr, 0, 0), "TextureSystem");
-            }
+            const bool           ok = read_file(full, &file) && decode_image(file, &rgba, &tw, &th);
+            if (!ok) warn("TextureSystem: texture " + full + " missing or not decodable");  // texture_system.cpp:50-56
+            for (CapContext* c : w.ctxs)
+                check(ok ? cap_texture_upload(c, t, rgba.data(), tw, th) : cap_texture_upload(c, t, nullptr, 0, 0), "TextureSystem");
         }
         cap_geometry_free(geo);
         a.loaded = true;
@@ -162,7 +167,7 @@ void run_acceleration_structure(World& w)
     bool any = false;
     for (auto& a : w.assets) any |= a.loaded;
     if (!any) return;
-    check(cap_bvh_build(w.ctx), "TLASSystem");
+    for (CapContext* c : w.ctxs) check(cap_bvh_build(c), "TLASSystem");
     CapBvhInfo bi;
     check(cap_bvh_info(w.ctx, &bi), "TLASSystem");
     info("TLASSystem: LBVH over " + std::to_string(bi.triangle_count) + " triangles, depth " + std::to_string(bi.max_depth) + ", " +
@@ -178,12 +183,12 @@ void run_camera(World& w)
     CapCameraData cd;
     static_assert(sizeof(cd) == sizeof(CameraData), "layout");
     std::memcpy(&cd, &w.camera, sizeof(cd));
-    check(cap_camera_set(w.ctx, &cd), "CameraSystem");
+    for (CapContext* c : w.ctxs) check(cap_camera_set(c, &cd), "CameraSystem");
     // the first frame has no predecessor: prev = current (camera_system.cpp:104-118 uploads the stored previous data)
     if (!w.prev_camera_valid) w.prev_camera = w.camera, w.prev_camera_valid = true;
     w.prev_camera.sensor_size[1] = w.prev_camera.sensor_size[0] * aspect;
     std::memcpy(&cd, &w.prev_camera, sizeof(cd));
-    check(cap_prev_camera_set(w.ctx, &cd), "CameraSystem");
+    for (CapContext* c : w.ctxs) check(cap_prev_camera_set(c, &cd), "CameraSystem");
 }
 
 // RaytracingSystem::Run, ray passes (raytracing_system.cpp:266-292)
@@ -194,6 +199,8 @@ void run_raytracing(World& w)
     {
         // ray passes + SpatialGather .. ApplyTAA of one frame (raytracing_system.cpp:262-317)
         const Settings& s = w.settings;
+        if (w.exchange)  // the C ABI has the sharded chain (cap_post_frame_gathered, cap_feedback_export / _import); this layer does not drive it
+            error_throw("RaytracingSystem: the reconstruction pipeline of this host layer renders on one GPU (gpus = 1, shard_count = 1)");
         if (s.frames_per_render != 1) error_throw("RaytracingSystem: the reconstruction pipeline renders one frame per Render()");
         const uint32_t flags = CAP_RENDER_STAGE_TIMERS | CAP_RENDER_AOV | (s.gbuffer_feedback ? (uint32_t)CAP_RENDER_GBUFFER_FEEDBACK : 0u) |
                                (s.lowres_indirect ? (uint32_t)CAP_RENDER_LOWRES_INDIRECT : 0u);
@@ -205,10 +212,21 @@ void run_raytracing(World& w)
         check(cap_post_frame(w.ctx, &ps, w.frame_count, &prev), "RaytracingSystem");
         return;
     }
-    if (!w.settings.accumulate) check(cap_accum_reset(w.ctx), "RaytracingSystem");
-    check(cap_render(w.ctx, w.frame_count, w.settings.frames_per_render, (uint32_t)std::max(0, w.settings.num_diffuse_bounces),
-                     CAP_RENDER_STAGE_TIMERS),
-          "RaytracingSystem");
+    for (CapContext* c : w.ctxs)
+    {
+        if (!w.settings.accumulate) check(cap_accum_reset(c), "RaytracingSystem");
+        check(cap_render(c, w.frame_count, w.settings.frames_per_render, (uint32_t)std::max(0, w.settings.num_diffuse_bounces),
+                         CAP_RENDER_STAGE_TIMERS),
+              "RaytracingSystem");
+    }
+    // frame end: the one collective of the design -- tile radiance to shard 0, assembled there
+    if (w.exchange)
+    {
+        if (w.ctxs.size() > 1)
+            check(cap_comm_gather_frame_all(w.ctxs.data(), (uint32_t)w.ctxs.size()), "RaytracingSystem");
+        else
+            check(cap_comm_gather_frame(w.ctx), "RaytracingSystem");
+    }
 }
 }  // namespace
 
@@ -224,15 +242,36 @@ void InitRenderSession(void* params)
     if (!params) error_throw("InitRenderSession: params is null");
     w.session = *static_cast<RenderSessionParams*>(params);
     info("capsaicin::InitRenderSession()");
-    check(cap_ctx_create(w.session.device, nullptr, &w.ctx), "InitRenderSession");
-    check(cap_set_resolution(w.ctx, w.session.width, w.session.height), "InitRenderSession");
-    check(cap_set_shard(w.ctx, w.session.shard_index, w.session.shard_count), "InitRenderSession");
+    const RenderSessionParams& sp = w.session;
+    if (!sp.gpus || !sp.shard_count || sp.shard_index >= sp.shard_count) error_throw("InitRenderSession: bad shard description");
+    if (sp.gpus > 1 && sp.shard_count > 1) error_throw("InitRenderSession: use gpus (one process, several GPUs) or shard_index / shard_count (one process per GPU), not both");
     // blue-noise texture = the sampler's random numbers (raytracing_system.cpp:642-646)
     std::vector<uint8_t> bn;
     std::string          dir = std::getenv("CAPSAICIN_ASSETS") ? std::string(std::getenv("CAPSAICIN_ASSETS")) + "/" : std::string("assets/");
     if (!read_file(dir + "bluenoise256.rgba", &bn) || bn.size() != 256 * 256 * 4)
         error_throw("RaytracingSystem: cannot read " + dir + "bluenoise256.rgba (set CAPSAICIN_ASSETS)");
-    check(cap_bluenoise_upload(w.ctx, bn.data()), "RaytracingSystem");
+    const int ndev = std::max(1, cap_device_count());
+    for (uint32_t i = 0; i < sp.gpus; ++i)
+    {
+        CapContext* c = nullptr;
+        check(cap_ctx_create((sp.device + (int)i) % ndev, nullptr, &c), "InitRenderSession");
+        w.ctxs.push_back(c);
+        check(cap_set_resolution(c, sp.width, sp.height), "InitRenderSession");
+        check(sp.gpus > 1 ? cap_set_shard(c, i, sp.gpus) : cap_set_shard(c, sp.shard_index, sp.shard_count), "InitRenderSession");
+        check(cap_bluenoise_upload(c, bn.data()), "RaytracingSystem");
+    }
+    w.ctx = w.ctxs[0];
+    if (sp.gpus > 1)
+    {
+        check(cap_comm_init_all(w.ctxs.data(), sp.gpus), "InitRenderSession");
+        w.exchange = true;
+    }
+    else if (sp.shard_count > 1)
+    {
+        if (!sp.comm_id) error_throw("InitRenderSession: shard_count > 1 needs comm_id (cap_comm_unique_id of rank 0)");
+        check(cap_comm_init_rank(w.ctx, sp.comm_id, sp.shard_index, sp.shard_count), "InitRenderSession");
+        w.exchange = true;
+    }
     w.session_active = true;
 }
 
@@ -255,7 +294,7 @@ void Render()
     run_camera(w);
     run_raytracing(w);
     // RenderSystem::Run: submit + ++frame_count_ (render_system.cpp:53-84)
-    check(cap_sync(w.ctx), "RenderSystem");
+    for (CapContext* c : w.ctxs) check(cap_sync(c), "RenderSystem");
     w.frame_count += w.settings.frames_per_render;
     w.prev_camera = w.camera;  // CameraSystem keeps this frame's data as the next frame's prev_camera_data
 }
@@ -264,7 +303,8 @@ void ShutdownRenderSession()
 {
     World& w = world();
     info("capsaicin::ShutdownRenderSession()");
-    if (w.ctx) cap_ctx_destroy(w.ctx);
+    for (CapContext* c : w.ctxs) cap_ctx_destroy(c);
+    w.ctxs.clear();
     w.ctx            = nullptr;
     w.session_active = false;
 }
@@ -272,7 +312,8 @@ void ShutdownRenderSession()
 void Shutdown()
 {
     info("capsaicin::Shutdown()");
-    if (g_world && g_world->ctx) cap_ctx_destroy(g_world->ctx);
+    if (g_world)
+        for (CapContext* c : g_world->ctxs) cap_ctx_destroy(c);
     g_world.reset();
 }
 
@@ -285,6 +326,8 @@ void ReadFrame(float* dst)
     World& w = world();
     if (w.settings.reconstruct)
         check(cap_post_readback(w.ctx, dst), "ReadFrame");  // current_frame_output(), raytracing_system.cpp:320-324
+    else if (w.exchange)
+        check(cap_comm_readback(w.ctx, dst), "ReadFrame");  // the frame shard 0 assembled from the gathered tiles
     else
         check(cap_readback(w.ctx, CAP_BUF_ACCUM_MEAN, dst), "ReadFrame");
 }
@@ -315,6 +358,13 @@ std::string TimingsReport()
 {
     CapStats s;
     check(cap_stats_get(world().ctx, &s), "TimingsReport");
+    for (size_t i = 1; i < world().ctxs.size(); ++i)
+    {
+        // the other shards of this process: their rays add up, their passes run concurrently on their own GPUs
+        CapStats o;
+        check(cap_stats_get(world().ctxs[i], &o), "TimingsReport");
+        s.rays_primary += o.rays_primary, s.rays_extension += o.rays_extension, s.rays_shadow += o.rays_shadow;
+    }
     // the reference's timestamp labels (gui_system.cpp:94-104 prints what the passes named with AllocateTimestampQueryPair:
     // raytracing_system.cpp:1024, 1099, 1207 and the reconstruction passes).  The wavefront passes map onto them as follows:
     // camera rays -> "RaytracePrimaryVisibility" (the fused small-scene kernel also shades the camera vertex there), the camera

@@ -12,8 +12,16 @@ struct RenderSessionParams
     uint32_t width       = 1920;  // viewer window size, main.cpp:53-54
     uint32_t height      = 1080;
     int      device      = 0;     // HIP device
-    uint32_t shard_index = 0;     // screen-tile shard rendered by this process
-    uint32_t shard_count = 1;
+    // Multi-GPU (no reference counterpart: dx12.cpp:13-25 picks one adapter).  Frames shard by 8x8 screen tile, tile t -> shard
+    // t % count; one RCCL gather of tile radiance to shard 0 per Render(), which assembles the frame (cap_comm_*).
+    //  * one process driving several GPUs: gpus = N; shard i renders on HIP device (device + i) % device count.  Shards that end
+    //    up on one device exchange by device copies.
+    //  * one process per GPU: shard_index / shard_count = this process's rank / the number of ranks, comm_id = the 128 bytes of
+    //    cap_comm_unique_id() made by rank 0 and carried to every rank by the launcher; ReadFrame / SaveFramePPM on rank 0.
+    uint32_t       gpus        = 1;
+    uint32_t       shard_index = 0;
+    uint32_t       shard_count = 1;
+    const uint8_t* comm_id     = nullptr;
 };
 
 namespace capsaicin

@@ -166,7 +166,14 @@ struct CapContext
         accum, image_tmp;
     DevBuf<uint32_t>   counters;  // per batch: ext[0..D], shadow[0..D]
     DevBuf<uint64_t>   shaded_counter;
-    DevBuf<FrameConst> frames;
+    // per-frame constants of a cap_render call: a ring of device buffers fed from pinned staging, so that a call need not wait
+    // for the previous one (which may still be reading its own slot)
+    static constexpr int kFrameRing = 4;
+    DevBuf<FrameConst> frames_ring[kFrameRing];
+    FrameConst*        frames_pinned[kFrameRing] = {nullptr, nullptr, nullptr, nullptr};
+    size_t             frames_pinned_n[kFrameRing] = {0, 0, 0, 0};
+    hipEvent_t         frames_event[kFrameRing] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t           frames_next = 0;
     uint32_t           slots_alloc = 0, bounces_alloc = 0;
     uint32_t           last_slots = 0;     // frame slots of the last batch rendered (AOV readback)
     bool               aov_valid = false;
@@ -179,6 +186,13 @@ struct CapContext
     DevBuf<float4> post_ihist[2], post_mhist[2], post_chist[2], post_prev_nd, post_itemp, post_temp[2], post_normals;
     uint32_t       post_w = 0, post_h = 0;
     int            post_last_dst = -1;
+
+    // multi-GPU frame exchange (cap_comm_*): RCCL communicator, or `comm_local` when the shards of one process share a device
+    void*           comm = nullptr;  // ncclComm_t
+    uint32_t        comm_rank = 0, comm_size = 0;
+    bool            comm_local = false;
+    DevBuf<float>   comm_send, comm_gathered, comm_image;
+    hipEvent_t      comm_event = nullptr;
 
     // statistics
     CapStats               stats{};
@@ -480,6 +494,12 @@ void cap_ctx_destroy(CapContext* c)
     for (auto& pc : c->pending) (void)hipHostFree(pc.first);
     for (auto p : c->pinned_pool) (void)hipHostFree(p);
     if (c->pinned_shaded) (void)hipHostFree(c->pinned_shaded);
+    (void)cap_comm_destroy(c);
+    for (int k = 0; k < CapContext::kFrameRing; ++k)
+    {
+        if (c->frames_pinned[k]) (void)hipHostFree(c->frames_pinned[k]);
+        if (c->frames_event[k]) (void)hipEventDestroy(c->frames_event[k]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -924,15 +944,36 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)32 << 20;  // measured on the headline workload: 8 Mi 39.6 ms, 16 Mi 35.1, 32 Mi 34.7, 64 Mi 35.8 per step
     uint32_t       slots  = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / std::max(1u, Ppad), kMaxFrameSlots));
     slots                 = std::min(slots, n_frames);
-    // drain the previous call (its per-frame constants and counters are reused below), then stage this call's constants
-    if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
-    if (ensure_wavefront(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
-    HIP_TRY(c->frames.ensure(n_frames));
+    // No host synchronisation with the previous call: everything it still uses is either ordered behind it on the stream (queues,
+    // counters, planes) or lives in another slot of the constants ring.  Only a long backlog of unread events / counters is
+    // drained (what cap_sync / cap_stats_get do anyway), and a growing allocation (which frees the old buffers).
+    if (c->spans.size() > 2048 || c->pending.size() > 64 || c->post_marks.size() > 256)
+        if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
     {
-        std::vector<FrameConst> fcs(n_frames);
-        for (uint32_t f = 0; f < n_frames; ++f) fcs[f] = frame_const(frame_begin + f, lowres);
-        HIP_TRY(hipMemcpy(c->frames.p, fcs.data(), sizeof(FrameConst) * n_frames, hipMemcpyHostToDevice));
+        const size_t planes_np = (size_t)slots * c->screen.pixels_padded;
+        const bool   grows     = c->pl_color.n < planes_np || c->counters.n < 3 * (size_t)(num_bounces + 1) * kQueueClasses * kCounterStride ||
+                           !c->accum.p || c->accum.n < c->screen.pixels_padded;
+        if (grows) HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    if (ensure_wavefront(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
+    const uint32_t ring = c->frames_next;
+    c->frames_next      = (c->frames_next + 1) % CapContext::kFrameRing;
+    if (!c->frames_event[ring]) HIP_TRY(hipEventCreateWithFlags(&c->frames_event[ring], hipEventDisableTiming));
+    HIP_TRY(hipEventSynchronize(c->frames_event[ring]));  // the call that used this slot kFrameRing calls ago: long done
+    if (c->frames_ring[ring].n < n_frames)
+    {
+        // (a larger buffer: the old one of this slot is idle by the event above)
+        HIP_TRY(c->frames_ring[ring].ensure(n_frames));
+    }
+    if (c->frames_pinned_n[ring] < n_frames)
+    {
+        if (c->frames_pinned[ring]) HIP_TRY(hipHostFree(c->frames_pinned[ring]));
+        c->frames_pinned[ring] = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&c->frames_pinned[ring], sizeof(FrameConst) * n_frames, hipHostMallocDefault));
+        c->frames_pinned_n[ring] = n_frames;
+    }
+    for (uint32_t f = 0; f < n_frames; ++f) c->frames_pinned[ring][f] = frame_const(frame_begin + f, lowres);
+    HIP_TRY(hipMemcpyAsync(c->frames_ring[ring].p, c->frames_pinned[ring], sizeof(FrameConst) * n_frames, hipMemcpyHostToDevice, c->stream));
     const bool st = (flags & CAP_RENDER_STAGE_TIMERS) != 0;
     if (c->textures_dirty)
     {
@@ -966,7 +1007,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     for (uint32_t done = 0; done < n_frames; done += slots)
     {
         const uint32_t ns = std::min(slots, n_frames - done);
-        const FrameConst* frames = c->frames.p + done;
+        const FrameConst* frames = c->frames_ring[ring].p + done;
         const size_t   per_queue     = (size_t)kQueueClasses * kCounterStride;  // counter words of one queue
         // per bounce and class one 64-bit word: low half = extension entries, high half = shadow entries (one atomic serves both)
         const size_t   counter_words = (size_t)(D + 1) * per_queue;
@@ -1088,6 +1129,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         }
     }
     total.reset();
+    HIP_TRY(hipEventRecord(c->frames_event[ring], c->stream));
     return CAP_OK;
 }
 
@@ -1369,6 +1411,275 @@ int cap_post_readback(CapContext* c, float* dst)
     HIP_TRY(hipSetDevice(c->device));
     if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
     HIP_TRY(hipMemcpy(dst, c->post_chist[c->post_last_dst].p, sizeof(float4) * (size_t)c->post_w * c->post_h, hipMemcpyDeviceToHost));
+    return CAP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU frame exchange: ONE gather of tile radiance to rank 0 at frame end, over RCCL (xGMI) -- the only data-path
+// collective of the design.  RCCL is loaded on first use (dlopen), so the library has no link-time dependency on
+// it and single-GPU users never touch it; a process that already has an RCCL loaded (e.g. through torch) shares that copy.
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace
+{
+struct Rccl
+{
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*)                                                              = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int)                                       = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*)                                               = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t)                                                                 = nullptr;
+    ncclResult_t (*GroupStart)()                                                                            = nullptr;
+    ncclResult_t (*GroupEnd)()                                                                              = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)                 = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)                       = nullptr;
+    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)        = nullptr;  // RCCL extension
+    const char* (*GetErrorString)(ncclResult_t)                                                             = nullptr;
+    std::string  path;
+};
+
+Rccl* rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (!tried)
+    {
+        tried = true;
+        std::vector<std::pair<std::string, int>> names;
+        if (const char* e = getenv("CAP_RCCL_LIBRARY")) names.push_back({e, RTLD_NOW});
+        // a copy the process already has (torch ships its own librccl.so), then the ROCm installation's
+        names.push_back({"librccl.so", RTLD_NOW | RTLD_NOLOAD});
+        names.push_back({"librccl.so.1", RTLD_NOW | RTLD_NOLOAD});
+        names.push_back({"librccl.so.1", RTLD_NOW});
+        names.push_back({"librccl.so", RTLD_NOW});
+        names.push_back({"/opt/rocm/lib/librccl.so.1", RTLD_NOW});
+        for (auto& n : names)
+            if ((r.lib = dlopen(n.first.c_str(), n.second | RTLD_GLOBAL)))
+            {
+                r.path = n.first;
+                break;
+            }
+        if (r.lib)
+        {
+#define CAP_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name))
+            CAP_SYM(GetUniqueId, "ncclGetUniqueId"), CAP_SYM(CommInitRank, "ncclCommInitRank"), CAP_SYM(CommInitAll, "ncclCommInitAll");
+            CAP_SYM(CommDestroy, "ncclCommDestroy"), CAP_SYM(GroupStart, "ncclGroupStart"), CAP_SYM(GroupEnd, "ncclGroupEnd");
+            CAP_SYM(Send, "ncclSend"), CAP_SYM(Recv, "ncclRecv"), CAP_SYM(Gather, "ncclGather"), CAP_SYM(GetErrorString, "ncclGetErrorString");
+#undef CAP_SYM
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv)
+                r.lib = nullptr;
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+
+#define NCCL_TRY(expr)                                                                                                             \
+    do                                                                                                                             \
+    {                                                                                                                              \
+        ncclResult_t r_ = (expr);                                                                                                  \
+        if (r_ != ncclSuccess)                                                                                                     \
+            return fail(CAP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, R->GetErrorString ? R->GetErrorString(r_) : "rccl error", __FILE__, \
+                        __LINE__);                                                                                                 \
+    } while (0)
+
+// this context's tiles (mean radiance, tile order) into its send buffer; the root's receive buffers
+int comm_stage(CapContext* c)
+{
+    if (!c->accum.p) return fail(CAP_ERR_STATE, "cap_comm_gather_frame: nothing rendered");
+    if (c->screen.shard_count != c->comm_size || c->screen.shard_index != c->comm_rank)
+        return fail(CAP_ERR_STATE, "cap_comm_gather_frame: the context renders shard %u of %u but is rank %u of %u", c->screen.shard_index,
+                    c->screen.shard_count, c->comm_rank, c->comm_size);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t floats = (size_t)c->screen.pixels_padded * 4;
+    HIP_TRY(c->comm_send.ensure(floats));
+    if (c->comm_rank == 0)
+    {
+        HIP_TRY(c->comm_gathered.ensure(floats * c->comm_size));
+        HIP_TRY(c->comm_image.ensure((size_t)c->screen.width * c->screen.height * 4));
+    }
+    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
+    launch_tiles_mean(cfg, c->accum.p, c->screen.pixels_padded, reinterpret_cast<float4*>(c->comm_send.p));
+    HIP_TRY(hipGetLastError());
+    return CAP_OK;
+}
+
+int comm_assemble(CapContext* root)
+{
+    HIP_TRY(hipSetDevice(root->device));
+    LaunchCfg cfg{root->stream, (uint32_t)root->cu_count * 8u, 32};
+    launch_assemble(cfg, root->screen, reinterpret_cast<const float4*>(root->comm_gathered.p), root->comm_size,
+                    reinterpret_cast<float4*>(root->comm_image.p));
+    HIP_TRY(hipGetLastError());
+    return CAP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int cap_comm_unique_id(uint8_t* id)
+{
+    if (!id) return fail(CAP_ERR_INVALID_ARG, "cap_comm_unique_id: NULL argument");
+    Rccl* R = rccl();
+    if (!R) return fail(CAP_ERR_UNSUPPORTED, "cap_comm_unique_id: no RCCL library could be loaded (librccl.so.1; set CAP_RCCL_LIBRARY)");
+    static_assert(sizeof(ncclUniqueId) == CAP_COMM_ID_BYTES, "id size");
+    ncclUniqueId u;
+    NCCL_TRY(R->GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return CAP_OK;
+}
+
+int cap_comm_init_rank(CapContext* c, const uint8_t* id, uint32_t rank, uint32_t nranks)
+{
+    if (!c || !id || !nranks || rank >= nranks) return fail(CAP_ERR_INVALID_ARG, "cap_comm_init_rank: bad argument");
+    if (c->comm || c->comm_local) return fail(CAP_ERR_STATE, "cap_comm_init_rank: the context already has a communicator");
+    Rccl* R = rccl();
+    if (!R) return fail(CAP_ERR_UNSUPPORTED, "cap_comm_init_rank: no RCCL library could be loaded (librccl.so.1; set CAP_RCCL_LIBRARY)");
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(R->CommInitRank(&comm, (int)nranks, u, (int)rank));
+    c->comm = comm, c->comm_rank = rank, c->comm_size = nranks;
+    return CAP_OK;
+}
+
+int cap_comm_init_all(CapContext* const* ctxs, uint32_t n)
+{
+    if (!ctxs || !n) return fail(CAP_ERR_INVALID_ARG, "cap_comm_init_all: bad argument");
+    std::vector<int> devs(n);
+    bool             distinct = true;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        if (!ctxs[i]) return fail(CAP_ERR_INVALID_ARG, "cap_comm_init_all: context %u is NULL", i);
+        if (ctxs[i]->comm || ctxs[i]->comm_local) return fail(CAP_ERR_STATE, "cap_comm_init_all: context %u already has a communicator", i);
+        devs[i] = ctxs[i]->device;
+        for (uint32_t j = 0; j < i; ++j) distinct &= devs[j] != devs[i];
+    }
+    if (n == 1 || !distinct)
+    {
+        // shards of one process on one device (or a single shard): nothing to send over a link, the "gather" is device copies
+        for (uint32_t i = 0; i < n; ++i)
+            if (devs[i] != devs[0]) return fail(CAP_ERR_UNSUPPORTED, "cap_comm_init_all: contexts must sit on pairwise distinct devices or all on one");
+        for (uint32_t i = 0; i < n; ++i) ctxs[i]->comm_local = true, ctxs[i]->comm_rank = i, ctxs[i]->comm_size = n;
+        return CAP_OK;
+    }
+    Rccl* R = rccl();
+    if (!R) return fail(CAP_ERR_UNSUPPORTED, "cap_comm_init_all: no RCCL library could be loaded (librccl.so.1; set CAP_RCCL_LIBRARY)");
+    std::vector<ncclComm_t> comms(n);
+    NCCL_TRY(R->CommInitAll(comms.data(), (int)n, devs.data()));
+    for (uint32_t i = 0; i < n; ++i) ctxs[i]->comm = comms[i], ctxs[i]->comm_rank = i, ctxs[i]->comm_size = n;
+    return CAP_OK;
+}
+
+int cap_comm_gather_frame(CapContext* c)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_comm_gather_frame: ctx is NULL");
+    if (c->comm_local && c->comm_size == 1)
+    {
+        CapContext* one[1] = {c};
+        return cap_comm_gather_frame_all(one, 1);
+    }
+    if (!c->comm) return fail(CAP_ERR_STATE, "cap_comm_gather_frame: cap_comm_init_rank has not run (contexts of cap_comm_init_all use cap_comm_gather_frame_all)");
+    Rccl* R = rccl();
+    if (int e = comm_stage(c)) return e;
+    const size_t floats = (size_t)c->screen.pixels_padded * 4;
+    if (R->Gather)
+        NCCL_TRY(R->Gather(c->comm_send.p, c->comm_gathered.p, floats, ncclFloat, 0, (ncclComm_t)c->comm, c->stream));
+    else
+    {
+        NCCL_TRY(R->GroupStart());
+        NCCL_TRY(R->Send(c->comm_send.p, floats, ncclFloat, 0, (ncclComm_t)c->comm, c->stream));
+        if (c->comm_rank == 0)
+            for (uint32_t r = 0; r < c->comm_size; ++r)
+                NCCL_TRY(R->Recv(c->comm_gathered.p + r * floats, floats, ncclFloat, (int)r, (ncclComm_t)c->comm, c->stream));
+        NCCL_TRY(R->GroupEnd());
+    }
+    return c->comm_rank == 0 ? comm_assemble(c) : CAP_OK;
+}
+
+int cap_comm_gather_frame_all(CapContext* const* ctxs, uint32_t n)
+{
+    if (!ctxs || !n) return fail(CAP_ERR_INVALID_ARG, "cap_comm_gather_frame_all: bad argument");
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        if (!ctxs[i] || ctxs[i]->comm_size != n || ctxs[i]->comm_rank != i || (!ctxs[i]->comm && !ctxs[i]->comm_local))
+            return fail(CAP_ERR_STATE, "cap_comm_gather_frame_all: pass the contexts of cap_comm_init_all in the same order");
+        if (int e = comm_stage(ctxs[i])) return e;
+    }
+    CapContext*  root   = ctxs[0];
+    const size_t floats = (size_t)root->screen.pixels_padded * 4;
+    if (root->comm_local)
+    {
+        // one device: the root's stream waits for every shard's tiles, then copies them into rank-major order
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            CapContext* c = ctxs[i];
+            if (c != root)
+            {
+                if (!c->comm_event) HIP_TRY(hipEventCreateWithFlags(&c->comm_event, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(c->comm_event, c->stream));
+                HIP_TRY(hipStreamWaitEvent(root->stream, c->comm_event, 0));
+            }
+            HIP_TRY(hipMemcpyAsync(root->comm_gathered.p + i * floats, c->comm_send.p, sizeof(float) * floats, hipMemcpyDeviceToDevice, root->stream));
+        }
+        return comm_assemble(root);
+    }
+    Rccl* R = rccl();
+    NCCL_TRY(R->GroupStart());
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        HIP_TRY(hipSetDevice(ctxs[i]->device));
+        NCCL_TRY(R->Send(ctxs[i]->comm_send.p, floats, ncclFloat, 0, (ncclComm_t)ctxs[i]->comm, ctxs[i]->stream));
+    }
+    HIP_TRY(hipSetDevice(root->device));
+    for (uint32_t r = 0; r < n; ++r) NCCL_TRY(R->Recv(root->comm_gathered.p + r * floats, floats, ncclFloat, (int)r, (ncclComm_t)root->comm, root->stream));
+    NCCL_TRY(R->GroupEnd());
+    return comm_assemble(root);
+}
+
+int cap_comm_image(CapContext* c, float** device_image)
+{
+    if (!c || !device_image) return fail(CAP_ERR_INVALID_ARG, "cap_comm_image: NULL argument");
+    if (c->comm_rank != 0 || !c->comm_image.p) return fail(CAP_ERR_STATE, "cap_comm_image: the assembled frame lives on rank 0 after cap_comm_gather_frame");
+    *device_image = c->comm_image.p;
+    return CAP_OK;
+}
+
+int cap_comm_readback(CapContext* c, float* dst)
+{
+    if (!c || !dst) return fail(CAP_ERR_INVALID_ARG, "cap_comm_readback: NULL argument");
+    if (c->comm_rank != 0 || !c->comm_image.p) return fail(CAP_ERR_STATE, "cap_comm_readback: the assembled frame lives on rank 0 after cap_comm_gather_frame");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, c->comm_image.p, sizeof(float) * 4 * (size_t)c->screen.width * c->screen.height, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CAP_OK;
+}
+
+int cap_comm_info(CapContext* c, uint32_t* rank, uint32_t* size, uint32_t* uses_rccl)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_comm_info: ctx is NULL");
+    if (rank) *rank = c->comm_rank;
+    if (size) *size = c->comm_size;
+    if (uses_rccl) *uses_rccl = c->comm ? 1u : 0u;
+    return CAP_OK;
+}
+
+int cap_comm_destroy(CapContext* c)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_comm_destroy: ctx is NULL");
+    if (c->comm)
+    {
+        Rccl* R = rccl();
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (R) (void)R->CommDestroy((ncclComm_t)c->comm);
+    }
+    if (c->comm_event) (void)hipEventDestroy(c->comm_event);
+    c->comm = nullptr, c->comm_event = nullptr, c->comm_local = false, c->comm_rank = c->comm_size = 0;
     return CAP_OK;
 }
 }

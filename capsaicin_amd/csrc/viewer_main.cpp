@@ -26,6 +26,7 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--frames")) frames = std::atoi(next());
         else if (!std::strcmp(argv[i], "--bounces")) bounces = std::atoi(next());
         else if (!std::strcmp(argv[i], "--device")) params.device = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--gpus")) params.gpus = (uint32_t)std::atoi(next());  // screen-tile shards, one per GPU
         else if (!std::strcmp(argv[i], "--default-camera")) cornell_camera = false;
         else if (!std::strcmp(argv[i], "--realtime")) realtime = true;  // the reference pipeline: 1 spp per frame + reconstruction chain
         else if (!std::strcmp(argv[i], "--no-feedback")) feedback = false;
@@ -34,7 +35,7 @@ int main(int argc, char** argv)
             for (int k = 0; k < 3; ++k) move[k] = (float)std::atof(next());
         else
         {
-            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--default-camera] [--realtime [--no-feedback] [--lowres] [--move dx dy dz]]\n", argv[0]);
+            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--gpus N] [--default-camera] [--realtime [--no-feedback] [--lowres] [--move dx dy dz]]\n", argv[0]);
             return 2;
         }
     }

@@ -224,6 +224,28 @@ int cap_resolve_tiles(CapContext* ctx, float* device_dst);
 /* device_src: shard_count tile buffers back to back (the gather result); device_image: width*height*4 floats */
 int cap_assemble_tiles(CapContext* ctx, const float* device_src, uint32_t shard_count, float* device_image);
 
+/* ---- the exchange itself: ONE gather of tile radiance to rank 0 per frame, over RCCL (xGMI) ----
+ * The reference is single-GPU (dx12.cpp:13-25, 196-234); this is the north star's "frames shard by screen tile across the GPUs of
+ * one node with a single RCCL gather of tile radiance at frame end".  Each context renders the shard cap_set_shard gave it
+ * (shard index == rank, shard count == ranks).  RCCL is loaded on first use (dlopen "librccl.so.1", or CAP_RCCL_LIBRARY); a copy
+ * the process already has loaded is shared.  cap_comm_gather_frame* resolve the tiles (as cap_resolve_tiles), gather them to rank
+ * 0 with ncclGather on the contexts' streams and assemble the row-major image there (as cap_assemble_tiles): asynchronous,
+ * ordered behind the render on each stream. */
+#define CAP_COMM_ID_BYTES 128
+/* one process per GPU: rank 0 makes the id, the host program carries it to the other ranks (file, MPI, a key-value store) */
+int cap_comm_unique_id(uint8_t* id_128_bytes);
+int cap_comm_init_rank(CapContext* ctx, const uint8_t* id_128_bytes, uint32_t rank, uint32_t nranks); /* collective */
+int cap_comm_gather_frame(CapContext* ctx);                                                            /* collective */
+/* one process driving n GPUs: ctxs[i] renders shard i of n; contexts on pairwise distinct devices get an RCCL communicator
+ * (ncclCommInitAll), contexts that all share one device exchange by device copies */
+int cap_comm_init_all(CapContext* const* ctxs, uint32_t n);
+int cap_comm_gather_frame_all(CapContext* const* ctxs, uint32_t n);
+/* rank 0 after a gather: the assembled frame, width*height*4 floats (mean radiance; .w = frames), on the device / on the host */
+int cap_comm_image(CapContext* ctx, float** device_image);
+int cap_comm_readback(CapContext* ctx, float* dst);
+int cap_comm_info(CapContext* ctx, uint32_t* rank, uint32_t* size, uint32_t* uses_rccl);
+int cap_comm_destroy(CapContext* ctx); /* also done by cap_ctx_destroy */
+
 /* ---- reconstruction chain ----
  * The passes RaytracingSystem::Run records after the ray passes (raytracing_system.cpp:294-317):
  * SpatialGather (cpp:1541-1604) -> IntegrateTemporally (cpp:1283-1342) -> Denoise = BlurDisocclusion + 2|4 a-trous blurs

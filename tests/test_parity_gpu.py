@@ -102,11 +102,14 @@ def test_sharded_render_equals_unsharded(cornell, bluenoise):
     r.set_camera(cam)
     r.set_shard(0, 1)
     r.accum_reset()
+    r.stats_reset()
     r.render(0, n, D)
     full = r.readback(capi.BUF_ACCUM_MEAN)
+    whole = r.stats()
     for count in (2, 3, 8):
         floats = None
         bufs = []
+        r.stats_reset()  # the shards' counters add up in one CapStats: every ray is traced by exactly one shard
         for idx in range(count):
             r.set_shard(idx, count)
             r.accum_reset()
@@ -135,6 +138,9 @@ def test_sharded_render_equals_unsharded(cornell, bluenoise):
         got = image.cpu().numpy().reshape(h, w, 4)
         assert_same(got, full, "assembled from %d shards" % count)
         assert_same(tiles.assemble([b.cpu().numpy().reshape(-1, 4) for b in bufs], w, h), full, "tiles.assemble %d" % count)
+        s = r.stats()
+        assert (s.rays_primary, s.rays_extension, s.rays_shadow, s.shaded_vertices) == \
+            (whole.rays_primary, whole.rays_extension, whole.rays_shadow, whole.shaded_vertices), "ray counters of %d shards" % count
     r.set_shard(0, 1)
 
 
