@@ -206,9 +206,47 @@ def main():
         gathered = torch.zeros(tile_floats * world, dtype=torch.float32, device="cuda") if rank == 0 else None
         image = torch.zeros(WIDTH * HEIGHT * 4, dtype=torch.float32, device="cuda") if rank == 0 else None
 
+        # The exchange of the product path: cap_comm_* (capsaicin_hip.h) -- ncclGather of tile radiance + assembly on rank 0, on
+        # the render stream, below Python.  The 128-byte RCCL id travels through the process group that also carries the
+        # barriers.  Before anything is timed the result of one frame is compared, on rank 0, with the same gather done by
+        # torch.distributed; every rank then uses the C-ABI path, or -- if RCCL could not be loaded or the comparison failed --
+        # every rank uses torch.distributed, and the JSON line says which.
+        exchange = "none" if world == 1 else "torch.distributed.gather"
+        if world > 1 and backend == "nccl":
+            ok = torch.zeros(1, dtype=torch.int32, device="cuda")
+            try:
+                ids = [capi.comm_unique_id() if rank == 0 else None]
+            except capi.CapError:
+                ids = [None]
+            dist.broadcast_object_list(ids, src=0)
+            if ids[0] is not None:
+                try:
+                    r.comm_init_rank(ids[0], rank, world)
+                    r.accum_reset()
+                    r.render(0, 1, DEPTH, 0)
+                    r.comm_gather_frame()
+                    r.resolve_tiles(tile_buf.data_ptr())
+                    r.sync()
+                    torch.cuda.synchronize()
+                    dist.gather(tile_buf, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+                    if rank == 0:
+                        r.assemble_tiles(gathered.data_ptr(), world, image.data_ptr())
+                        r.sync()
+                        torch.cuda.synchronize()
+                        a = r.comm_readback().reshape(-1)
+                        ok[0] = int(np.array_equal(a.view(np.uint32), image.cpu().numpy().view(np.uint32)))
+                except capi.CapError as exc:
+                    sys.stderr.write("[bench] rank %d: cap_comm path unavailable: %s\n" % (rank, exc))
+                dist.broadcast(ok, src=0)
+                if int(ok.item()) == 1:
+                    exchange = "cap_comm_gather_frame (ncclGather, C ABI)"
+
         def step(flags=0):
             r.accum_reset()
             r.render(0, args.spp, DEPTH, flags)
+            if exchange.startswith("cap_comm"):
+                r.comm_gather_frame()
+                return
             r.resolve_tiles(tile_buf.data_ptr())
             if world > 1:
                 # the single data-path collective: tile radiance -> rank 0 over xGMI
@@ -400,7 +438,7 @@ def main():
 
         if rank == 0:
             # sanity of the product of the timed region: finite image, every pixel accumulated spp frames
-            img = image.cpu().numpy().reshape(HEIGHT, WIDTH, 4)
+            img = (r.comm_readback() if exchange.startswith("cap_comm") else image.cpu().numpy()).reshape(HEIGHT, WIDTH, 4)
             assert np.isfinite(img).all() and (img[..., 3] == args.spp).all(), "bench image is incomplete"
             out = {"metric": "Mrays/sec (primary+secondary), cornell_box 1080p 64spp", "value": rays / dt / 1e6, "unit": "Mrays/s",
                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -409,7 +447,7 @@ def main():
                                           "tile-sharded over %d GPU(s)" % (WIDTH, HEIGHT, args.spp, DEPTH, world),
                               "triangles": int(bvh.triangle_count), "bvh_depth": int(bvh.max_depth),
                               "rays_per_step": {"primary": rays_p / args.steps, "extension": rays_e / args.steps, "shadow": rays_s / args.steps},
-                              "parallelism": "tiles%d" % world},
+                              "parallelism": "tiles%d" % world, "exchange": exchange},
                    "roofline": roofline, "ext_variant": ext_variant, "tree_variant": tree_variant}
             out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()  # rank 0, N = 1 only
             print(json.dumps(out), flush=True)
