@@ -14,6 +14,30 @@ namespace
 {
 constexpr float kEpsPost = 1e-8f;  // math_functions.h:4
 
+// length(float2(dx, dy)) of the 7 x 7 stencils' taps: sqrtf((float)(dx * dx + dy * dy)) evaluated once (correctly rounded square
+// roots of small integers: the values the per-tap evaluation gives).  The loop indices are wave-uniform, so this is a scalar load.
+struct TapLen7
+{
+    float v[7][7];
+};
+constexpr float csqrt(float x)
+{
+    // Newton iterations in double, then the correctly rounded float: x <= 18 is far from any rounding boundary issue
+    double r = x > 0.f ? (double)x : 0.0;
+    if (r == 0.0) return 0.f;
+    double g = r;
+    for (int i = 0; i < 40; ++i) g = 0.5 * (g + r / g);
+    return (float)g;
+}
+constexpr TapLen7 make_len7()
+{
+    TapLen7 t{};
+    for (int dy = -3; dy <= 3; ++dy)
+        for (int dx = -3; dx <= 3; ++dx) t.v[dy + 3][dx + 3] = csqrt((float)(dx * dx + dy * dy));
+    return t;
+}
+__constant__ TapLen7 kLen7 = make_len7();
+
 __device__ __forceinline__ float    lerp1(float a, float b, float t) { return a + t * (b - a); }
 __device__ __forceinline__ v3       div3(v3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 __device__ __forceinline__ float    luminance(v3 c) { return dot3(c, mk3(0.299f, 0.587f, 0.114f)); }
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color,
                 const float4 g = UP ? ldi(nd, (sx << 1) + ox, (sy << 1) + oy) : ldi(nd, sx, sy);
                 if (g.w < 1e-5f) continue;
                 const v3    n   = xyz(g);
-                const float len = sqrtf((float)(dx * dx + dy * dy));
+                const float len = kLen7.v[dy + 3][dx + 3];
                 const float wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * len) * luma_weight(luminance(cc), luminance(c), s_luma);
                 filtered = filtered + c * wgt;
                 total += wgt;
@@ -278,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void k_blur_disocclusion(PostSettingsDev s,
                 const float4 m = ldi(moments, sx, sy);
                 if (g.w < 1e-5f) continue;
                 const v3    n   = xyz(g);
-                const float len = sqrtf((float)(dx * dx + dy * dy));
+                const float len = kLen7.v[dy + 3][dx + 3];
                 const float wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * len) * luma_weight(luminance(cc), luminance(c), s_luma);
                 filtered = filtered + c * wgt;
                 fm0 += wgt * m.x, fm1 += wgt * m.y;
@@ -359,12 +383,27 @@ __device__ __forceinline__ v3 clip_to_aabb(v3 pmin, v3 pmax, v3 p)
 }
 
 // temporal_accumulation.hlsl:362-447
+constexpr uint32_t kTaaTileW = 32 + 4, kTaaTileH = 8 + 4;  // the workgroup's 32 x 8 pixels + the 5 x 5 window's halo
 __global__ __launch_bounds__(kBlock) void k_taa(PostSettingsDev s, CameraDev cam, CameraDev prev_cam, Img color, Img nd, Img history_img,
                                                 float4* out)
 {
-    uint32_t x, y;
     const uint32_t W = color.w, H = color.h;
+    __shared__ v3  lds_tap[kTaaTileW * kTaaTileH];
+    {
+        const int x0 = (int)(blockIdx.x * 32u) - 2, y0 = (int)(blockIdx.y * 8u) - 2;
+        for (uint32_t e = threadIdx.x; e < kTaaTileW * kTaaTileH; e += kBlock)
+        {
+            int sx = x0 + (int)(e % kTaaTileW), sy = y0 + (int)(e / kTaaTileW);
+            sx = sx < 0 ? 0 : (sx > (int)W - 1 ? (int)W - 1 : sx);
+            sy = sy < 0 ? 0 : (sy > (int)H - 1 ? (int)H - 1 : sy);
+            lds_tap[e] = rgb2ycocg(simple_tonemap(sample_bilinear(color, xy_to_uv(f2{(float)sx, (float)sy}, W, H))));
+        }
+        __syncthreads();
+    }
+    uint32_t x, y;
     if (!pixel_of_thread(W, H, x, y)) return;
+    const uint32_t lx = threadIdx.x & 31u, ly = threadIdx.x >> 5;
+    const v3       tap_of_thread = lds_tap[(ly + 2) * kTaaTileW + (lx + 2)];
     const f2     uv = f2{((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H};
     const float4 g  = ld(nd, x, y);
     const size_t o  = (size_t)y * W + x;
@@ -391,16 +430,16 @@ __global__ __launch_bounds__(kBlock) void k_taa(PostSettingsDev s, CameraDev cam
     alpha             = fminf(s.taa_feedback, alpha);
     v3       history = rgb2ycocg(simple_tonemap(resample_bicubic(history_img, puv)));
     const v3 c       = rgb2ycocg(simple_tonemap(cur));
-    // CalculateNeighbourhoodColorAABB(gidx, dim, scale), :98-137
-    const v3 center = rgb2ycocg(simple_tonemap(sample_bilinear(color, xy_to_uv(f2{(float)x, (float)y}, W, H))));
+    // CalculateNeighbourhoodColorAABB(gidx, dim, scale), :98-137.  The 25 tonemapped bilinear taps of a pixel sit at whole-pixel
+    // positions (clamped to the image), so a tap's value depends on that position only and neighbouring pixels share 20 of their
+    // 25: the workgroup evaluates each position of its 36 x 12 footprint once into LDS (the same operations on the same
+    // operands as the per-pixel evaluation, so the same bits) and every pixel sums its 5 x 5 window in the reference's order.
+    const v3 center = tap_of_thread;
     v3       m1 = mk3(0.f, 0.f, 0.f), m2 = mk3(0.f, 0.f, 0.f);
     for (int i = -2; i <= 2; ++i)
         for (int j = -2; j <= 2; ++j)
         {
-            int sx = (int)x + i, sy = (int)y + j;
-            sx = sx < 0 ? 0 : (sx > (int)W - 1 ? (int)W - 1 : sx);
-            sy = sy < 0 ? 0 : (sy > (int)H - 1 ? (int)H - 1 : sy);
-            const v3 v = rgb2ycocg(simple_tonemap(sample_bilinear(color, xy_to_uv(f2{(float)sx, (float)sy}, W, H))));
+            const v3 v = lds_tap[(ly + 2 + j) * kTaaTileW + (lx + 2 + i)];
             m1 = m1 + v;
             m2 = m2 + v * v;
         }
