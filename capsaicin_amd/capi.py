@@ -127,6 +127,8 @@ SYMBOLS = {
     "cap_comm_readback": (_i, [_vp, _vp]),
     "cap_comm_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "cap_comm_destroy": (_i, [_vp]),
+    "cap_image_decode": (_i, [_vp, C.c_size_t, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_u32), C.POINTER(_u32)]),
+    "cap_image_free": (None, [_vp]),
     "cap_host_sah_build": (_i, [_vp, _u32, _vp, _vp, C.POINTER(_u32)]),
     "cap_host_wide_build": (_i, [_vp, _u32, _vp, _vp, _vp, _u32, _vp, _vp]),
 }
@@ -262,6 +264,16 @@ def host_sah_build(tri_lo, tri_hi):
     depth = C.c_uint32()
     _check(lib().cap_host_sah_build(_p(boxes), n, _p(nodes), _p(order), C.byref(depth)), "cap_host_sah_build")
     return nodes[:max(n - 1, 0)], order, int(depth.value)
+
+
+def image_decode(data, name=None):
+    """Texture file bytes -> [h, w, 4] uint8 (PNG / TGA / binary PPM), as TextureSystem's stbi_load(..., 4) would hand over."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    px, w, h = C.c_void_p(), _u32(), _u32()
+    _check(lib().cap_image_decode(_p(buf), buf.size, name.encode() if name else None, C.byref(px), C.byref(w), C.byref(h)), "cap_image_decode")
+    out = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint8)), (h.value, w.value, 4)).copy()
+    lib().cap_image_free(px)
+    return out
 
 
 def host_wide_build(nodes, n, scene_lo, scene_hi):

@@ -55,46 +55,14 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out)
     return true;
 }
 
-// Binary PPM (P6, maxval 255) -> RGBA8; the only image container decoded natively (PNG/JPEG decoding was stb_image in the
-// reference, a vendored third-party header that is not re-implemented).
-bool decode_ppm(const std::vector<uint8_t>& d, std::vector<uint8_t>* rgba, uint32_t* w, uint32_t* h)
+// texture_system.cpp:41-45: stbi_load(file, &w, &h, &n, 4) -> own decoders behind the C ABI (PNG, TGA, binary PPM)
+bool decode_image(const std::vector<uint8_t>& d, const std::string& name, std::vector<uint8_t>* rgba, uint32_t* w, uint32_t* h)
 {
-    if (d.size() < 2 || d[0] != 'P' || d[1] != '6') return false;
-    size_t pos = 0;
-    auto   token = [&]() {
-        std::string t;
-        while (pos < d.size())
-        {
-            if (d[pos] == '#')
-                while (pos < d.size() && d[pos] != '\n') ++pos;
-            else if (std::isspace(d[pos]))
-                ++pos;
-            else
-                break;
-        }
-        while (pos < d.size() && !std::isspace(d[pos])) t += (char)d[pos++];
-        return t;
-    };
-    if (token() != "P6") return false;
-    long W = std::atol(token().c_str()), H = std::atol(token().c_str()), M = std::atol(token().c_str());
-    if (W <= 0 || H <= 0 || M != 255) return false;
-    ++pos;  // single whitespace after maxval
-    if (d.size() < pos + (size_t)W * H * 3) return false;
-    rgba->resize((size_t)W * H * 4);
-    for (size_t i = 0; i < (size_t)W * H; ++i)
-    {
-        (*rgba)[4 * i + 0] = d[pos + 3 * i + 0];
-        (*rgba)[4 * i + 1] = d[pos + 3 * i + 1];
-        (*rgba)[4 * i + 2] = d[pos + 3 * i + 2];
-        (*rgba)[4 * i + 3] = 255;
-    }
-    *w = (uint32_t)W, *h = (uint32_t)H;
+    uint8_t* px = nullptr;
+    if (cap_image_decode(d.data(), d.size(), name.c_str(), &px, w, h) != CAP_OK) return false;
+    rgba->assign(px, px + (size_t)*w * *h * 4);
+    cap_image_free(px);
     return true;
-}
-
-bool decode_image(const std::vector<uint8_t>& d, std::vector<uint8_t>* rgba, uint32_t* w, uint32_t* h)
-{
-    return decode_ppm(d, rgba, w, h);
 }
 
 struct World
@@ -150,7 +118,7 @@ void run_asset_load(World& w)
             const std::string    full = w.assets_dir + "textures/" + cap_geometry_texture_name(geo, t);
             std::vector<uint8_t> file, rgba;
             uint32_t             tw = 0, th = 0;
-            const bool           ok = read_file(full, &file) && decode_image(file, &rgba, &tw, &th);
+            const bool           ok = read_file(full, &file) && decode_image(file, full, &rgba, &tw, &th);
             if (!ok) warn("TextureSystem: texture " + full + " missing or not decodable");  // texture_system.cpp:50-56
             for (CapContext* c : w.ctxs)
                 check(ok ? cap_texture_upload(c, t, rgba.data(), tw, th) : cap_texture_upload(c, t, nullptr, 0, 0), "TextureSystem");

@@ -1,6 +1,7 @@
 // viewer_main.cpp — headless counterpart of the reference viewer (src/viewer/main.cpp:50-107): same call sequence
 // (Init, InitRenderSession, LoadSceneFromOBJ, Render per frame, ShutdownRenderSession, Shutdown), a frame loop
 // instead of the Win32 message pump, a PPM file instead of the swap chain.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,8 @@ int main(int argc, char** argv)
     int                 frames = 64, bounces = 1;
     bool                cornell_camera = true, realtime = false, feedback = true, lowres = false;
     float               move[3] = {0.f, 0.f, 0.f};  // camera translation per frame (a scripted fly-through, input_system.cpp:49-148)
+    float               view[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // --camera: position, forward, focal length
+    bool                custom_view = false;
     for (int i = 1; i < argc; ++i)
     {
         auto next = [&]() { return i + 1 < argc ? argv[++i] : ""; };
@@ -33,9 +36,14 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--lowres")) lowres = true;  // half-resolution interleaved indirect (lowres_indirect)
         else if (!std::strcmp(argv[i], "--move"))
             for (int k = 0; k < 3; ++k) move[k] = (float)std::atof(next());
+        else if (!std::strcmp(argv[i], "--camera"))
+        {
+            for (int k = 0; k < 7; ++k) view[k] = (float)std::atof(next());
+            custom_view = true;
+        }
         else
         {
-            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--gpus N] [--default-camera] [--realtime [--no-feedback] [--lowres] [--move dx dy dz]]\n", argv[0]);
+            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--gpus N] [--default-camera | --camera px py pz fx fy fz focal] [--realtime [--no-feedback] [--lowres] [--move dx dy dz]]\n", argv[0]);
             return 2;
         }
     }
@@ -48,7 +56,20 @@ int main(int argc, char** argv)
         capsaicin::GetSettings().reconstruct         = realtime;
         capsaicin::GetSettings().gbuffer_feedback    = feedback;
         capsaicin::GetSettings().lowres_indirect     = lowres;
-        if (cornell_camera)
+        if (custom_view)
+        {
+            // right and up as InputSystem derives them from the forward vector (input_system.cpp:134-141)
+            auto&       cam = capsaicin::GetCamera();
+            const float fl  = std::sqrt(view[3] * view[3] + view[4] * view[4] + view[5] * view[5]);
+            const float f[3] = {view[3] / fl, view[4] / fl, view[5] / fl};
+            float       r[3] = {-(f[1] * 0.f - f[2] * 1.f), -(f[2] * 0.f - f[0] * 0.f), -(f[0] * 1.f - f[1] * 0.f)};  // -cross(f, (0,1,0))
+            const float rl   = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+            for (float& x : r) x /= rl;
+            const float u[3] = {f[1] * r[2] - f[2] * r[1], f[2] * r[0] - f[0] * r[2], f[0] * r[1] - f[1] * r[0]};  // cross(f, right)
+            for (int k = 0; k < 3; ++k) cam.position[k] = view[k], cam.forward[k] = f[k], cam.right[k] = r[k], cam.up[k] = u[k];
+            cam.focal_length = view[6];
+        }
+        else if (cornell_camera)
         {
             // the reference default (0,15,0)/+z is tuned for Sponza; SURVEY.md 8d fixes this view for the Cornell box
             auto& cam = capsaicin::GetCamera();

@@ -48,6 +48,15 @@ int cap_geometry_materials(const CapGeometry* g, CapMaterial* out_materials);
 /* Convenience: cap_scene_upload(ctx, view...) */
 int cap_scene_upload_geometry(CapContext* ctx, const CapGeometry* g);
 
+/* Texture file -> what TextureSystem hands to the GPU (texture_system.cpp:41-45: stbi_load(file, &w, &h, &n, 4)): 8-bit RGBA,
+ * rows top to bottom, grey replicated, alpha 255 when the file has none.  Decodes PNG (non-interlaced), TGA and binary PPM
+ * (capsaicin_amd/csrc/image_decode.cpp); name_hint (may be NULL) is the file name, consulted for formats without a signature.
+ * Anything else returns CAP_ERR_UNSUPPORTED -- the caller then does what the reference does for a missing file: a warning and
+ * a 1x1 black texel (texture_system.cpp:50-56).  Release the pixels with cap_image_free. */
+int  cap_image_decode(const uint8_t* bytes, size_t size, const char* name_hint, uint8_t** out_rgba8, uint32_t* out_width,
+                      uint32_t* out_height);
+void cap_image_free(uint8_t* rgba8);
+
 /* Host-side tree build used by cap_bvh_build in SAH mode, callable without a GPU (tools, tests): triangle boxes in, the
  * device node layout out.  tri_boxes: n x 8 floats (lo.xyz, -, hi.xyz, -); nodes: 16 floats per internal node, n - 1 of
  * them (box of child 0, box of child 1, child0, child1, traversal child0, traversal child1 as int bits; a child < 0 is

@@ -1,0 +1,96 @@
+"""Texture decoding of the host layer (capsaicin_amd/csrc/image_decode.cpp, C ABI cap_image_decode) against PIL on files PIL
+writes: what TextureSystem's stbi_load(file, &w, &h, &n, 4) hands over in the reference (texture_system.cpp:41-45) -- 8-bit RGBA,
+rows top to bottom, grey replicated, alpha 255 when the file has none.  No GPU."""
+import io
+
+import numpy as np
+import pytest
+
+from capsaicin_amd import capi
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def image(mode, w=37, h=23, seed=0):
+    rs = np.random.RandomState(seed)
+    if mode == "P":
+        im = PIL.fromarray(rs.randint(0, 17, (h, w)).astype(np.uint8), "P")
+        im.putpalette(rs.randint(0, 256, 17 * 3).astype(np.uint8).tolist())
+        return im
+    if mode == "1":
+        return PIL.fromarray((rs.randint(0, 2, (h, w)) * 255).astype(np.uint8), "L").convert("1")
+    if mode == "I;16":
+        return PIL.fromarray(rs.randint(0, 65536, (h, w)).astype(np.uint16), "I;16")
+    ch = {"L": 1, "LA": 2, "RGB": 3, "RGBA": 4}[mode]
+    # smooth gradients + noise: exercises every PNG filter heuristics pick
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.stack([(xx * 5 + yy * 3 + 40 * c) % 256 for c in range(ch)], -1) + rs.randint(0, 9, (h, w, ch))
+    return PIL.fromarray(np.squeeze(a % 256).astype(np.uint8), mode)
+
+
+def expected(im):
+    if im.mode == "I;16":  # stb keeps the high byte of 16-bit samples
+        g = (np.asarray(im).astype(np.uint16) >> 8).astype(np.uint8)
+        return np.stack([g, g, g, np.full_like(g, 255)], -1)
+    return np.asarray(im.convert("RGBA"))
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "LA", "P", "1", "I;16"])
+@pytest.mark.parametrize("level", [0, 1, 9])
+def test_png(native_lib, mode, level):
+    im = image(mode, seed=level)
+    buf = io.BytesIO()
+    im.save(buf, "PNG", compress_level=level)  # level 0: stored blocks; others: dynamic / fixed Huffman
+    got = capi.image_decode(buf.getvalue(), "t.png")
+    assert got.shape == (im.height, im.width, 4) and np.array_equal(got, expected(im))
+
+
+def test_png_large_and_optimised(native_lib):
+    im = image("RGB", 300, 211, seed=5)
+    buf = io.BytesIO()
+    im.save(buf, "PNG", optimize=True)
+    assert np.array_equal(capi.image_decode(buf.getvalue()), expected(im))
+
+
+def test_png_interlaced_and_garbage_are_refused(native_lib):
+    # a hand-made IHDR with the interlace flag set
+    import struct
+    import zlib
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(b"\0" * 52)) + chunk(b"IEND", b"")
+    with pytest.raises(capi.CapError):
+        capi.image_decode(png, "i.png")
+    with pytest.raises(capi.CapError):
+        capi.image_decode(b"\xff\xd8\xff\xe0 not a format this build decodes", "t.jpg")
+    with pytest.raises(capi.CapError):
+        capi.image_decode(b"\x89PNG\r\n\x1a\n" + b"\0" * 40, "t.png")
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L"])
+@pytest.mark.parametrize("rle", [False, True])
+def test_tga(native_lib, mode, rle):
+    im = image(mode, 41, 19, seed=3)
+    if rle:  # runs for the run-length packets
+        a = np.asarray(im).copy()
+        a[4:9, 5:30] = a[4, 5]
+        im = PIL.fromarray(a, mode)
+    buf = io.BytesIO()
+    im.save(buf, "TGA", compression="tga_rle" if rle else None)
+    got = capi.image_decode(buf.getvalue(), "t.tga")
+    assert np.array_equal(got, expected(im))
+
+
+def test_tga_top_left_origin(native_lib):
+    im = image("RGB", 9, 7, seed=8)
+    buf = io.BytesIO()
+    im.save(buf, "TGA", orientation=1)  # top-left origin
+    assert np.array_equal(capi.image_decode(buf.getvalue(), "t.TGA"), expected(im))
+
+
+def test_ppm(native_lib):
+    im = image("RGB", 13, 5, seed=2)
+    buf = io.BytesIO()
+    im.save(buf, "PPM")
+    assert np.array_equal(capi.image_decode(buf.getvalue(), "t.ppm"), expected(im))
