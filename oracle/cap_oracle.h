@@ -160,6 +160,11 @@ void  oracle_post_destroy(void* chain);
 int oracle_post_frame(void* chain, const OraclePostSettings* settings, uint32_t frame_count, const OracleCamera* camera,
                       const OracleCamera* prev_camera, const float* indirect, const float* direct, const float* albedo,
                       const float* normal_depth, float* out);
+/* one pass on caller-supplied full-resolution images (see cap_oracle_post.cpp): 0 Gather, 1 Accumulate (arg = frame_count),
+ * 2 BlurDisocclusion, 3 Blur (arg = stride), 4 TAA */
+int oracle_post_pass(int pass, const OraclePostSettings* settings, uint32_t width, uint32_t height, uint32_t arg, const OracleCamera* camera,
+                     const OracleCamera* prev_camera, const float* in0, const float* in1, const float* in2, const float* in3,
+                     const float* in4, float* out0, float* out1);
 
 /* ---- pure functions (known-answer tests) ---- */
 void     oracle_halton23(uint32_t frame_count, float out[2]);                                   /* sampling.h:143-155 */

@@ -70,6 +70,7 @@ def lib():
         L.oracle_post_create.restype = C.c_void_p
         L.oracle_post_create.argtypes = [C.c_uint32, C.c_uint32]
         L.oracle_post_destroy.argtypes = [C.c_void_p]
+        L.oracle_post_pass.argtypes = [C.c_int, C.POINTER(PostSettings), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Camera), C.POINTER(Camera)] + [C.c_void_p] * 7
         L.oracle_post_frame.argtypes = [C.c_void_p, C.POINTER(PostSettings), C.c_uint32, C.POINTER(Camera), C.POINTER(Camera)] + [C.c_void_p] * 5
         L.oracle_wang_hash.restype = C.c_uint32
         L.oracle_wang_hash.argtypes = [C.c_uint32, C.c_uint32]
@@ -198,6 +199,20 @@ class PostChain:
 
 
 # ---- pure functions ----
+def post_pass(kind, settings, inputs, arg=0, cam=None, prev_cam=None):
+    """One pass of the reconstruction chain on full-resolution [h, w, 4] images: kind 0 Gather, 1 Accumulate (arg = frame_count),
+    2 BlurDisocclusion, 3 Blur (arg = stride), 4 TAA.  Returns (out0, out1)."""
+    ins = [np.ascontiguousarray(a, np.float32) if a is not None else None for a in inputs] + [None] * (5 - len(inputs))
+    h, w = ins[0].shape[:2]
+    out0, out1 = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    rc = lib().oracle_post_pass(kind, C.byref(settings), w, h, arg, C.byref(cam) if cam is not None else None,
+                                C.byref(prev_cam) if prev_cam is not None else None, *[(_p(a) if a is not None else None) for a in ins],
+                                _p(out0), _p(out1))
+    if rc:
+        raise RuntimeError("oracle_post_pass rc=%d" % rc)
+    return out0, out1
+
+
 def halton23(fc):
     o = np.zeros(2, np.float32); lib().oracle_halton23(fc, _p(o)); return o
 

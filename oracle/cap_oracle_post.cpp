@@ -626,4 +626,44 @@ int oracle_post_frame(void* handle, const OraclePostSettings* s, uint32_t frame_
     c.prev_nd = nd;
     return 0;
 }
+
+/* One pass of the chain on caller-supplied images (full resolution; w*h*4 floats each; unused inputs may be NULL): for known-answer
+ * tests that pin a pass by itself against an independent evaluation of the shader text (tests/test_oracle_post_kat.py).
+ * pass: 0 Gather(in0 = color, in1 = normal_depth) -> out0
+ *       1 Accumulate(in0 = color, in1 = normal_depth, in2 = color history, in3 = moments history, in4 = previous normal_depth) ->
+ *         out0 = color, out1 = moments          2 BlurDisocclusion(in0 = color, in1 = normal_depth, in2 = moments) -> out0
+ *       3 Blur(stride = arg; in0 = color, in1 = normal_depth) -> out0      4 TAA(in0 = color, in1 = normal_depth, in2 = history) -> out0 */
+int oracle_post_pass(int pass, const OraclePostSettings* s, uint32_t w, uint32_t h, uint32_t arg, const OracleCamera* cam,
+                     const OracleCamera* prev_cam, const float* in0, const float* in1, const float* in2, const float* in3,
+                     const float* in4, float* out0, float* out1)
+{
+    if (!s || !w || !h || !in0 || !in1 || !out0) return 1;
+    Image a, b, c, d, e, o0, o1;
+    for (Image* im : {&a, &b, &c, &d, &e, &o0, &o1}) im->init(w, h);
+    from_floats(a, in0), from_floats(b, in1);
+    if (in2) from_floats(c, in2);
+    if (in3) from_floats(d, in3);
+    if (in4) from_floats(e, in4);
+    switch (pass)
+    {
+    case 0: gather(*s, a, b, o0); break;
+    case 1:
+        if (!cam || !prev_cam || !in2 || !in3 || !in4 || !out1) return 1;
+        accumulate(*s, arg, *cam, *prev_cam, a, b, c, d, e, o0, o1);
+        break;
+    case 2:
+        if (!in2) return 1;
+        blur_disocclusion(*s, a, b, c, o0);
+        break;
+    case 3: blur(*s, arg, a, b, o0); break;
+    case 4:
+        if (!cam || !prev_cam || !in2) return 1;
+        taa(*s, *cam, *prev_cam, a, b, c, o0);
+        break;
+    default: return 2;
+    }
+    memcpy(out0, o0.px.data(), sizeof(f4) * (size_t)w * h);
+    if (out1) memcpy(out1, o1.px.data(), sizeof(f4) * (size_t)w * h);
+    return 0;
+}
 }
