@@ -425,11 +425,22 @@ def main():
                     ab = (BYTES_CLOSEST + trav) * tp.rays_extension / (tp.ms_trace_closest * 1e-3) / 1e9
                     troof.update({"traversal_bytes_per_ray": trav, "achieved_with_traversal_bytes": ab,
                                   "frac_with_traversal_bytes": ab / HBM_PEAK_GBS})
+                # the stand-alone shade stage of this path IS bound by HBM: SURVEY.md 8d's 144 B per shaded vertex (hit 16 + path state
+                # 32 read, path state 32 + extension ray 32 + shadow ray 32 written) -- the shading record of the hit triangle (96 B,
+                # random) and the texels come on top and show in `traffic` when the counters are quoted
+                spmc, ssrc = committed_counters("tree_shade")
+                shade_ms, shade_launches = tp.ms_shade, max(1, tp.launches_shade)
+                sroof = {"bound": "hbm", "kernel": "k_shade (attributes, material, direct light, BSDF sample, queue compaction)",
+                         "achieved": BYTES_VERTEX * tp.shaded_vertices / (shade_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "traffic": (spmc["hbm_bytes_per_launch"] / (shade_ms / shade_launches * 1e-3) / 1e9) if spmc else None,
+                         "traffic_source": ssrc, "avg_launch_ms": shade_ms / shade_launches, "launches": int(shade_launches),
+                         "bytes_per_vertex": BYTES_VERTEX, "vertices_per_step": int(tp.shaded_vertices)}
+                sroof["frac"] = sroof["achieved"] / HBM_PEAK_GBS
                 tree_variant = {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d 16spp depth=%d, reference shading" %
                                             (bi2.triangle_count, WIDTH, HEIGHT, DEPTH),
                                 "value": trays / tdt / 1e6, "unit": "Mrays/s", "ms_per_step": tdt / 2 * 1e3,
                                 "bvh": {"build": "host SAH + 8-wide collapse", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
-                                "roofline": troof,
+                                "roofline": troof, "shade_roofline": sroof,
                                 "stage_ms": {"primary": tp.ms_primary, "trace_closest": tp.ms_trace_closest, "trace_any": tp.ms_trace_any,
                                              "shade": tp.ms_shade, "resolve": tp.ms_resolve, "total": tp.ms_total}}
                 r2.close()

@@ -64,6 +64,9 @@ void launch_resolve(const LaunchCfg& cfg, const Planes& planes, uint32_t n_slots
 // plane_kind: 0 copy, 1 combined (color*albedo+direct from the three planes at slot offset), 2 mean (xyz / w)
 void launch_untile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* src, const float4* albedo, const float4* direct,
                    int plane_kind, float4* image);
+// s0 may be null (its image is produced elsewhere)
+void launch_untile4(const LaunchCfg& cfg, const ScreenDev& screen, const float4* s0, const float4* s1, const float4* s2, const float4* s3,
+                    float4* d0, float4* d1, float4* d2, float4* d3);
 void launch_tiles_mean(const LaunchCfg& cfg, const float4* accum, uint32_t pixels_padded, float4* dst);
 // shard_stride: float4 elements between two shards' buffers (0: pixels_padded, i.e. back to back)
 void launch_assemble(const LaunchCfg& cfg, const ScreenDev& screen, const float4* gathered, uint32_t shard_count, float4* image,

@@ -1397,11 +1397,8 @@ int cap_post_frame(CapContext* c, const CapPostSettings* s, uint32_t frame_count
         launch_decimate2x(c->stream, c->image_tmp.p, c->screen.width, c->screen.height, (frame_count % 4u) / 2u, (frame_count % 4u) % 2u,
                           c->post_in[0].p);
     }
-    else
-        launch_untile(cfg, c->screen, c->pl_color.p + off, nullptr, nullptr, 0, c->post_in[0].p);
-    launch_untile(cfg, c->screen, c->pl_direct.p + off, nullptr, nullptr, 0, c->post_in[1].p);
-    launch_untile(cfg, c->screen, c->pl_albedo.p + off, nullptr, nullptr, 0, c->post_in[2].p);
-    launch_untile(cfg, c->screen, c->aov_nd.p, nullptr, nullptr, 0, c->post_in[3].p);
+    launch_untile4(cfg, c->screen, lowres ? nullptr : c->pl_color.p + off, c->pl_direct.p + off, c->pl_albedo.p + off, c->aov_nd.p, c->post_in[0].p,
+                   c->post_in[1].p, c->post_in[2].p, c->post_in[3].p);
     return run_post_chain(c, s, frame_count, prev_camera);
 }
 

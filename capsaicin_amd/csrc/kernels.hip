@@ -2156,6 +2156,29 @@ __global__ __launch_bounds__(kBlock) void k_untile(ScreenDev sc, const float4* s
     }
 }
 
+// four tile-ordered planes -> four row-major images in one pass (the reconstruction chain's inputs)
+__global__ __launch_bounds__(kBlock) void k_untile4(ScreenDev sc, const float4* s0, const float4* s1, const float4* s2, const float4* s3,
+                                                    float4* d0, float4* d1, float4* d2, float4* d3)
+{
+    const uint32_t n = sc.local_tiles * kTilePixels;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < n; pl += gridDim.x * kBlock)
+    {
+        uint32_t x, y;
+        if (!local_pixel_to_xy(sc, pl, x, y)) continue;
+        const size_t o = (size_t)y * sc.width + x;
+        if (s0) d0[o] = s0[pl];
+        d1[o] = s1[pl], d2[o] = s2[pl], d3[o] = s3[pl];
+    }
+}
+
+void launch_untile4(const LaunchCfg& cfg, const ScreenDev& screen, const float4* s0, const float4* s1, const float4* s2, const float4* s3,
+                    float4* d0, float4* d1, float4* d2, float4* d3)
+{
+    uint32_t g = (screen.local_tiles * kTilePixels + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_untile4, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, screen, s0, s1, s2, s3, d0, d1, d2, d3);
+}
+
 void launch_untile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* src, const float4* albedo, const float4* direct,
                    int plane_kind, float4* image)
 {

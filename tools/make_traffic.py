@@ -15,7 +15,7 @@ import bench  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 KERNELS = {"headline": "k_trace_shade<false, false, false, true>", "ext": "k_trace_shade<false, true, false, true>",
-           "tree": "k_trace_closest8"}
+           "tree": "k_trace_closest8", "tree_shade": "k_shade<"}
 
 
 def total(pass_glob, counter, kernel):
@@ -23,7 +23,8 @@ def total(pass_glob, counter, kernel):
     if not fs:
         return 0.0, 0
     s, n = 0.0, 0
-    for r in csv.DictReader(open(fs[0])):
+    newest = max(fs, key=os.path.getmtime)  # gpurun merges into gpurun_out/: files of earlier runs may still lie there
+    for r in csv.DictReader(open(newest)):
         if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
             s += float(r["Counter_Value"])
             n += 1

@@ -9,7 +9,16 @@ def short(name):
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 # kernel trace
-for f in glob.glob(os.path.join(root, "prof_kt", "**", "*kernel_trace.csv"), recursive=True):
+def newest_per_dir(pattern):
+    by_dir = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = f.split(os.sep)[1] if root == "gpurun_out" else os.path.dirname(os.path.dirname(f))
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
+for f in newest_per_dir(os.path.join(root, "prof_kt", "**", "*kernel_trace.csv")):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         d[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -19,7 +28,7 @@ for f in glob.glob(os.path.join(root, "prof_kt", "**", "*kernel_trace.csv"), rec
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
         print("%-62s %8d %12.1f %10.1f %6.1f" % (k, len(v), sum(v), sum(v) / len(v), 100 * sum(v) / tot))
 # counters
-for f in sorted(glob.glob(os.path.join(root, "prof_pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+for f in newest_per_dir(os.path.join(root, "prof_pmc_*", "**", "*counter_collection.csv")):
     d = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
