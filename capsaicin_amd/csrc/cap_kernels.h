@@ -51,6 +51,7 @@ struct ShadeArgs
     uint64_t*         shaded_counter;
     uint32_t*         work;        // fused kernels: kQueueClasses chunk-grab counters of this launch (zeroed), kCounterStride apart
     FeedbackDev       fb;          // read only by the feedback variants
+    uint32_t          cull_camera_pairs;  // bounce 0 of the small-scene path: the camera basis is orthonormal, so a tile may skip the pairs off its screen area
 };
 // feedback: vertices of bounce >= 1 that the previous frame saw take its shaded colour and end the path (rt_indirect.hlsl:116-145;
 // reference shading model only)

@@ -6,6 +6,7 @@
 // kernel is available; there is no CPU fallback.
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1027,6 +1028,16 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         sa.scene = scene, sa.cam = cam, sa.screen = c->screen, sa.frames = frames, sa.hits = c->hits.p;
         sa.planes = Planes{c->pl_color.p, c->pl_direct.p, c->pl_albedo.p, c->aov_geo.p, c->aov_nd.p};
         sa.n_slots = ns, sa.num_bounces = D, sa.max_count = max_count, sa.aov_slot = aov_slot, sa.shaded_counter = c->shaded_counter.p;
+        {
+            // screen-space culling of bounce 0 inverts primary_dir (camera.h:39-63), which needs an orthonormal basis
+            static const bool no_cull = getenv("CAP_NO_CAMERA_CULL") != nullptr;  // A/B switch
+            auto dotf = [](const float* x, const float* y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+            const CapCameraData& cd = c->camera;
+            const bool ortho = std::fabs(dotf(cd.right, cd.up)) < 1e-4f && std::fabs(dotf(cd.right, cd.forward)) < 1e-4f &&
+                               std::fabs(dotf(cd.up, cd.forward)) < 1e-4f && std::fabs(dotf(cd.right, cd.right) - 1.f) < 1e-4f &&
+                               std::fabs(dotf(cd.up, cd.up) - 1.f) < 1e-4f && std::fabs(dotf(cd.forward, cd.forward) - 1.f) < 1e-4f;
+            sa.cull_camera_pairs = (ortho && !no_cull) ? 1u : 0u;
+        }
         if (feedback)  // g_color_history = combined_history[(frame_count + 1) % 2], raytracing_system.cpp:1754-1759
             sa.fb = FeedbackDev{camera_dev(c->prev_camera), c->post_prev_nd.p, c->post_chist[(frame_begin + 1) % 2].p};
         const bool fused = cfg.stack_entries == 0;  // small-scene path: closest hit and shading in one kernel per bounce

@@ -360,9 +360,11 @@ __device__ __forceinline__ PairScaled pair_scaled(const Ray& r, const float4* ba
 // a tree instead of a sequential compare chain (measured faster: more independent instructions for the scheduler to
 // interleave); "(t, id) lexicographic minimum" is associative, so the tree gives the winner of the sequential rule.
 // rec_tab: where the winner's record is re-read from (bvh.tris_by_id, or its LDS copy).
-template <bool ORG = false>
+// MANY: the scene may hold more than 32 fan pairs (only in forced exhaustive mode beyond kExhaustiveMax triangles)
+template <bool ORG = false, bool MANY = true>
 __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const float4* rec_tab, const Ray& r, float& best_t, float& best_u,
-                                                   float& best_v, uint32_t& best_gid, const float4* org_tab = nullptr)
+                                                   float& best_v, uint32_t& best_gid, const float4* org_tab = nullptr,
+                                                   uint32_t pair_mask = ~0u)
 {
     best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
     auto cand = [&](const TriScaled& s) {
@@ -392,31 +394,70 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const floa
             im = ib ? p.id + 1u : p.id;
         }
     };
+    // pair_mask (wave-uniform): the fan pairs some ray of the wave can reach at all (camera rays: the pairs whose screen bounds
+    // overlap the wave's tile, k_trace_shade); visited in ascending order, like the full list
     const uint32_t np = bvh.fan_pair_count;
-    uint32_t       k  = 0;
-    for (; k + 2 <= np; k += 2)
+    uint32_t       pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pair_mask & (np >= 32u ? ~0u : ((1u << np) - 1u))));
+    if (MANY && np > 32u)
     {
-        const PairScaled p0 = pair_scaled<ORG>(r, bvh.fan_pairs, k, org_tab), p1 = pair_scaled<ORG>(r, bvh.fan_pairs, k + 1, org_tab);
-        float            m01, m23;
-        uint32_t         i01, i23;
-        pair_cand(p0, m01, i01);
-        pair_cand(p1, m23, i23);
-        const bool     p  = m23 < m01;
-        const float    m  = p ? m23 : m01;
-        const uint32_t im = p ? i23 : i01;
-        const bool     better = m < best_t;
-        best_t   = better ? m : best_t;
-        best_gid = better ? im : best_gid;
+        // more pairs than the mask holds (forced exhaustive mode on a larger scene): every pair, two at a time
+        pm         = 0u;
+        uint32_t k = 0;
+        for (; k + 2 <= np; k += 2)
+        {
+            const PairScaled p0 = pair_scaled<ORG>(r, bvh.fan_pairs, k, org_tab), p1 = pair_scaled<ORG>(r, bvh.fan_pairs, k + 1, org_tab);
+            float            m01, m23;
+            uint32_t         i01, i23;
+            pair_cand(p0, m01, i01);
+            pair_cand(p1, m23, i23);
+            const bool     p  = m23 < m01;
+            const float    m  = p ? m23 : m01;
+            const uint32_t im = p ? i23 : i01;
+            const bool     better = m < best_t;
+            best_t   = better ? m : best_t;
+            best_gid = better ? im : best_gid;
+        }
+        if (k < np)
+        {
+            const PairScaled p0 = pair_scaled<ORG>(r, bvh.fan_pairs, k, org_tab);
+            float            m;
+            uint32_t         im;
+            pair_cand(p0, m, im);
+            const bool better = m < best_t;
+            best_t   = better ? m : best_t;
+            best_gid = better ? im : best_gid;
+        }
     }
-    if (k < np)
+    while (pm != 0u)
     {
-        const PairScaled p0 = pair_scaled<ORG>(r, bvh.fan_pairs, k, org_tab);
-        float            m;
-        uint32_t         im;
-        pair_cand(p0, m, im);
-        const bool better = m < best_t;
-        best_t   = better ? m : best_t;
-        best_gid = better ? im : best_gid;
+        const uint32_t k0 = (uint32_t)__builtin_ctz(pm);
+        pm &= pm - 1u;
+        if (pm != 0u)
+        {
+            const uint32_t k1 = (uint32_t)__builtin_ctz(pm);
+            pm &= pm - 1u;
+            const PairScaled p0 = pair_scaled<ORG>(r, bvh.fan_pairs, k0, org_tab), p1 = pair_scaled<ORG>(r, bvh.fan_pairs, k1, org_tab);
+            float            m01, m23;
+            uint32_t         i01, i23;
+            pair_cand(p0, m01, i01);
+            pair_cand(p1, m23, i23);
+            const bool     p  = m23 < m01;
+            const float    m  = p ? m23 : m01;
+            const uint32_t im = p ? i23 : i01;
+            const bool     better = m < best_t;
+            best_t   = better ? m : best_t;
+            best_gid = better ? im : best_gid;
+        }
+        else
+        {
+            const PairScaled p0 = pair_scaled<ORG>(r, bvh.fan_pairs, k0, org_tab);
+            float            m;
+            uint32_t         im;
+            pair_cand(p0, m, im);
+            const bool better = m < best_t;
+            best_t   = better ? m : best_t;
+            best_gid = better ? im : best_gid;
+        }
     }
     // ---- unpaired triangles ----
     const uint32_t ns = bvh.fan_single_count;
@@ -829,6 +870,189 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_any(Bv
 }
 
 // ------------------------------------------------------------------------------------------------
+// Shadow rays of the reference model on small scenes, with occluder-first ordering and wave-level compaction.
+//
+// An any-hit query is over at the first occluder, but the exhaustive loop is wave-uniform: it could only stop early when all 64
+// rays of the wave are occluded.  Inside a box most shadow rays ARE occluded, and by very few of the triangles -- whatever lies
+// farthest along the light direction (the ceiling of the Cornell box for the reference's light from above: 84 % of the shadow
+// rays of the headline workload; the other 16 % leave through the open front).  So the loop is split:
+//   probe   every ray is tested against the first `probe` fan pairs of an order sorted by how far along the light direction a
+//           pair's centre lies (per launch, for the light of the batch's first frame);
+//   rest    the rays that survived are parked in a per-wave LDS buffer; whenever 64 of them have gathered, the wave tests those 64
+//           against the remaining pairs and the unpaired triangles, and adds the contributions of the unoccluded ones.
+// An occlusion query's answer does not depend on the order of the tests, and each path has at most one shadow entry per launch,
+// so the planes receive the same additions as in k_trace_any: bit-identical images and counters.
+// ------------------------------------------------------------------------------------------------
+#ifndef CAP_ANY_GRAB
+#define CAP_ANY_GRAB 4  // chunk slots per grab of the probe kernel
+#endif
+#ifndef CAP_ANY_PROBE
+#define CAP_ANY_PROBE 1
+#endif
+constexpr uint32_t kSurvivorCap = 128;  // per wave: <= 63 parked + <= 64 new
+__global__ __launch_bounds__(kBlock) void k_trace_any_small(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded, uint32_t n_slots,
+                                                           uint64_t* guard, uint32_t* work, const FrameConst* frames, uint32_t probe)
+{
+    extern __shared__ float4 lds_pre[];  // PairPre rows per frame slot, see k_trace_any
+    __shared__ float4   lds_light[kMaxFrameSlots];
+    __shared__ float    lds_score[kExhaustiveMax / 2];
+    __shared__ uint32_t lds_order[kExhaustiveMax / 2];
+    __shared__ float4   lds_surv[(kBlock / 64) * kSurvivorCap];    // (origin, path id) of parked rays
+    __shared__ uint32_t lds_surv_i[(kBlock / 64) * kSurvivorCap];  // their queue entries
+    const uint32_t np      = bvh.fan_pair_count;  // <= kExhaustiveMax / 2
+    const uint32_t pre_row = 2u * np + 1u;
+    const float*   fp      = reinterpret_cast<const float*>(bvh.fan_pairs);
+    for (uint32_t k = threadIdx.x; k < n_slots && k < kMaxFrameSlots; k += kBlock)
+        lds_light[k] = make_float4(frames[k].light_dir[0], frames[k].light_dir[1], frames[k].light_dir[2], 0.f);
+    for (uint32_t e = threadIdx.x; e < n_slots * np; e += kBlock)
+    {
+        const uint32_t slot = e / np, k = e - slot * np;
+        const v3       d    = mk3(frames[slot].light_dir[0], frames[slot].light_dir[1], frames[slot].light_dir[2]);
+        const float*   rec  = fp + 20 * (size_t)k;  // (v0, e1, e2, e3, nA, nB, id, 0)
+        lds_pre[slot * pre_row + 2 * k]     = tri_pre(d, mk3(rec[12], rec[13], rec[14]), kRayEps, kRayFar);
+        lds_pre[slot * pre_row + 2 * k + 1] = tri_pre(d, mk3(rec[15], rec[16], rec[17]), kRayEps, kRayFar);
+    }
+    if (threadIdx.x < np)
+    {
+        const float* rec = fp + 20 * (size_t)threadIdx.x;
+        const v3     L   = mk3(frames[0].light_dir[0], frames[0].light_dir[1], frames[0].light_dir[2]);
+        const v3     v0  = mk3(rec[0], rec[1], rec[2]);
+        float        sc  = dot3(v0, L);  // sum over the quad's four vertices = 4 x its centre's reach
+        for (int e = 0; e < 3; ++e) sc += dot3(v0 + mk3(rec[3 + 3 * e], rec[4 + 3 * e], rec[5 + 3 * e]), L);
+        lds_score[threadIdx.x] = sc;
+    }
+    __syncthreads();
+    if (threadIdx.x < np)
+    {
+        // rank sort: position = pairs whose centre lies farther along the light (ties by index)
+        const float sc   = lds_score[threadIdx.x];
+        uint32_t    rank = 0;
+        for (uint32_t j = 0; j < np; ++j)
+        {
+            const float o = lds_score[j];
+            rank += (o > sc || (o == sc && j < threadIdx.x)) ? 1u : 0u;
+        }
+        lds_order[rank] = threadIdx.x;
+    }
+    __syncthreads();
+    const uint32_t  n_probe = probe < np ? probe : np;
+    const uint32_t  lane    = threadIdx.x & 63u;
+    float4* const   surv    = lds_surv + (threadIdx.x >> 6) * kSurvivorCap;
+    uint32_t* const surv_i  = lds_surv_i + (threadIdx.x >> 6) * kSurvivorCap;
+    uint32_t        surv_n  = 0;  // wave-uniform
+
+    // the rest of the tests for the parked rays [first, first + count), count <= 64
+    auto finish = [&](uint32_t first, uint32_t count) {
+        if (lane < count)
+        {
+            const float4   a    = surv[first + lane];
+            const uint32_t i    = surv_i[first + lane];
+            const uint32_t pid  = f2u(a.w);
+            const bool     good = (pid >> kPidShift) < n_slots && (pid & kPidMask) < pixels_padded;  // counted once, in the probe
+            const uint32_t slot = good ? (pid >> kPidShift) : 0u;
+            const float4   L    = lds_light[slot];
+            const Ray      r    = make_ray(mk3(a.x, a.y, a.z), mk3(L.x, L.y, L.z), kRayEps, good ? kRayFar : 0.0f);
+            const float4*  row  = lds_pre + slot * pre_row;
+            bool           hit  = false;
+            for (uint32_t j = n_probe; j < np; ++j)
+            {
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_order[j]);  // wave-uniform: scalar-cache record
+                hit |= pair_occludes_pre(r, bvh.fan_pairs, k, row[2 * k], row[2 * k + 1]);
+            }
+            const uint32_t ns = bvh.fan_single_count;
+            for (uint32_t j = 0; j < ns; ++j)
+            {
+                float4 t0, t1, t2, t3;
+                load_const_tri(bvh.fan_singles, j, t0, t1, t2, t3);
+                hit |= tri_occludes(r, t0, t1, t2);
+            }
+            if (!hit && good)
+            {
+                // lighting.h:57-60: unoccluded -> the contribution evaluated at shading time is added
+                const size_t idx = (size_t)(pid >> kPidShift) * pixels_padded + (pid & kPidMask);
+                const float4 c = q.contrib_pid[i], cur = target[idx];
+                target[idx]    = make_float4(cur.x + c.x, cur.y + c.y, cur.z + c.z, cur.w);
+            }
+        }
+    };
+
+    const uint32_t my_class = wave_global_id() % kQueueClasses;
+    uint32_t       n_class  = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.count[my_class * kCounterStride]);
+    n_class                 = n_class < q.class_capacity ? n_class : q.class_capacity;
+    // The probe is short (a few hundred cycles per chunk), far shorter than a returned device atomic or a queue-entry load take:
+    // a grab therefore fetches kGrabChunks consecutive chunk slots of the class, the grab for the next group is issued when a
+    // group is started, and within the stream of chunks the entry of the NEXT chunk is loaded before this chunk is worked on.
+    constexpr uint32_t kGrabChunks = CAP_ANY_GRAB;
+    auto grab_group = [&]() {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(work + my_class * kCounterStride, kGrabChunks);
+        return v;
+    };
+    uint32_t grab     = grab_group();
+    uint32_t local0   = grab_value(grab) * 64u;  // first ray of the chunk being worked on
+    grab              = grab_group();
+    uint32_t in_group = 0;
+    float4   a_next   = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (local0 + lane < n_class) a_next = q.org_tmin[my_class * q.class_capacity + local0 + lane];
+    while (true)
+    {
+        if (local0 >= n_class) break;  // past the end of this class's sub-queue (groups are handed out in order)
+        const bool     active = local0 + lane < n_class;
+        const uint32_t i      = my_class * q.class_capacity + local0 + lane;
+        const float4   a      = a_next;
+        // the next chunk: the next one of this group, or the first one of the next group
+        if (++in_group == kGrabChunks)
+        {
+            in_group = 0;
+            local0   = grab_value(grab) * 64u;
+            grab     = grab_group();
+        }
+        else
+            local0 += 64u;
+        if (local0 + lane < n_class) a_next = q.org_tmin[my_class * q.class_capacity + local0 + lane];
+        bool hit = false;
+        if (active)
+        {
+            const uint32_t pid  = f2u(a.w);
+            const bool     good = (pid >> kPidShift) < n_slots && (pid & kPidMask) < pixels_padded;
+            if (!good)
+            {
+                // never true for a well-formed queue; reported through CapStats::guard_* instead of faulting
+                atomicAdd((unsigned long long*)guard + 2, 1ull);
+                guard[3] = ((uint64_t)i << 32) | pid;
+            }
+            const uint32_t slot = good ? (pid >> kPidShift) : 0u;
+            const float4   L    = lds_light[slot];
+            const Ray      r    = make_ray(mk3(a.x, a.y, a.z), mk3(L.x, L.y, L.z), kRayEps, good ? kRayFar : 0.0f);
+            const float4*  row  = lds_pre + slot * pre_row;
+            for (uint32_t j = 0; j < n_probe; ++j)
+            {
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_order[j]);
+                hit |= pair_occludes_pre(r, bvh.fan_pairs, k, row[2 * k], row[2 * k + 1]);
+            }
+        }
+        // park the survivors
+        const bool               alive = active && !hit;
+        const unsigned long long m     = __ballot(alive);
+        if (alive)
+        {
+            const uint32_t at = surv_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            surv[at]   = a;
+            surv_i[at] = i;
+        }
+        surv_n += (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (surv_n >= 64u)
+        {
+            surv_n -= 64u;
+            finish(surv_n, 64u);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (surv_n) finish(0u, surv_n);
+}
+
+// ------------------------------------------------------------------------------------------------
 // LBVH traversal with lane refill.  Incoherent rays leave a wave in the stack loop for the MAXIMUM of 64 traversal lengths
 // (measured on the 262 k-triangle scene: 11 of 64 lanes active on average).  Here a lane that finishes its ray takes the next
 // ray of the wave's own chunk sequence, so the wave keeps its lanes busy until that sequence is exhausted.  The feed is
@@ -1214,6 +1438,19 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
     // shadow rays share one direction per frame and retire early: the plain per-chunk kernel beats the refill variant here
     // (8.3 vs 10.5 ms on the 262 k-triangle scene when it was tried)
     const uint32_t pre = (cfg.stack_entries == 0 && !mostly_unoccluded) ? pre_table_bytes(n_slots, bvh.fan_pair_count) : 0u;
+    static const bool     no_probe = getenv("CAP_NO_ANY_PROBE") != nullptr;  // A/B switch
+    static const uint32_t probe    = getenv("CAP_ANY_PROBE") ? (uint32_t)atoi(getenv("CAP_ANY_PROBE")) : (uint32_t)CAP_ANY_PROBE;
+    if (pre != 0u && work && !no_probe && bvh.fan_pair_count <= kExhaustiveMax / 2)
+    {
+        // (3 .. 8 workgroups per CU measure the same: what is left is the planes' scattered read-modify-write traffic)
+        static const uint32_t per_cu = getenv("CAP_ANY_BLOCKS") ? (uint32_t)atoi(getenv("CAP_ANY_BLOCKS")) : 6u;
+        uint32_t g = (max_count + kBlock - 1) / kBlock;
+        const uint32_t cap = cfg.cu_count ? cfg.cu_count * per_cu : cfg.grid_blocks;
+        g = g > cap ? cap : (g ? g : 1u);
+        grid = dim3(g);
+        hipLaunchKernelGGL(k_trace_any_small, grid, dim3(kBlock), pre, cfg.stream, bw, q, target, pixels_padded, n_slots, guard, work, frames, probe);
+        return;
+    }
 #define CAP_LAUNCH_ANY(S, R) \
     hipLaunchKernelGGL((k_trace_any<S, R>), grid, dim3(kBlock), pre, cfg.stream, bw, q, target, pixels_padded, n_slots, guard, work, frames, pre)
     if (cfg.stack_entries == 0)
@@ -1941,6 +2178,11 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
     __shared__ float4     lds_rec[LDS ? 4 * kExhaustiveMax : 1];
     constexpr bool        ORG = FIRST && LDS;  // camera rays of a small scene: per-pair origin terms from a table (pair_scaled<ORG>)
     __shared__ float4     lds_org[ORG ? kExhaustiveMax : 1];
+    // ORG: pixel bounds (x0, y0, x1, y1) of every fan pair as the launch's camera sees it, grown by two pixels (the sub-pixel
+    // jitter of the frames and the rounding of the projection); a pair with a vertex at or behind the camera plane covers the
+    // screen.  A tile of camera rays only tests the pairs whose bounds overlap it: a ray can only hit a quad through a sample
+    // point inside the quad's projection, so the pairs left out are missed by all 64 rays -- same hits, same bits.
+    __shared__ float4     lds_bounds[ORG ? kExhaustiveMax / 2 : 1];
     if (LDS)
     {
         const uint32_t n = bvh.tri_count <= kExhaustiveMax ? bvh.tri_count : kExhaustiveMax;
@@ -1956,6 +2198,22 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
                 const v3     tvec = o - mk3(rec[0], rec[1], rec[2]);
                 lds_org[2 * k]     = make_float4(tvec.x, tvec.y, tvec.z, dot3(tvec, mk3(rec[12], rec[13], rec[14])));
                 lds_org[2 * k + 1] = make_float4(dot3(tvec, mk3(rec[15], rec[16], rec[17])), 0.f, 0.f, 0.f);
+                // screen bounds: pixel = ((f * (d.right) / (d.forward)) / sensor + 0.5) * extent  (inverse of primary_dir, camera.h:39-63)
+                const v3 R = mk3(a.cam.right[0], a.cam.right[1], a.cam.right[2]), U = mk3(a.cam.up[0], a.cam.up[1], a.cam.up[2]),
+                         F = mk3(a.cam.forward[0], a.cam.forward[1], a.cam.forward[2]);
+                float x0 = 3.0e38f, y0 = 3.0e38f, x1 = -3.0e38f, y1 = -3.0e38f;
+                bool  behind = false;
+                for (int e = 0; e < 4; ++e)
+                {
+                    const v3    d = e == 0 ? tvec * -1.0f : (mk3(rec[3 * e], rec[3 * e + 1], rec[3 * e + 2]) - tvec);  // vertex - camera
+                    const float z = dot3(d, F);
+                    behind |= !(z > 1e-4f);
+                    const float px = ((a.cam.focal_length * dot3(d, R) / z) / a.cam.sensor_x + 0.5f) * (float)a.screen.width;
+                    const float py = ((a.cam.focal_length * dot3(d, U) / z) / a.cam.sensor_y + 0.5f) * (float)a.screen.height;
+                    x0 = fminf(x0, px), x1 = fmaxf(x1, px), y0 = fminf(y0, py), y1 = fmaxf(y1, py);
+                }
+                const bool usable = a.cull_camera_pairs != 0u && !behind && x0 == x0 && y0 == y0 && x1 == x1 && y1 == y1;
+                lds_bounds[k] = usable ? make_float4(x0 - 2.0f, y0 - 2.0f, x1 + 2.0f, y1 + 2.0f) : make_float4(-3.0e38f, -3.0e38f, 3.0e38f, 3.0e38f);
             }
         }
     }
@@ -2022,8 +2280,18 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
         // the append atomic, the stores) is short and latency-bound.  Raising the wave's priority outside the loop lets those
         // phases issue ahead of other waves' loops, so more memory operations are in flight per SIMD (closest 18.1 -> 17.5 ms;
         // the opposite assignment: no gain).
+        uint32_t pair_mask = ~0u;
+        if (ORG)
+        {
+            // the tile of this chunk against the pairs' screen bounds: lane k answers for pair k
+            uint32_t tx = 0, ty = 0;
+            (void)local_pixel_to_xy(a.screen, i & ~63u, tx, ty);  // first pixel of the 8x8 tile
+            const float4 b    = lds_bounds[lane < kExhaustiveMax / 2 ? lane : 0u];
+            const bool   over = lane < bvh.fan_pair_count && b.x < (float)(tx + 8u) && b.z >= (float)tx && b.y < (float)(ty + 8u) && b.w >= (float)ty;
+            pair_mask         = (uint32_t)__ballot(over);
+        }
         __builtin_amdgcn_s_setprio(0);
-        exhaustive_closest<ORG>(bvh, rec_tab, r, t, u, v, gid, lds_org);
+        exhaustive_closest<ORG, !LDS>(bvh, rec_tab, r, t, u, v, gid, lds_org, pair_mask);
         __builtin_amdgcn_s_setprio(3);
         STAMP(st, 1, true);  // triangle loop + winner's record
         const ShadePre pre = shade_prefetch<EXT, FIRST, CARRY>(a, lds_frames, active, pid, carried_r1, carried_r2);
