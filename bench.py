@@ -42,7 +42,7 @@ def committed_counters(key):
     """Per-launch HBM bytes / vector instructions of one kernel from the newest profiles/rNN_traffic.json (PMC passes of this very
     command, tools/make_traffic.py; counters cannot be collected from inside the timed process).  None when the kernel sources
     have changed since the passes were taken."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
     if not files:
         return None, None
     try:
