@@ -289,50 +289,6 @@ __global__ __launch_bounds__(kBlock) void k_refit(BvhBuildArgs a, const uint32_t
     }
 }
 
-// Wide view of the binary tree: for every internal node the boxes and traversal pointers of its (up to four) GRANDchildren -- a
-// child that is a traversal leaf stays as it is.  128 B = 8 x float4 per node, SoA over the four slots:
-//   lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4] (int bits) -
-// A ray visiting node i tests four boxes with one fetch and descends two binary levels: half the dependent fetches per ray.
-// Unused slots hold child kNoChild (and an empty box, which by itself would NOT fail the conservative slab test).
-__global__ __launch_bounds__(kBlock) void k_node4(const float4* nodes, uint32_t n_internal, float4* nodes4)
-{
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_internal) return;
-    float lo[3][4], hi[3][4];
-    int   ch[4];
-    for (int k = 0; k < 4; ++k)
-    {
-        for (int a = 0; a < 3; ++a) lo[a][k] = 3.402823466e+38f, hi[a][k] = -3.402823466e+38f;
-        ch[k] = kNoChild;
-    }
-    int        cnt = 0;
-    const auto emit = [&](const float* box, int child) {
-        for (int a = 0; a < 3; ++a) lo[a][cnt] = box[a], hi[a][cnt] = box[3 + a];
-        ch[cnt++] = child;
-    };
-    const float* q  = reinterpret_cast<const float*>(nodes + 4 * (size_t)i);  // 12 box floats, then child0 child1 tchild0 tchild1
-    const int    c[2] = {(int)f2u(q[14]), (int)f2u(q[15])};
-    for (int s = 0; s < 2; ++s)
-    {
-        if (c[s] >= 0)
-        {
-            const float* g = reinterpret_cast<const float*>(nodes + 4 * (size_t)c[s]);
-            emit(g, (int)f2u(g[14]));
-            emit(g + 6, (int)f2u(g[15]));
-        }
-        else
-            emit(q + 6 * s, c[s]);
-    }
-    float4* o = nodes4 + 8 * (size_t)i;
-    for (int a = 0; a < 3; ++a)
-    {
-        o[a]     = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
-        o[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
-    }
-    o[6] = make_float4(u2f((uint32_t)ch[0]), u2f((uint32_t)ch[1]), u2f((uint32_t)ch[2]), u2f((uint32_t)ch[3]));
-    o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 __global__ __launch_bounds__(kBlock) void k_depth(const uint32_t* parent, uint32_t n, uint32_t* max_depth)
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -397,7 +353,6 @@ void launch_bvh_finish_host(hipStream_t stream, const BvhBuildArgs& a)
     if (n == 0) return;
     const uint32_t blocks = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_gather_sorted, dim3(blocks), dim3(kBlock), 0, stream, a);
-    if (n >= 2 && a.nodes4) hipLaunchKernelGGL(k_node4, dim3(blocks), dim3(kBlock), 0, stream, a.nodes, n - 1, a.nodes4);
 }
 
 
@@ -432,7 +387,6 @@ void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
         (void)hipMemcpyAsync(a.vals[0], &zero, sizeof(zero), hipMemcpyHostToDevice, stream);
     }
     hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(kBlock), 0, stream, a, sorted_vals);
-    if (n >= 2 && a.nodes4) hipLaunchKernelGGL(k_node4, dim3(blocks), dim3(kBlock), 0, stream, a.nodes, n - 1, a.nodes4);
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(kBlock), 0, stream, a.parent, n, a.max_depth);
 }
 }  // namespace cap

@@ -24,11 +24,9 @@ constexpr uint32_t kQueueClasses  = 64;
 constexpr uint32_t kCounterStride = 32;  // uint32 words between two class counters (128 B)
 constexpr uint32_t kExhaustiveMax = 64;  // scenes up to this many triangles are traced exhaustively (kernels.hip)
 constexpr int      kNoChild        = 0x7fffffff;  // unused slot of a wide node
-#ifndef CAP_WIDE_LDS
-#define CAP_WIDE_LDS 24  // LDS entries of the wide closest-hit kernel's per-lane stack (24 KB per workgroup: six workgroups per CU)
-#endif
-constexpr uint32_t kWideLdsEntries = CAP_WIDE_LDS;
-constexpr uint32_t kSpillEntries   = 48 - CAP_WIDE_LDS;  // per-thread stack entries kept in global memory behind the LDS part
+// k_trace_any on the 8-wide view: 24 LDS words per lane = 12 (g_base, g_mask) pairs (24 KB per workgroup: six workgroups per CU)
+constexpr uint32_t kWideLdsEntries = 24;
+constexpr uint32_t kSpillEntries   = 24;  // per-thread stack words (12 pairs) kept in global memory behind the LDS part
 
 // BVH node, 64 B = 4 x float4 (both children's boxes live in the parent, one fetch tests both):
 //   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
@@ -42,10 +40,8 @@ constexpr uint32_t kSpillEntries   = 48 - CAP_WIDE_LDS;  // per-thread stack ent
 struct BvhDev
 {
     const float4* nodes;
-    const float4* nodes4;      // wide view: per internal node the four grandchild boxes, SoA, 128 B (bvh.hip k_node4)
     uint32_t*     stack_spill; // kSpillEntries words per thread of the persistent grid: stack entries beyond the LDS part
     uint32_t      spill_threads;  // threads the spill area is sized for
-    uint32_t      wide_ok;        // the wide kernels' stack bound 3 * ceil(depth / 2) fits kWideLdsEntries + kSpillEntries entries
     const float4* tris;        // 64-B intersection records in leaf order (.w of the 4th float4 = global triangle id)
     const float4* tris_by_id;  // the same records in global triangle id order (exhaustive small-scene kernels)
     // exhaustive loop order: fan pairs (triangles id, id + 1 sharing v0 and the edge v0->v2), 20 floats each

@@ -89,7 +89,6 @@ struct BvhBuildArgs
     float4*         shade_tris;     // 6 per triangle, global order
     float4*         tris_sorted;    // 4 per triangle, leaf order
     float4*         nodes;          // 4 per internal node
-    float4*         nodes4;         // 8 per internal node: boxes and traversal pointers of its grandchildren (or NULL)
     uint32_t*       leaf_tri;       // global triangle id per leaf
     // scratch
     float4*         tri_raw;        // 4 per triangle, global order

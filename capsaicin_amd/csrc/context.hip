@@ -142,7 +142,6 @@ struct CapContext
 
     // BVH
     DevBuf<float4>   shade_tris, tris_sorted, nodes, tri_raw, tri_box;
-    DevBuf<float4>   nodes4;                  // wide view of the tree, 8 float4 per internal node (bvh.hip k_node4)
     DevBuf<float4>   nodes8, tris8;           // compressed 8-wide view (cap_wide.h) and its intersection records
     DevBuf<uint32_t> wide_src;                // scratch: leaf-order index per wide-order record
     uint32_t         wide8_depth = 0, wide8_top = 0, wide8_nodes = 0;
@@ -366,12 +365,10 @@ BvhDev bvh_dev(const CapContext* c)
     b.nodes     = c->nodes.p;
     b.tris      = c->tris_sorted.p;
     b.tris_by_id = c->tri_raw.p;
-    b.nodes4 = c->nodes4.p;
     b.stack_spill   = c->stack_spill.p;
     b.spill_threads = (uint32_t)(c->stack_spill.n / kSpillEntries);
-    static const bool binary_only = getenv("CAP_BVH_BINARY") != nullptr;  // A/B switch: binary traversal kernels only
-    b.wide_ok = !binary_only && c->stack_spill.p && c->tri_count >= 2 && 3u * ((c->bvh_info.max_depth + 1u) / 2u) <= kWideLdsEntries + kSpillEntries;
-    static const bool no_wide8 = getenv("CAP_NO_WIDE8") != nullptr;  // A/B switch: the 4-wide / binary kernels of round 1
+    // A/B switch: the binary-tree kernels (also what runs if the 8-wide view's depth ever exceeds the pair stacks)
+    static const bool no_wide8 = getenv("CAP_NO_WIDE8") != nullptr || getenv("CAP_BVH_BINARY") != nullptr;
     b.nodes8 = c->nodes8.p, b.tris8 = c->tris8.p;
     b.wide8_ok  = !no_wide8 && c->stack_spill.p && c->wide8_nodes != 0 && c->wide8_depth <= wide8_stack_pairs() + 1u &&
                  c->wide8_depth <= kWideLdsEntries / 2u + kSpillEntries / 2u + 1u;
@@ -673,7 +670,6 @@ int cap_bvh_build(CapContext* c)
     HIP_TRY(c->tri_raw.ensure(4 * (size_t)n));
     HIP_TRY(c->tri_box.ensure(2 * (size_t)n));
     HIP_TRY(c->nodes.ensure(4 * (size_t)(n > 1 ? n - 1 : 1)));
-    HIP_TRY(c->nodes4.ensure(8 * (size_t)(n > 1 ? n - 1 : 1)));
     HIP_TRY(c->stack_spill.ensure((size_t)c->cu_count * 8 * kBlock * kSpillEntries));  // up to 8 workgroups per CU
     HIP_TRY(c->leaf_tri.ensure(n));
     HIP_TRY(c->keys0.ensure(n));
@@ -688,7 +684,6 @@ int cap_bvh_build(CapContext* c)
     a.positions = c->positions.p, a.normals = c->normals.p, a.texcoords = c->texcoords.p, a.indices = c->indices.p;
     a.tri_ids = c->tri_ids.p, a.mesh_offsets = c->mesh_offsets.p, a.tri_count = n;
     a.shade_tris = c->shade_tris.p, a.tris_sorted = c->tris_sorted.p, a.nodes = c->nodes.p, a.leaf_tri = c->leaf_tri.p;
-    a.nodes4 = c->nodes4.p;
     a.tri_raw = c->tri_raw.p, a.tri_box = c->tri_box.p;
     a.keys[0] = c->keys0.p, a.keys[1] = c->keys1.p, a.vals[0] = c->vals0.p, a.vals[1] = c->vals1.p;
     a.hist = c->hist.p, a.parent = c->parent.p, a.flags = c->flags.p, a.bounds = c->bvh_misc.p, a.max_depth = c->bvh_misc.p + 6;

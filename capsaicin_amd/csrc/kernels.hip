@@ -12,135 +12,6 @@
 
 namespace cap
 {
-// ---- wide view of the tree (bvh.hip k_node4): four grandchild boxes per 128-B node, two binary levels per step ----
-// Per-lane stack: STACK entries in LDS, then kSpillEntries in global memory (a wide step pushes up to three entries; the host
-// enables these paths only when 3 * ceil(depth / 2) fits, BvhDev::wide_ok, and only on 1-D grids the spill area covers).
-template <int STACK>
-struct LaneStack
-{
-    uint32_t* lds;    // this lane's column: entry k at lds[k * kBlock]
-    uint32_t* spill;  // this thread's kSpillEntries words
-    int       sp;
-    __device__ __forceinline__ void push(int x)
-    {
-        if (sp < STACK)
-            lds[sp * kBlock] = (uint32_t)x;
-        else
-            spill[sp - STACK] = (uint32_t)x;
-        ++sp;
-    }
-    __device__ __forceinline__ int pop()
-    {
-        --sp;
-        return (int)(sp < STACK ? lds[sp * kBlock] : spill[sp - STACK]);
-    }
-};
-__device__ __forceinline__ uint32_t* spill_of_thread(const BvhDev& bvh)
-{
-    return bvh.stack_spill + (size_t)(blockIdx.x * kBlock + threadIdx.x) * kSpillEntries;
-}
-// Tests the four slots of wide node `node`; returns the number of boxes hit and their children sorted by entry distance.
-__device__ __forceinline__ int wide_step(const BvhDev& bvh, const Ray& r, int node, float tfar, bool sorted, int ch[4])
-{
-    const float4* N  = bvh.nodes4 + 8 * (size_t)node;
-    const float4  lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], cc = N[6];
-    float         tn[4];
-    ch[0] = (int)f2u(cc.x), ch[1] = (int)f2u(cc.y), ch[2] = (int)f2u(cc.z), ch[3] = (int)f2u(cc.w);
-    // an unused slot is told by its child value, not by its box: the slab test's overflow handling is conservative
-    // (inf * inv never rejects), so no box content reliably fails it
-    const bool  h0 = slab(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, tfar, tn[0]) && ch[0] != kNoChild;
-    const bool  h1 = slab(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, tfar, tn[1]) && ch[1] != kNoChild;
-    const bool  h2 = slab(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, tfar, tn[2]) && ch[2] != kNoChild;
-    const bool  h3 = slab(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, tfar, tn[3]) && ch[3] != kNoChild;
-    const float kInf = __builtin_inff();
-    tn[0] = h0 ? tn[0] : kInf, tn[1] = h1 ? tn[1] : kInf, tn[2] = h2 ? tn[2] : kInf, tn[3] = h3 ? tn[3] : kInf;
-    auto cswap = [&](int i, int j) {
-        const bool  sw = tn[j] < tn[i];
-        const float ta = sw ? tn[j] : tn[i], tb = sw ? tn[i] : tn[j];
-        const int   ca = sw ? ch[j] : ch[i], cb = sw ? ch[i] : ch[j];
-        tn[i] = ta, tn[j] = tb, ch[i] = ca, ch[j] = cb;
-    };
-    cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);  // misses (+inf) end up last even when order is not needed
-    (void)sorted;
-    return (int)h0 + (int)h1 + (int)h2 + (int)h3;
-}
-
-template <int STACK>
-__device__ __forceinline__ void traverse_closest4(const BvhDev& bvh, const Ray& r, uint32_t* stack, float& best_t, float& best_u,
-                                                  float& best_v, uint32_t& best_gid)
-{
-    best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
-    LaneStack<STACK> st{stack, spill_of_thread(bvh), 0};
-    int              node = bvh.root;
-    while (true)
-    {
-        if (node >= 0)
-        {
-            int       ch[4];
-            const int nh = wide_step(bvh, r, node, best_t, true, ch);
-            if (nh > 0)
-            {
-                node = ch[0];
-                if (nh > 3) st.push(ch[3]);
-                if (nh > 2) st.push(ch[2]);
-                if (nh > 1) st.push(ch[1]);
-                continue;
-            }
-        }
-        else
-        {
-            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
-            for (uint32_t leaf = first; leaf <= last; ++leaf)
-            {
-                const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
-                float        t, u, v;
-                if (tri_test(r, t0, t1, t2, t, u, v))
-                {
-                    const uint32_t gid = f2u(bvh.tris[4 * leaf + 3].x);
-                    if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
-                }
-            }
-        }
-        if (st.sp == 0) break;
-        node = st.pop();
-    }
-}
-
-template <int STACK>
-__device__ __forceinline__ bool traverse_any4(const BvhDev& bvh, const Ray& r, uint32_t* stack)
-{
-    LaneStack<STACK> st{stack, spill_of_thread(bvh), 0};
-    int              node = bvh.root;
-    while (true)
-    {
-        if (node >= 0)
-        {
-            int       ch[4];
-            const int nh = wide_step(bvh, r, node, r.tmax, false, ch);
-            if (nh > 0)
-            {
-                node = ch[0];
-                if (nh > 3) st.push(ch[3]);
-                if (nh > 2) st.push(ch[2]);
-                if (nh > 1) st.push(ch[1]);
-                continue;
-            }
-        }
-        else
-        {
-            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
-            for (uint32_t leaf = first; leaf <= last; ++leaf)
-            {
-                const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
-                if (tri_occludes(r, t0, t1, t2)) return true;
-            }
-        }
-        if (st.sp == 0) break;
-        node = st.pop();
-    }
-    return false;
-}
-
 // Closest hit: minimum t, equal t resolved towards the lower global triangle id (visit-order independent).
 // stack: this lane's column of the per-wave LDS stack; entry k lives at stack[k * kBlock].
 template <int STACK>
@@ -149,7 +20,6 @@ __device__ __forceinline__ void traverse_closest(const BvhDev& bvh, const Ray& r
 {
     best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
     if (bvh.tri_count == 0) return;
-    if (bvh.wide_ok) return traverse_closest4<STACK>(bvh, r, stack, best_t, best_u, best_v, best_gid);  // wave-uniform
     int node = bvh.root;
     int sp   = 0;
     while (true)
@@ -201,7 +71,6 @@ __device__ __forceinline__ bool traverse_any(const BvhDev& bvh, const Ray& r, ui
 {
     if (bvh.tri_count == 0) return false;
     if (bvh.wide8_ok) return traverse_any8<STACK>(bvh, r, stack);  // wave-uniform
-    if (bvh.wide_ok) return traverse_any4<STACK>(bvh, r, stack);  // wave-uniform
     int node = bvh.root;
     int sp   = 0;
     while (true)
@@ -603,7 +472,7 @@ constexpr int stack_residency(int stack_entries) { return stack_entries == 0 ? 0
 
 // One workgroup per four 64-pixel groups of a frame slot (blockIdx.y): camera rays are coherent but their cost varies strongly
 // over the image, and a persistent grid with static slots left long tails here (4.1 -> 5.4 ms on the 262 k-triangle scene).
-// The grid is therefore far larger than the wide traversal's spill area: binary traversal (wide_ok cleared by the launcher).
+// The grid is therefore far larger than the wide traversal's spill area: binary traversal (wide8_ok cleared by the launcher).
 template <int STACK>
 __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_primary(BvhDev bvh, CameraDev cam, ScreenDev screen, const FrameConst* frames,
                                                           float4* hits)
@@ -1218,136 +1087,11 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_closes
     }
 }
 
-// The same kernel on the wide view of the tree (bvh.hip k_node4): two binary levels per step.
-#ifndef CAP_WIDE_BLOCKS
-#define CAP_WIDE_BLOCKS 6
-#endif
-template <int STACK>
-__global__ __launch_bounds__(kBlock, CAP_WIDE_BLOCKS) void k_trace_closest_refill4(BvhDev bvh, RayQueue q, float4* hits)
-{
-    __shared__ uint32_t lds_stack[STACK * kBlock];
-    uint32_t*           stack = lds_stack + threadIdx.x;
-    // entries beyond the LDS part (a wide step pushes up to three; the host checks 3 * ceil(depth / 2) <= STACK + kSpillEntries)
-    uint32_t* const spill = bvh.stack_spill + (size_t)(blockIdx.x * kBlock + threadIdx.x) * kSpillEntries;
-    WaveFeed            feed;
-    feed_init(feed, q.class_capacity);
-    if (bvh.tri_count == 0)
-    {
-        // no geometry: every queued ray misses
-        for (uint32_t cs = wave_global_id(); cs < feed.slots; cs += wave_total())
-        {
-            uint32_t i, klass;
-            if (queue_chunk(q.count, q.class_capacity, cs, threadIdx.x & 63u, i, klass)) hits[i] = make_float4(0.f, 0.f, u2f(kInvalidId), 0.f);
-        }
-        return;
-    }
-    bool     alive = false;
-    Ray      r     = make_ray(mk3(0, 0, 0), mk3(0, 0, 1), 0.f, 0.f);
-    float    best_t = 0.f, best_u = 0.f, best_v = 0.f;
-    uint32_t best_gid = kInvalidId, out = 0;
-    int      node = 0, sp = 0;
-    auto     push = [&](int x) {
-        if (sp < STACK)
-            stack[sp * kBlock] = (uint32_t)x;
-        else
-            spill[sp - STACK] = (uint32_t)x;
-        ++sp;
-    };
-    while (true)
-    {
-        const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
-        if (!feed.exhausted && 64u - n_alive >= kRefillIdle)
-        {
-            const uint32_t i = feed_take(feed, !alive, q.count, q.class_capacity);
-            if (i != kInvalidId)
-            {
-                const float4 a = q.org_tmin[i], b = q.dir_tmax[i];
-                r      = make_ray(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, b.w);
-                best_t = r.tmax, best_u = 0.f, best_v = 0.f, best_gid = kInvalidId;
-                out = i, node = bvh.root, sp = 0, alive = true;
-            }
-        }
-        if (__ballot(alive) == 0ull) break;  // feed exhausted and every lane retired
-        // while-while: as long as enough lanes sit on an internal node only the box code runs; lanes that reached a leaf wait
-        // until leaves are due (few lanes left on internal nodes), then only the triangle code runs.  Every iteration pays for
-        // one of the two bodies instead of both.
-        const unsigned long long m_inner = __ballot(alive && node >= 0);
-        const unsigned long long m_leaf  = __ballot(alive && node < 0);
-        const bool               inner_phase = __popcll(m_inner) >= kLeafBatch || m_leaf == 0ull;
-        bool pop = false;
-        if (inner_phase)
-        {
-            if (alive && node >= 0)
-            {
-                // four grandchild boxes with one 112-B fetch (k_node4), sorted by entry distance: nearest next, the others pushed
-                // farthest first
-                const float4* N  = bvh.nodes4 + 8 * (size_t)node;
-                const float4  lx = N[0], ly = N[1], lz = N[2], hx = N[3], hy = N[4], hz = N[5], cc = N[6];
-                float         tn[4];
-                int           ch[4] = {(int)f2u(cc.x), (int)f2u(cc.y), (int)f2u(cc.z), (int)f2u(cc.w)};
-                // an unused slot is told by its child value, not by its box: the slab test's overflow handling is conservative
-                // (inf * inv never rejects), so no box content reliably fails it
-                const bool    h0 = slab(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, best_t, tn[0]) && ch[0] != kNoChild;
-                const bool    h1 = slab(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, best_t, tn[1]) && ch[1] != kNoChild;
-                const bool    h2 = slab(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, best_t, tn[2]) && ch[2] != kNoChild;
-                const bool    h3 = slab(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, best_t, tn[3]) && ch[3] != kNoChild;
-                const float   kInf = __builtin_inff();
-                tn[0] = h0 ? tn[0] : kInf, tn[1] = h1 ? tn[1] : kInf, tn[2] = h2 ? tn[2] : kInf, tn[3] = h3 ? tn[3] : kInf;
-                auto cswap = [&](int i, int j) {
-                    const bool  sw = tn[j] < tn[i];
-                    const float ta = sw ? tn[j] : tn[i], tb = sw ? tn[i] : tn[j];
-                    const int   ca = sw ? ch[j] : ch[i], cb = sw ? ch[i] : ch[j];
-                    tn[i] = ta, tn[j] = tb, ch[i] = ca, ch[j] = cb;
-                };
-                cswap(0, 1), cswap(2, 3), cswap(0, 2), cswap(1, 3), cswap(1, 2);
-                const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-                pop          = nh == 0;
-                if (nh > 0)
-                {
-                    node = ch[0];
-                    if (nh > 3) push(ch[3]);
-                    if (nh > 2) push(ch[2]);
-                    if (nh > 1) push(ch[1]);
-                }
-            }
-        }
-        else if (alive && node < 0)
-        {
-            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
-            for (uint32_t leaf = first; leaf <= last; ++leaf)
-            {
-                const float4 t0 = bvh.tris[4 * leaf + 0], t1 = bvh.tris[4 * leaf + 1], t2 = bvh.tris[4 * leaf + 2];
-                float        t, u, v;
-                if (tri_test(r, t0, t1, t2, t, u, v))
-                {
-                    const uint32_t gid = f2u(bvh.tris[4 * leaf + 3].x);
-                    if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
-                }
-            }
-            pop = true;
-        }
-        if (pop)
-        {
-            if (sp == 0)
-            {
-                hits[out] = make_float4(best_u, best_v, u2f(best_gid), best_t);
-                alive     = false;
-            }
-            else
-            {
-                --sp;
-                node = (int)(sp < STACK ? stack[sp * kBlock] : spill[sp - STACK]);
-            }
-        }
-    }
-}
-
-
 // the wide traversal paths need every thread of the (1-D) grid to own a slice of the spill area
 static BvhDev for_grid(const BvhDev& bvh, uint32_t grid_blocks)
 {
     BvhDev b = bvh;
-    if ((uint64_t)grid_blocks * kBlock > b.spill_threads) b.wide_ok = 0, b.wide8_ok = 0;
+    if ((uint64_t)grid_blocks * kBlock > b.spill_threads) b.wide8_ok = 0;
     return b;
 }
 
@@ -1390,8 +1134,7 @@ void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraD
     if (gx == 0) gx = 1;
     const dim3 grid(gx, n_slots);
     BvhDev     b = bvh;
-    b.wide_ok    = 0;  // 2-D grid: no per-thread spill slice
-    b.wide8_ok   = 0;
+    b.wide8_ok   = 0;  // 2-D grid: no per-thread spill slice
     if (cfg.stack_entries == 0)
         hipLaunchKernelGGL(k_trace_primary<0>, grid, dim3(kBlock), 0, cfg.stream, b, cam, screen, frames, hits);
     else if (cfg.stack_entries <= 32)
@@ -1412,11 +1155,6 @@ void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueu
     dim3 grid(queue_grid(cfg, max_count));
     if (cfg.stack_entries == 0)
         hipLaunchKernelGGL(k_trace_closest<0>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
-    else if (bvh.wide_ok && grid.x * kBlock <= bvh.spill_threads)
-    {
-        grid.x = resident_grid<k_trace_closest_refill4<(int)kWideLdsEntries>>(cfg, grid.x);
-        hipLaunchKernelGGL(k_trace_closest_refill4<(int)kWideLdsEntries>, grid, dim3(kBlock), 0, cfg.stream, bvh, q, hits);
-    }
     else if (cfg.stack_entries <= 32)
     {
         grid.x = resident_grid<k_trace_closest_refill<32>>(cfg, grid.x);
@@ -1457,7 +1195,7 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
     {
         if (mostly_unoccluded) CAP_LAUNCH_ANY(0, true); else CAP_LAUNCH_ANY(0, false);
     }
-    else if (bw.wide_ok || bw.wide8_ok)
+    else if (bw.wide8_ok)
     {
         // wide traversal only (its stack continues in the spill slice): the smaller LDS part lets more workgroups be resident.
         // The binary code in this instantiation is never reached -- it has no spill and would drop entries past the LDS part.
