@@ -87,6 +87,7 @@ SYMBOLS = {
     "cap_set_bvh_build": (_i, [_vp, _u32]),
     "cap_bvh_info": (_i, [_vp, C.POINTER(BvhInfo)]),
     "cap_bvh_readback": (_i, [_vp, _vp, _vp]),
+    "cap_bvh_wide_readback": (_i, [_vp, _vp, _vp, _vp]),
     "cap_camera_set": (_i, [_vp, C.POINTER(CameraData)]),
     "cap_prev_camera_set": (_i, [_vp, C.POINTER(CameraData)]),
     "cap_set_resolution": (_i, [_vp, _u32, _u32]),
@@ -368,6 +369,15 @@ class Renderer:
         return nodes, leaves
 
     # ---- view ----
+    def bvh_wide_readback(self):
+        """(wide nodes [count, 20] uint32, tri_src [triangles] uint32, depth, top) of the compressed 8-wide view."""
+        info = np.zeros(3, np.uint32)
+        _check(lib().cap_bvh_wide_readback(self.ctx, None, None, _p(info)), "cap_bvh_wide_readback")
+        nodes = np.zeros((int(info[0]), 20), np.uint32)
+        src = np.zeros(max(1, self.bvh_info().triangle_count), np.uint32)
+        _check(lib().cap_bvh_wide_readback(self.ctx, _p(nodes), _p(src), _p(info)), "cap_bvh_wide_readback")
+        return nodes, src[:self.bvh_info().triangle_count], int(info[1]), int(info[2])
+
     def set_camera(self, cam):
         _check(lib().cap_camera_set(self.ctx, C.byref(cam)), "cap_camera_set")
 

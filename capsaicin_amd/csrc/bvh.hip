@@ -8,6 +8,7 @@
 // LSD radix sort (4 x 8 bit, stable) -> Karras 2012 hierarchy -> bottom-up refit with arrival counters.
 // The traversal result does not depend on the tree shape (closest hit = min t, ties to the lower triangle id).
 #include "cap_kernels.h"
+#include "cap_wide.h"
 
 namespace cap
 {
@@ -203,7 +204,7 @@ __device__ __forceinline__ int delta(const uint32_t* keys, int n, int i, int j)
     return __clzll((long long)(a ^ b));
 }
 
-__global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t* keys, uint32_t n, float4* nodes, uint32_t* parent)
+__global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t* keys, uint32_t n, float4* nodes, uint32_t* parent, uint32_t* subtree_count)
 {
     const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
     const int N = (int)n;
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(kBlock) void k_hierarchy(const uint32_t* keys, uint
     // the range code ~(first | (count - 1) << kLeafCountShift).  Fewer box tests and stack operations; the binary tree
     // (and its boxes) stays complete for the refit and for cap_bvh_readback.
     const int      nl = gamma - lo + 1, nr = hi - gamma;
+    subtree_count[i] = (uint32_t)(hi - lo + 1);  // triangles below node i (the device collapse into the 8-wide view reads it)
     const uint32_t tleft  = nl <= kLeafMax ? ~((uint32_t)lo | ((uint32_t)(nl - 1) << kLeafCountShift)) : (uint32_t)gamma;
     const uint32_t tright = nr <= kLeafMax ? ~((uint32_t)(gamma + 1) | ((uint32_t)(nr - 1) << kLeafCountShift)) : (uint32_t)(gamma + 1);
     nodes[4 * (size_t)i + 3] = make_float4(u2f((uint32_t)left), u2f((uint32_t)right), u2f(tleft), u2f(tright));
@@ -328,6 +330,192 @@ void launch_gather_wide(hipStream_t stream, const uint32_t* tri_src, const float
     if (n) hipLaunchKernelGGL(k_gather_wide, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, tri_src, tris_sorted, n, tris8);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-side collapse of the binary tree into the compressed 8-wide view (cap_wide.h): the same greedy rules as the host
+// builder (wide_builder.cpp: open the largest inner child until eight, then multi-triangle leaf children; octant slots by greedy
+// assignment; planes quantised outwards in double precision after padding), one thread per wide node, level by level.  A level's
+// nodes are contiguous (breadth-first array, top levels first); a node's inner children are allocated as one block, so they
+// are contiguous in slot order, and its triangles likewise.  Within a level the order depends on the atomics' arrival: the layout
+// may differ from run to run, the traversal result never does.
+// ------------------------------------------------------------------------------------------------
+namespace
+{
+struct WideRef
+{
+    int      node;   // >= 0: binary internal node, < 0: ~(leaf-order triangle)
+    uint32_t count;  // triangles below
+    float    lo[3], hi[3];
+};
+__device__ __forceinline__ WideRef wide_ref(const float4* bn, const uint32_t* count, uint32_t node, int s)
+{
+    const float* q = reinterpret_cast<const float*>(bn + 4 * (size_t)node);
+    WideRef      r;
+    for (int k = 0; k < 3; ++k) r.lo[k] = q[6 * s + k], r.hi[k] = q[6 * s + 3 + k];
+    r.node  = (int)f2u(q[12 + s]);
+    r.count = r.node >= 0 ? count[r.node] : 1u;
+    return r;
+}
+__device__ __forceinline__ double wide_half_area(const WideRef& r)
+{
+    const double dx = (double)r.hi[0] - r.lo[0], dy = (double)r.hi[1] - r.lo[1], dz = (double)r.hi[2] - r.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ __launch_bounds__(kBlock) void k_wide_level(WideCollapseArgs a)
+{
+    const uint32_t w = a.begin + blockIdx.x * kBlock + threadIdx.x;
+    if (w >= a.end) return;
+    const uint32_t root = a.task[w];
+    WideRef        kids[8];
+    int            nk = 2;
+    kids[0] = wide_ref(a.bnodes, a.count, root, 0), kids[1] = wide_ref(a.bnodes, a.count, root, 1);
+    for (int pass = 0; pass < 2; ++pass)
+        while (nk < 8)
+        {
+            int    best = -1;
+            double best_area = -1.0;
+            for (int i = 0; i < nk; ++i)
+            {
+                const bool inner = kids[i].count > kWideLeafMax;
+                const bool can   = pass == 0 ? inner : (!inner && kids[i].count > 1u);
+                const double ar  = wide_half_area(kids[i]);
+                if (can && ar > best_area) best_area = ar, best = i;
+            }
+            if (best < 0) break;
+            const uint32_t open = (uint32_t)kids[best].node;
+            kids[best]  = wide_ref(a.bnodes, a.count, open, 0);
+            kids[nk++]  = wide_ref(a.bnodes, a.count, open, 1);
+        }
+    // padded child boxes (double) and the node box
+    double clo[8][3], chi[8][3], nlo[3] = {1e300, 1e300, 1e300}, nhi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < nk; ++i)
+        for (int k = 0; k < 3; ++k)
+        {
+            clo[i][k] = (double)kids[i].lo[k] - a.pad, chi[i][k] = (double)kids[i].hi[k] + a.pad;
+            nlo[k] = fmin(nlo[k], clo[i][k]), nhi[k] = fmax(nhi[k], chi[i][k]);
+        }
+    // slot assignment: greedy maximum of <child centre - node centre, direction(slot)>
+    int  kid_at[8];
+    bool slot_used[8], kid_done[8];
+    for (int s = 0; s < 8; ++s) kid_at[s] = -1, slot_used[s] = false, kid_done[s] = false;
+    for (int step = 0; step < nk; ++step)
+    {
+        double best = -1e300;
+        int    bi = -1, bs = -1;
+        for (int i = 0; i < nk; ++i)
+        {
+            if (kid_done[i]) continue;
+            double off[3];
+            for (int k = 0; k < 3; ++k) off[k] = 0.5 * (clo[i][k] + chi[i][k]) - 0.5 * (nlo[k] + nhi[k]);
+            for (int s = 0; s < 8; ++s)
+            {
+                if (slot_used[s]) continue;
+                const double v = ((s & 1) ? off[0] : -off[0]) + ((s & 2) ? off[1] : -off[1]) + ((s & 4) ? off[2] : -off[2]);
+                if (v > best) best = v, bi = i, bs = s;
+            }
+        }
+        kid_at[bs] = bi, slot_used[bs] = true, kid_done[bi] = true;
+    }
+    uint32_t word[kWideNodeWords];
+    for (uint32_t k = 0; k < kWideNodeWords; ++k) word[k] = 0u;
+    // grid origin (the node's low corner rounded down to float) and steps (the smallest power of two with <= 255 steps)
+    float  p[3];
+    double step[3];
+    uint32_t eb[3];
+    for (int k = 0; k < 3; ++k)
+    {
+        p[k] = (float)nlo[k];
+        if ((double)p[k] > nlo[k]) p[k] = u2f(p[k] > 0.0f ? f2u(p[k]) - 1u : (p[k] < 0.0f ? f2u(p[k]) + 1u : 0x80000001u));  // next float down
+        word[k] = f2u(p[k]);
+        const double ext = nhi[k] - (double)p[k];
+        int          e   = -100;
+        if (ext > 0.0)
+        {
+            int fe;
+            (void)frexp(ext / 255.0, &fe);
+            e = fe - 1 > -100 ? fe - 1 : -100;
+        }
+        while (ceil(ext / ldexp(1.0, e)) > 255.0) ++e;
+        step[k] = ldexp(1.0, e);
+        eb[k]   = (uint32_t)(e + 127);
+    }
+    word[3] = eb[0] << 23;
+    word[7] = ((eb[1] << 23) & 0xffff0000u) | ((eb[2] << 23) >> 16);
+    uint32_t imask = 0u, tvalid = 0u, n_inner = 0u, n_tris = 0u;
+    uint32_t leaf_tri[8][kWideLeafMax];
+    uint32_t leaf_n[8];
+    for (int s = 0; s < 8; ++s)
+    {
+        leaf_n[s] = 0u;
+        const int i = kid_at[s];
+        if (i < 0) continue;
+        if (kids[i].count > kWideLeafMax)
+            imask |= 1u << s, ++n_inner;
+        else
+        {
+            // the (at most kWideLeafMax) triangles below: a tiny explicit stack over the binary subtree
+            int st[4], sp = 0;
+            st[sp++] = kids[i].node;
+            while (sp > 0)
+            {
+                const int c = st[--sp];
+                if (c < 0)
+                    leaf_tri[s][leaf_n[s]++] = (uint32_t)~c;
+                else
+                {
+                    const float* q = reinterpret_cast<const float*>(a.bnodes + 4 * (size_t)c);
+                    st[sp++] = (int)f2u(q[13]), st[sp++] = (int)f2u(q[12]);
+                }
+            }
+            for (uint32_t k = 0; k < leaf_n[s]; ++k) tvalid |= 1u << (k * 8u + (uint32_t)s);
+            n_tris += leaf_n[s];
+        }
+        for (int k = 0; k < 3; ++k)
+        {
+            double qlo = floor((clo[i][k] - (double)p[k]) / step[k]), qhi = ceil((chi[i][k] - (double)p[k]) / step[k]);
+            qlo = fmin(fmax(qlo, 0.0), 255.0), qhi = fmin(fmax(qhi, 0.0), 255.0);
+            const uint32_t wi = 8u + 2u * (uint32_t)k + ((uint32_t)s >> 2), sh = 8u * ((uint32_t)s & 3u);
+            word[wi] |= (uint32_t)qlo << sh;
+            word[wi + 6] |= (uint32_t)qhi << sh;
+        }
+    }
+    const uint32_t child_base = n_inner ? atomicAdd(&a.alloc[0], n_inner) : 0u;
+    const uint32_t tri_base   = n_tris ? atomicAdd(&a.alloc[1], n_tris) : 0u;
+    word[4] = child_base, word[5] = tri_base, word[6] = tvalid | (imask << 24);
+    uint32_t rel = 0u, at = tri_base;
+    for (int s = 0; s < 8; ++s)
+        if (imask & (1u << s)) a.task[child_base + rel++] = (uint32_t)kids[kid_at[s]].node;
+    for (uint32_t k = 0; k < kWideLeafMax; ++k)
+        for (int s = 0; s < 8; ++s)
+            if (leaf_n[s] > k) a.tri_src[at++] = leaf_tri[s][k];
+    uint32_t* o = a.nodes8 + (size_t)w * kWideNodeWords;
+    for (uint32_t k = 0; k < kWideNodeWords; ++k) o[k] = word[k];
+}
+}  // namespace
+
+int launch_wide_collapse(hipStream_t stream, WideCollapseArgs a, uint32_t* node_count, uint32_t* depth, uint32_t* top_nodes)
+{
+    // level 0 = the root (binary node 0); alloc[0] counts allocated wide nodes, alloc[1] emitted triangles
+    const uint32_t init[2] = {1u, 0u}, root_task = 0u;
+    if (hipMemcpyAsync(a.alloc, init, sizeof(init), hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
+    if (hipMemcpyAsync(a.task, &root_task, sizeof(root_task), hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
+    uint32_t begin = 0u, end = 1u, levels = 0u, top = 0u;
+    while (begin < end)
+    {
+        ++levels;
+        if (levels <= 3) top = end < kWideTopNodes ? end : kWideTopNodes;
+        a.begin = begin, a.end = end;
+        hipLaunchKernelGGL(k_wide_level, dim3((end - begin + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
+        uint32_t allocated = 0u;
+        if (hipMemcpyAsync(&allocated, a.alloc, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;
+        if (hipStreamSynchronize(stream) != hipSuccess) return 1;
+        if (allocated > a.capacity) return 2;  // cannot happen: a wide node stands for >= 4 triangles
+        begin = end, end = allocated;
+    }
+    *node_count = end, *depth = levels, *top_nodes = top;
+    return 0;
+}
+
 size_t bvh_radix_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 
 static void bvh_setup(hipStream_t stream, const BvhBuildArgs& a)
@@ -379,7 +567,7 @@ void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
         }
         sorted_keys = a.keys[src];
         sorted_vals = a.vals[src];
-        hipLaunchKernelGGL(k_hierarchy, dim3(blocks), dim3(kBlock), 0, stream, sorted_keys, n, a.nodes, a.parent);
+        hipLaunchKernelGGL(k_hierarchy, dim3(blocks), dim3(kBlock), 0, stream, sorted_keys, n, a.nodes, a.parent, a.keys[src ^ 1]);  // the other key buffer is free after the sort
     }
     else
     {

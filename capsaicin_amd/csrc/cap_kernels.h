@@ -110,6 +110,18 @@ void launch_bvh_finish_host(hipStream_t stream, const BvhBuildArgs& a);
 
 // Compressed 8-wide view (wide_builder.cpp builds the nodes on the host): intersection records into its leaf order.
 void     launch_gather_wide(hipStream_t stream, const uint32_t* tri_src, const float4* tris_sorted, uint32_t n, float4* tris8);
+// Device-side collapse of the device-built binary tree (needs BvhBuildArgs::keys[1] = the subtree counts launch_bvh_build leaves
+// there).  task: capacity words of scratch; alloc: 2 words; nodes8: capacity * kWideNodeWords words; tri_src: n_tris words.
+struct WideCollapseArgs
+{
+    const float4*   bnodes;
+    const uint32_t* count;
+    uint32_t        n_tris, capacity;
+    double          pad;
+    uint32_t *      task, *alloc, *nodes8, *tri_src;
+    uint32_t        begin, end;
+};
+int      launch_wide_collapse(hipStream_t stream, WideCollapseArgs a, uint32_t* node_count, uint32_t* depth, uint32_t* top_nodes);
 uint32_t wide8_stack_pairs();  // (g_base, g_mask) entries a lane of the wide kernels can hold: the tree's depth - 1 must fit
 
 // ---- reconstruction chain (post.hip): Gather -> Accumulate -> BlurDisocclusion -> Blur -> Combine -> TAA ----

@@ -143,7 +143,8 @@ struct CapContext
     // BVH
     DevBuf<float4>   shade_tris, tris_sorted, nodes, tri_raw, tri_box;
     DevBuf<float4>   nodes8, tris8;           // compressed 8-wide view (cap_wide.h) and its intersection records
-    DevBuf<uint32_t> wide_src;                // scratch: leaf-order index per wide-order record
+    DevBuf<uint32_t> wide_src;                // leaf-order index per wide-order record
+    DevBuf<uint32_t> wide_task, wide_alloc;   // device collapse: binary node per wide node, allocation counters
     uint32_t         wide8_depth = 0, wide8_top = 0, wide8_nodes = 0;
     float            wide8_ms = 0.f;
     DevBuf<uint32_t> stack_spill;             // traversal-stack entries beyond the LDS part, per thread of the persistent grid
@@ -740,27 +741,51 @@ int cap_bvh_build(CapContext* c)
     if (n >= 1)
     {
         const auto w0 = std::chrono::steady_clock::now();
-        if (n >= 2 && bnodes_host.empty())
-        {
-            bnodes_host.resize(16 * (size_t)(n - 1));
-            HIP_TRY(hipMemcpy(bnodes_host.data(), c->nodes.p, sizeof(float) * bnodes_host.size(), hipMemcpyDeviceToHost));
-        }
-        WideTree wt;
-        build_wide_tree(n >= 2 ? bnodes_host.data() : nullptr, n, bi.bounds_lo, bi.bounds_hi, wt);
-        const size_t wn = wt.nodes.size() / kWideNodeWords;
-        HIP_TRY(c->nodes8.ensure(5 * std::max<size_t>(wn + 1, kWideTopNodes)));
         HIP_TRY(c->tris8.ensure(4 * (size_t)n));
         HIP_TRY(c->wide_src.ensure(n));
-        HIP_TRY(hipMemcpy(c->nodes8.p, wt.nodes.data(), sizeof(uint32_t) * wt.nodes.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->wide_src.p, wt.tri_src.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+        size_t   wn = 0;
+        uint32_t wdepth = 0, wtop = 0;
+        static const bool host_collapse = getenv("CAP_WIDE_HOST_COLLAPSE") != nullptr;  // A/B switch
+        if (!sah && n >= 2 && !host_collapse)
+        {
+            // the device built the binary tree: collapse it there too (bvh.hip k_wide_level), nothing leaves the GPU
+            const uint32_t cap = n / 2u + 16u;  // an inner child stands for >= 4 triangles
+            HIP_TRY(c->nodes8.ensure(5 * std::max<size_t>((size_t)cap + 1, kWideTopNodes)));
+            HIP_TRY(c->wide_task.ensure(cap));
+            HIP_TRY(c->wide_alloc.ensure(2));
+            double m = 0.0;
+            for (int k = 0; k < 3; ++k)
+                m = std::max({m, (double)bi.bounds_hi[k] - (double)bi.bounds_lo[k], std::fabs((double)bi.bounds_lo[k]), std::fabs((double)bi.bounds_hi[k])});
+            WideCollapseArgs wa{};
+            wa.bnodes = c->nodes.p, wa.count = c->keys1.p, wa.n_tris = n, wa.capacity = cap;
+            wa.pad = (double)kWidePad * std::max(m, 1e-30);
+            wa.task = c->wide_task.p, wa.alloc = c->wide_alloc.p, wa.nodes8 = reinterpret_cast<uint32_t*>(c->nodes8.p), wa.tri_src = c->wide_src.p;
+            uint32_t count = 0;
+            if (launch_wide_collapse(c->stream, wa, &count, &wdepth, &wtop) != 0) return fail(CAP_ERR_HIP, "cap_bvh_build: device collapse into the 8-wide view failed");
+            wn = count;
+        }
+        else
+        {
+            if (n >= 2 && bnodes_host.empty())
+            {
+                bnodes_host.resize(16 * (size_t)(n - 1));
+                HIP_TRY(hipMemcpy(bnodes_host.data(), c->nodes.p, sizeof(float) * bnodes_host.size(), hipMemcpyDeviceToHost));
+            }
+            WideTree wt;
+            build_wide_tree(n >= 2 ? bnodes_host.data() : nullptr, n, bi.bounds_lo, bi.bounds_hi, wt);
+            wn = wt.nodes.size() / kWideNodeWords, wdepth = wt.depth, wtop = wt.top_nodes;
+            HIP_TRY(c->nodes8.ensure(5 * std::max<size_t>(wn + 1, kWideTopNodes)));
+            HIP_TRY(hipMemcpy(c->nodes8.p, wt.nodes.data(), sizeof(uint32_t) * wt.nodes.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->wide_src.p, wt.tri_src.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+        }
         launch_gather_wide(c->stream, c->wide_src.p, c->tris_sorted.p, n, c->tris8.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
-        c->wide8_nodes = (uint32_t)wn, c->wide8_depth = wt.depth, c->wide8_top = wt.top_nodes;
+        c->wide8_nodes = (uint32_t)wn, c->wide8_depth = wdepth, c->wide8_top = wtop;
         c->wide8_ms    = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
         bi.build_ms += c->wide8_ms;  // the collapse is part of the build
         if (getenv("CAP_TRACE_LAUNCHES"))
-            fprintf(stderr, "[cap] wide view: %zu nodes, depth %u, top %u, %.1f ms\n", wn, wt.depth, wt.top_nodes, c->wide8_ms);
+            fprintf(stderr, "[cap] wide view: %zu nodes, depth %u, top %u, %.1f ms\n", wn, wdepth, wtop, c->wide8_ms);
     }
     // Exhaustive path (cap_set_traversal): triangles that come in fans (k, k + 1 share v0 and the edge v0->v2, as every
     // triangulated quad of an OBJ face does) are stored as one record, so the kernels compute tvec, q and the shared edge's dot
@@ -822,6 +847,18 @@ int cap_bvh_readback(CapContext* c, float* nodes, uint32_t* leaf_triangles)
         HIP_TRY(hipMemcpy(nodes, c->nodes.p, sizeof(float4) * 4 * c->bvh_info.node_count, hipMemcpyDeviceToHost));
     if (leaf_triangles && c->tri_count)
         HIP_TRY(hipMemcpy(leaf_triangles, c->leaf_tri.p, sizeof(uint32_t) * c->tri_count, hipMemcpyDeviceToHost));
+    return CAP_OK;
+}
+
+int cap_bvh_wide_readback(CapContext* c, uint32_t* nodes, uint32_t* tri_src, uint32_t* info)
+{
+    if (!c || !info) return fail(CAP_ERR_INVALID_ARG, "cap_bvh_wide_readback: NULL argument");
+    if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_bvh_wide_readback: BVH not built");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    info[0] = c->wide8_nodes, info[1] = c->wide8_depth, info[2] = c->wide8_top;
+    if (nodes && c->wide8_nodes) HIP_TRY(hipMemcpy(nodes, c->nodes8.p, sizeof(uint32_t) * kWideNodeWords * c->wide8_nodes, hipMemcpyDeviceToHost));
+    if (tri_src && c->tri_count) HIP_TRY(hipMemcpy(tri_src, c->wide_src.p, sizeof(uint32_t) * c->tri_count, hipMemcpyDeviceToHost));
     return CAP_OK;
 }
 

@@ -180,6 +180,11 @@ int cap_set_bvh_build(CapContext* ctx, uint32_t mode);
 int cap_bvh_info(CapContext* ctx, CapBvhInfo* out);
 /* Debug/test readback: nodes = node_count * 16 floats (see DESIGN.md "BVH node"), leaf_triangles = triangle ids in leaf order. */
 int cap_bvh_readback(CapContext* ctx, float* nodes, uint32_t* leaf_triangles);
+/* The compressed 8-wide view the extension- and shadow-ray kernels walk (capsaicin_amd/csrc/cap_wide.h): nodes = 20 uint32 per
+ * node (info[0] nodes; call with nodes = NULL first), tri_src = leaf position per wide-order triangle record (triangle_count
+ * entries), info = {node count, depth, leading top-level nodes}.  Built by cap_bvh_build: on the device when the device built
+ * the binary tree (CAP_BVH_BUILD_LBVH), on the host from the host's SAH tree.  For tests and tools. */
+int cap_bvh_wide_readback(CapContext* ctx, uint32_t* nodes, uint32_t* tri_src, uint32_t* info);
 
 /* CameraSystem::Run upload (camera_system.cpp:89-131). sensor_size is used as given (the caller applies
  * AdjustCameraAspectBasedOnWindow, camera_system.cpp:10-17). */

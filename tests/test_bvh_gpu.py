@@ -328,3 +328,31 @@ def test_textured_quad_parity(native_lib, bluenoise):
     ref2 = sc2.render_frame(ocam, bluenoise, w, h, 9, D)
     assert np.array_equal(bits(r.readback(capi.BUF_COMBINED)), bits(ref2["combined"]))
     r.close()
+
+
+@pytest.mark.parametrize("n,build", [(2, 1), (7, 1), (500, 1), (20000, 1), (20000, 2)])
+def test_wide_view_structure_on_device(native_lib, n, build):
+    """The compressed 8-wide view as cap_bvh_build leaves it on the device -- collapsed on the device itself for the device-built
+    LBVH (bvh.hip k_wide_level), on the host for the SAH tree -- satisfies the structural and conservativeness checks of the host
+    builder's CPU test (tests/test_host_wide.py walk): every triangle in exactly one leaf child, inner children contiguous in slot
+    order, every decoded child box containing its triangles' padded boxes."""
+    import test_host_wide as hw
+    rs = np.random.RandomState(300 + n)
+    tri = (rs.uniform(-4, 4, (n, 1, 3)) + rs.uniform(-0.3, 0.3, (n, 3, 3))).astype(np.float32)
+    pos = tri.reshape(-1, 3)
+    nrm = np.tile(np.float32([0, 1, 0]), (3 * n, 1))
+    uv = np.zeros((3 * n, 2), np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    meshes = np.uint32([[3 * n, 0, 3 * n, 0, 0, 0xFFFFFFFF, 0, 0]])
+    r = capi.Renderer(0)
+    r.set_bvh_build(build)
+    r.upload_scene(pos, nrm, uv, idx, meshes)
+    info = r.build_bvh()
+    nodes, order = r.bvh_readback()
+    wide, src, depth, top = r.bvh_wide_readback()
+    lo, hi = tri.min(1), tri.max(1)
+    d, _ = hw.walk(lo, hi, order, wide, src, np.float32(info.bounds_lo), np.float32(info.bounds_hi))
+    assert d == depth and 1 <= top <= min(len(wide), 73)
+    if n >= 20000:
+        assert depth <= 14 and len(wide) < n // 3
+    r.close()
