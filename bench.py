@@ -220,26 +220,37 @@ def main():
                 ids = [None]
             dist.broadcast_object_list(ids, src=0)
             if ids[0] is not None:
+                # every rank must have its communicator before any rank enters the gather (a rank that failed would leave the
+                # others waiting in ncclGather): agree on the minimum of the ranks' results first
+                inited = torch.ones(1, dtype=torch.int32, device="cuda")
                 try:
                     r.comm_init_rank(ids[0], rank, world)
-                    r.accum_reset()
-                    r.render(0, 1, DEPTH, 0)
-                    r.comm_gather_frame()
-                    r.resolve_tiles(tile_buf.data_ptr())
-                    r.sync()
-                    torch.cuda.synchronize()
-                    dist.gather(tile_buf, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
-                    if rank == 0:
-                        r.assemble_tiles(gathered.data_ptr(), world, image.data_ptr())
+                except capi.CapError as exc:
+                    inited[0] = 0
+                    sys.stderr.write("[bench] rank %d: cap_comm_init_rank failed: %s\n" % (rank, exc))
+                dist.all_reduce(inited, op=dist.ReduceOp.MIN)
+                if int(inited.item()) == 1:
+                    try:
+                        r.accum_reset()
+                        r.render(0, 1, DEPTH, 0)
+                        r.comm_gather_frame()
+                        r.resolve_tiles(tile_buf.data_ptr())
                         r.sync()
                         torch.cuda.synchronize()
-                        a = r.comm_readback().reshape(-1)
-                        ok[0] = int(np.array_equal(a.view(np.uint32), image.cpu().numpy().view(np.uint32)))
-                except capi.CapError as exc:
-                    sys.stderr.write("[bench] rank %d: cap_comm path unavailable: %s\n" % (rank, exc))
-                dist.broadcast(ok, src=0)
-                if int(ok.item()) == 1:
-                    exchange = "cap_comm_gather_frame (ncclGather, C ABI)"
+                        dist.gather(tile_buf, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+                        if rank == 0:
+                            r.assemble_tiles(gathered.data_ptr(), world, image.data_ptr())
+                            r.sync()
+                            torch.cuda.synchronize()
+                            a = r.comm_readback().reshape(-1)
+                            ok[0] = int(np.array_equal(a.view(np.uint32), image.cpu().numpy().view(np.uint32)))
+                    except capi.CapError as exc:
+                        sys.stderr.write("[bench] rank %d: cap_comm path unavailable: %s\n" % (rank, exc))
+                    dist.broadcast(ok, src=0)
+                    if int(ok.item()) == 1:
+                        exchange = "cap_comm_gather_frame (ncclGather, C ABI)"
+                if not exchange.startswith("cap_comm"):
+                    r.comm_destroy()
 
         def step(flags=0):
             r.accum_reset()
