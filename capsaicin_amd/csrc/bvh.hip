@@ -50,13 +50,15 @@ __global__ __launch_bounds__(kBlock) void k_tri_setup(BvhBuildArgs a)
         a.tri_raw[4 * (size_t)g + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
         a.tri_raw[4 * (size_t)g + 2] = make_float4(e2.z, n.x, n.y, n.z);
         a.tri_raw[4 * (size_t)g + 3] = make_float4(u2f(g), 0.f, 0.f, 0.f);
-        float4* st = a.shade_tris + 6 * (size_t)g;
+        float4* st = a.shade_tris + kShadeRec * (size_t)g;
         st[0] = make_float4(p0.x, p0.y, p0.z, T[2 * i0]);
         st[1] = make_float4(p1.x, p1.y, p1.z, T[2 * i0 + 1]);
         st[2] = make_float4(p2.x, p2.y, p2.z, T[2 * i1]);
         st[3] = make_float4(N[3 * i0], N[3 * i0 + 1], N[3 * i0 + 2], T[2 * i1 + 1]);
         st[4] = make_float4(N[3 * i1], N[3 * i1 + 1], N[3 * i1 + 2], T[2 * i2]);
         st[5] = make_float4(N[3 * i2], N[3 * i2 + 1], N[3 * i2 + 2], T[2 * i2 + 1]);
+        st[6] = make_float4(u2f(id.x), u2f(id.y), u2f(id.z), 0.f);  // (instance, primitive, texture index): rides in the record's second sector
+        st[7] = make_float4(0.f, 0.f, 0.f, 0.f);
         lo[0] = fminf(p0.x, fminf(p1.x, p2.x)), lo[1] = fminf(p0.y, fminf(p1.y, p2.y)), lo[2] = fminf(p0.z, fminf(p1.z, p2.z));
         hi[0] = fmaxf(p0.x, fmaxf(p1.x, p2.x)), hi[1] = fmaxf(p0.y, fmaxf(p1.y, p2.y)), hi[2] = fmaxf(p0.z, fmaxf(p1.z, p2.z));
         tri_box[2 * (size_t)g + 0] = make_float4(lo[0], lo[1], lo[2], 0.f);

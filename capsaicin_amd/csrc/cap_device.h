@@ -22,6 +22,7 @@ constexpr uint32_t kBlock      = 256;  // threads per workgroup (4 waves, one pe
 // and never changes, so sub-queue k can never hold more than the class-k paths: static capacity, no overflow handling.
 constexpr uint32_t kQueueClasses  = 64;
 constexpr uint32_t kCounterStride = 32;  // uint32 words between two class counters (128 B)
+constexpr uint32_t kShadeRec      = 8;   // float4 per shading record
 constexpr uint32_t kExhaustiveMax = 64;  // scenes up to this many triangles are traced exhaustively (kernels.hip)
 constexpr int      kNoChild        = 0x7fffffff;  // unused slot of a wide node
 // k_trace_any on the 8-wide view: 24 LDS words per lane = 12 (g_base, g_mask) pairs (24 KB per workgroup: six workgroups per CU)
@@ -35,8 +36,10 @@ constexpr uint32_t kSpillEntries   = 24;  // per-thread stack words (12 pairs) k
 //        ~(first sorted triangle | (count - 1) << kLeafCountShift)
 // Intersection triangle, 64 B = 4 x float4, in leaf order (n = cross(e1, e2)):
 //   t0 = (v0.x v0.y v0.z e1.x)  t1 = (e1.y e1.z e2.x e2.y)  t2 = (e2.z n.x n.y n.z)  t3 = (asfloat(global triangle id), -, -, -)
-// Shading triangle, 96 B = 6 x float4, in global triangle order (mesh order, then primitive order):
+// Shading triangle, 128 B = kShadeRec x float4 (two 64-B sectors, nothing else to fetch per shaded vertex), in global triangle
+// order (mesh order, then primitive order):
 //   s0 = (p0, uv0.x) s1 = (p1, uv0.y) s2 = (p2, uv1.x) s3 = (n0, uv1.y) s4 = (n1, uv2.x) s5 = (n2, uv2.y)
+//   s6 = (instance, primitive, texture index of the instance's mesh, -) as int bits     s7 unused
 struct BvhDev
 {
     const float4* nodes;
@@ -159,7 +162,7 @@ struct MaterialDev
 
 struct SceneDev
 {
-    const float4*     shade_tris;  // 6 per triangle
+    const float4*     shade_tris;  // kShadeRec per triangle
     const uint4*      tri_ids;     // (instance, primitive, texture index of the instance's mesh, -) per global triangle
                                    // (tlas_system.cpp:40-58; the texture index spares the shading a dependent load)
     const uint32_t*   mesh_texture;  // texture index per mesh (MeshComponent::material_index)

@@ -86,7 +86,7 @@ struct BvhBuildArgs
     const uint4*    mesh_offsets;   // per mesh: (first_vertex_offset, first_index_offset, -, -)
     uint32_t        tri_count;
     // outputs
-    float4*         shade_tris;     // 6 per triangle, global order
+    float4*         shade_tris;     // kShadeRec per triangle, global order
     float4*         tris_sorted;    // 4 per triangle, leaf order
     float4*         nodes;          // 4 per internal node
     uint32_t*       leaf_tri;       // global triangle id per leaf

@@ -663,7 +663,7 @@ int cap_bvh_build(CapContext* c)
     if (!c->scene_ready) return fail(CAP_ERR_STATE, "cap_bvh_build: no scene uploaded");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t n = c->tri_count;
-    HIP_TRY(c->shade_tris.ensure(6 * (size_t)n));
+    HIP_TRY(c->shade_tris.ensure(kShadeRec * (size_t)n));
     // + 4 zero records: the exhaustive kernels test triangles in pairs and fetch one pair ahead (kernels.hip); a zero record
     // has det == 0 and is never hit
     HIP_TRY(c->tris_sorted.ensure(4 * ((size_t)n + 4)));

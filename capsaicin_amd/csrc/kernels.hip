@@ -1490,7 +1490,7 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
         {
             ++n_shaded;
             // scene.h:5-50 InterpolateAttributes on the pre-gathered triangle record
-            const float4* tab = shade_tab + 6 * (size_t)gid;
+            const float4* tab = shade_tab + kShadeRec * (size_t)gid;
             const float4  s0 = tab[0], s1 = tab[1], s2 = tab[2], s3 = tab[3], s4 = tab[4], s5 = tab[5];
             const float   u = hit.x, v = hit.y, w = (1.0f - u) - v;
             auto          mix = [&](float c0, float c1, float c2) { return fmaf(c2, v, fmaf(c1, u, c0 * w)); };
@@ -1501,9 +1501,9 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
             uint32_t inst = 0;
             if (a.scene.texture_count != 0 || (FIRST && slot == a.aov_slot))  // wave-uniform: untextured scenes skip the dependent load
             {
-                const uint4 id     = a.scene.tri_ids[gid];  // .z = mesh_texture[instance], stored per triangle: one load, not two in a row
-                inst               = id.x;
-                const uint32_t tex = id.z;
+                const float4 idf   = tab[6];  // (instance, primitive, mesh_texture[instance]) in the record itself: no second fetch
+                inst               = f2u(idf.x);
+                const uint32_t tex = f2u(idf.z);
                 if (tex != kInvalidId && tex < a.scene.texture_count)
                 {
                     const float tu = mix(s0.w, s2.w, s4.w), tv = mix(s1.w, s3.w, s5.w);
@@ -1672,13 +1672,13 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
     else if (valid)
     {
         ++n_shaded;
-        const float4* st = shade_tab + 6 * (size_t)gid;
+        const float4* st = shade_tab + kShadeRec * (size_t)gid;
         const float4  s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3], s4 = st[4], s5 = st[5];
         const float   u = hit.x, v = hit.y, w = (1.0f - u) - v;
         auto          mix = [&](float c0, float c1, float c2) { return fmaf(c2, v, fmaf(c1, u, c0 * w)); };
         const v3      n = normalize3(mk3(mix(s3.x, s4.x, s5.x), mix(s3.y, s4.y, s5.y), mix(s3.z, s4.z, s5.z)));
         p = mk3(mix(s0.x, s1.x, s2.x), mix(s0.y, s1.y, s2.y), mix(s0.z, s1.z, s2.z));
-        const uint32_t    inst = a.scene.tri_ids[gid].x;
+        const uint32_t    inst = f2u(st[6].x);
         const MaterialDev m    = a.scene.materials[inst];
         const v3    kd = mk3(m.kd[0], m.kd[1], m.kd[2]), ks = mk3(m.ks[0], m.ks[1], m.ks[2]), ke = mk3(m.ke[0], m.ke[1], m.ke[2]);
         const float alpha = fmaxf(m.roughness * m.roughness, 1e-3f), a2 = alpha * alpha;
@@ -1709,7 +1709,7 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
                 if (a.scene.light_cdf[mid] > target) hi = mid; else lo = mid + 1;
             }
             const uint32_t lg = a.scene.light_tris[lo];
-            const float4*  lt = shade_tab + 6 * (size_t)lg;
+            const float4*  lt = shade_tab + kShadeRec * (size_t)lg;
             const float4   l0 = lt[0], l1 = lt[1], l2 = lt[2];
             const v3       q0 = mk3(l0.x, l0.y, l0.z), q1 = mk3(l1.x, l1.y, l1.z), q2 = mk3(l2.x, l2.y, l2.z);
             const float    su = sqrtf(pre.r5), b0 = 1.0f - su, b1 = su * (1.0f - pre.r6), b2 = su * pre.r6;
@@ -1722,7 +1722,7 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
             const float cos_s = dot3(nf, wi), cos_l = fabsf(dot3(nl, wi));
             if (cos_s > 0.0f && cos_l > 0.0f && d2 > 0.0f)
             {
-                const MaterialDev lm  = a.scene.materials[a.scene.tri_ids[lg].x];
+                const MaterialDev lm  = a.scene.materials[f2u(lt[6].x)];
                 const ExtBsdf     bs  = ext_bsdf(kd, ks, a2, nf, wo, wi);
                 const float       wgt = ((cos_s * cos_l) * a.scene.light_area) / d2;
                 const v3 c = mk3((thr.x * bs.f.x) * (lm.ke[0] * wgt), (thr.y * bs.f.y) * (lm.ke[1] * wgt), (thr.z * bs.f.z) * (lm.ke[2] * wgt));
@@ -1912,7 +1912,7 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
     const uint32_t chunks   = FIRST ? cps * a.n_slots : (a.in.class_capacity >> 6) * kQueueClasses;
     uint32_t       n_shaded = 0;
     __shared__ FrameConst lds_frames[kMaxFrameSlots];
-    __shared__ float4     lds_shade[LDS ? 6 * kExhaustiveMax : 1];
+    __shared__ float4     lds_shade[LDS ? kShadeRec * kExhaustiveMax : 1];
     __shared__ float4     lds_rec[LDS ? 4 * kExhaustiveMax : 1];
     constexpr bool        ORG = FIRST && LDS;  // camera rays of a small scene: per-pair origin terms from a table (pair_scaled<ORG>)
     __shared__ float4     lds_org[ORG ? kExhaustiveMax : 1];
@@ -1924,7 +1924,7 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
     if (LDS)
     {
         const uint32_t n = bvh.tri_count <= kExhaustiveMax ? bvh.tri_count : kExhaustiveMax;
-        for (uint32_t k = threadIdx.x; k < 6 * n; k += kBlock) lds_shade[k] = a.scene.shade_tris[k];
+        for (uint32_t k = threadIdx.x; k < kShadeRec * n; k += kBlock) lds_shade[k] = a.scene.shade_tris[k];
         for (uint32_t k = threadIdx.x; k < 4 * n; k += kBlock) lds_rec[k] = bvh.tris_by_id[k];
         if (ORG)
         {
