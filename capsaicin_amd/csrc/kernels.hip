@@ -1436,7 +1436,8 @@ struct Stamps
 #define STAMP(st, i, wait) ((void)0)
 #endif
 
-template <bool FIRST, bool FB = false, bool CARRY = false>
+// SKY_RMW: the sky term goes to the plane by load-add-store instead of three float atomics (the stand-alone shade stage)
+template <bool FIRST, bool FB = false, bool CARRY = false, bool SKY_RMW = false>
 __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* shade_tab, const ShadePre& pre, uint32_t klass,
                                              uint32_t pid, float4 hit, v3 thr, uint32_t& n_shaded, Stamps& st)
 {
@@ -1480,10 +1481,21 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
                 // three no-return float atomics are plain IEEE adds in program order; unlike a load-add-store they do not make
                 // the wave wait for the old value.
                 // (A load-add-store here instead, as in k_trace_any: 16.4 -> 16.6 ms.)
-                float* c = reinterpret_cast<float*>(a.planes.color + plane_idx);
-                atomicAdd(c + 0, thr.x * 0.7f);
-                atomicAdd(c + 1, thr.y * 0.7f);
-                atomicAdd(c + 2, thr.z * 0.85f);
+                if (SKY_RMW)
+                {
+                    // the tree path's shade stage: three scattered float atomics per escaping ray are three 64-B memory-side
+                    // requests each; the path is this entry's only writer within the launch, so a 16-B load-add-store gives the
+                    // same IEEE additions
+                    const float4 cur = a.planes.color[plane_idx];
+                    a.planes.color[plane_idx] = make_float4(cur.x + thr.x * 0.7f, cur.y + thr.y * 0.7f, cur.z + thr.z * 0.85f, cur.w);
+                }
+                else
+                {
+                    float* c = reinterpret_cast<float*>(a.planes.color + plane_idx);
+                    atomicAdd(c + 0, thr.x * 0.7f);
+                    atomicAdd(c + 1, thr.y * 0.7f);
+                    atomicAdd(c + 2, thr.z * 0.85f);
+                }
             }
         }
         else if (valid)
@@ -1857,7 +1869,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
             shade_vertex_ext<FIRST>(a, a.scene.shade_tris, pre, klass, pid, hit, thr, d, n_shaded);
         }
         else
-            shade_vertex<FIRST, FB>(a, a.scene.shade_tris, pre, klass, pid, hit, thr, n_shaded, st);
+            shade_vertex<FIRST, FB, false, true>(a, a.scene.shade_tris, pre, klass, pid, hit, thr, n_shaded, st);
     }
     flush_shaded(a.shaded_counter, n_shaded);
 }
