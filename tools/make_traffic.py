@@ -54,4 +54,9 @@ if len(sys.argv) > 2 and "tree" in out["kernels"]:
                                    "triangle_tests_per_ray": c["triangle_tests_per_ray"],
                                    "traversal_bytes_source": "tools/w8_counts.py on the diagnostic build (EXTRA=-DCAP_W8_COUNT)"})
 json.dump(out, open(os.path.join(root, "profiles", tag + "_traffic.json"), "w"), indent=1)
+if "tree" in out["kernels"]:  # the file VERDICT round 1 asked for by name: the tree path's two priced kernels on their own
+    tree = {"source_sha256": out["source_sha256"], "kernel": out["kernels"]["tree"], "method": out["method"]}
+    if "tree_shade" in out["kernels"]:
+        tree["shade"] = out["kernels"]["tree_shade"]
+    json.dump(tree, open(os.path.join(root, "profiles", tag + "_tree_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
