@@ -348,6 +348,8 @@ class Renderer:
         m = np.ascontiguousarray(materials, np.float32).reshape(-1, 12)
         _check(lib().cap_materials_upload(self.ctx, _p(m), m.shape[0]), "cap_materials_upload")
 
+    BVH_BUILD_AUTO, BVH_BUILD_LBVH, BVH_BUILD_SAH, BVH_BUILD_PLOC = 0, 1, 2, 3  # CapBvhBuild
+
     def set_bvh_build(self, mode):
         """0 auto, 1 LBVH on the device (fast build), 2 SAH on the host (fast trace)."""
         _check(lib().cap_set_bvh_build(self.ctx, mode), "cap_set_bvh_build")

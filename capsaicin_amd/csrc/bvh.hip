@@ -546,19 +546,18 @@ void launch_bvh_finish_host(hipStream_t stream, const BvhBuildArgs& a)
 }
 
 
-void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
+// setup + Morton codes + radix sort; the sorted (key, triangle) arrays are a.keys[r], a.vals[r] for the returned r
+int launch_bvh_sort(hipStream_t stream, const BvhBuildArgs& a)
 {
     const uint32_t n = a.tri_count;
-    if (n == 0) return;
+    if (n == 0) return 0;
     const uint32_t blocks = (n + kBlock - 1) / kBlock;
     bvh_setup(stream, a);
-    const uint32_t* sorted_keys = a.keys[0];
-    const uint32_t* sorted_vals = a.vals[0];
+    int src = 0;
     if (n >= 2)
     {
         hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(kBlock), 0, stream, a);
         const uint32_t nb = (uint32_t)bvh_radix_blocks(n);
-        int            src = 0;
         for (uint32_t shift = 0; shift < 32; shift += 8)
         {
             hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(kBlock), 0, stream, a.keys[src], n, shift, nb, a.hist);
@@ -567,16 +566,24 @@ void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
                                a.vals[src ^ 1], n, shift, nb, a.hist);
             src ^= 1;
         }
-        sorted_keys = a.keys[src];
-        sorted_vals = a.vals[src];
-        hipLaunchKernelGGL(k_hierarchy, dim3(blocks), dim3(kBlock), 0, stream, sorted_keys, n, a.nodes, a.parent, a.keys[src ^ 1]);  // the other key buffer is free after the sort
     }
     else
     {
         const uint32_t zero = 0;
         (void)hipMemcpyAsync(a.vals[0], &zero, sizeof(zero), hipMemcpyHostToDevice, stream);
     }
-    hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(kBlock), 0, stream, a, sorted_vals);
+    return src;
+}
+
+void launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a)
+{
+    const uint32_t n = a.tri_count;
+    if (n == 0) return;
+    const uint32_t blocks = (n + kBlock - 1) / kBlock;
+    const int      src    = launch_bvh_sort(stream, a);
+    if (n >= 2)
+        hipLaunchKernelGGL(k_hierarchy, dim3(blocks), dim3(kBlock), 0, stream, a.keys[src], n, a.nodes, a.parent, a.keys[src ^ 1]);  // the other key buffer is free after the sort
+    hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(kBlock), 0, stream, a, a.vals[src]);
     hipLaunchKernelGGL(k_depth, dim3(blocks), dim3(kBlock), 0, stream, a.parent, n, a.max_depth);
 }
 }  // namespace cap

@@ -103,6 +103,15 @@ struct BvhBuildArgs
 };
 size_t bvh_radix_blocks(uint32_t n);
 void   launch_bvh_build(hipStream_t stream, const BvhBuildArgs& a);
+int    launch_bvh_sort(hipStream_t stream, const BvhBuildArgs& a);  // setup + Morton order only: a.keys[r] / a.vals[r] sorted, returns r
+// Agglomerative build with a surface-area distance over the Morton order (ploc.hip); same outputs as launch_bvh_build,
+// incl. the subtree counts in a.keys[1].  boxes: 4 * tri_count float4; ints: 3 * tri_count + 4 words.  Returns 0 on success.
+struct PlocScratch
+{
+    float4*   boxes;
+    uint32_t* ints;
+};
+int    launch_bvh_build_ploc(hipStream_t stream, const BvhBuildArgs& a, const PlocScratch& s, uint32_t radius);
 // Host-built tree (sah_builder.cpp): setup = triangle records, boxes and scene bounds only; finish = after `nodes` and
 // `leaf_tri` have been uploaded: intersection records into leaf order + the wide view.
 void launch_bvh_setup(hipStream_t stream, const BvhBuildArgs& a);

@@ -151,6 +151,8 @@ struct CapContext
     DevBuf<float4>   fan_pairs, fan_singles;  // exhaustive path: fan-pair records (5 float4) and the unpaired triangles (4 float4)
     uint32_t         fan_pair_count = 0, fan_single_count = 0;
     DevBuf<uint32_t> leaf_tri, keys0, keys1, vals0, vals1, hist, parent, flags, bvh_misc;  // bvh_misc: 6 bounds + depth
+    DevBuf<float4>   ploc_boxes;  // CAP_BVH_BUILD_PLOC scratch (ploc.hip)
+    DevBuf<uint32_t> ploc_ints;
     CapBvhInfo       bvh_info{};
     bool             bvh_ready = false;
 
@@ -691,6 +693,7 @@ int cap_bvh_build(CapContext* c)
     // AUTO: scenes the exhaustive kernels handle need no tree quality; everything else is built once and traced for a long
     // time (the reference asks the driver for PREFER_FAST_TRACE, blas_system.cpp:42-47), so it gets the host-side SAH build.
     const bool sah = n >= 2 && (c->bvh_build_mode == CAP_BVH_BUILD_SAH || (c->bvh_build_mode == CAP_BVH_BUILD_AUTO && n > kExhaustiveMax));
+    const bool ploc = !sah && n >= 2 && c->bvh_build_mode == CAP_BVH_BUILD_PLOC;
     const auto wall0 = std::chrono::steady_clock::now();
     uint32_t   host_depth = 0;
     std::vector<float> bnodes_host;  // the binary tree on the host, for the collapse into the compressed 8-wide view
@@ -708,6 +711,14 @@ int cap_bvh_build(CapContext* c)
         HIP_TRY(hipMemcpy(c->leaf_tri.p, tree.order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
         launch_bvh_finish_host(c->stream, a);
         bnodes_host.swap(tree.nodes);
+    }
+    else if (ploc)
+    {
+        HIP_TRY(c->ploc_boxes.ensure(4 * (size_t)n));
+        HIP_TRY(c->ploc_ints.ensure(3 * (size_t)n + 4));
+        static const int radius = getenv("CAP_PLOC_RADIUS") ? atoi(getenv("CAP_PLOC_RADIUS")) : 16;  // A/B switch
+        const int rc = launch_bvh_build_ploc(c->stream, a, PlocScratch{c->ploc_boxes.p, c->ploc_ints.p}, (uint32_t)radius);
+        if (rc != 0) return fail(CAP_ERR_HIP, "cap_bvh_build: clustering build failed (%d)", rc);
     }
     else
         launch_bvh_build(c->stream, a);
@@ -913,7 +924,7 @@ int cap_set_batch_paths(CapContext* c, uint64_t max_paths)
 int cap_set_bvh_build(CapContext* c, uint32_t mode)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_bvh_build: ctx is NULL");
-    if (mode > CAP_BVH_BUILD_SAH) return fail(CAP_ERR_INVALID_ARG, "cap_set_bvh_build: unknown mode %u", mode);
+    if (mode > CAP_BVH_BUILD_PLOC) return fail(CAP_ERR_INVALID_ARG, "cap_set_bvh_build: unknown mode %u", mode);
     c->bvh_build_mode = mode;
     return CAP_OK;
 }

@@ -166,15 +166,18 @@ int cap_materials_upload(CapContext* ctx, const CapMaterial* materials, uint32_t
 /* Replaces BLASSystem::BuildBLAS + TLASSystem::BuildTLAS (blas_system.cpp:14-67, tlas_system.cpp:11-73):
  * explicit on-device LBVH over all meshes; (instance, primitive) ids are kept per triangle. */
 int cap_bvh_build(CapContext* ctx);
-/* How cap_bvh_build builds the tree (the hits are the same either way).  LBVH: on the device, ~0.3 ms for 262 k triangles (dynamic
- * scenes).  SAH: binned surface-area heuristic on the host, ~0.1 s for 262 k triangles, faster traversal -- the counterpart of
+/* How cap_bvh_build builds the tree (the hits are the same either way; every build ends with the collapse into the compressed
+ * 8-wide view).  LBVH: Morton hierarchy on the device, ~4 ms for 262 k triangles.  PLOC: agglomerative clustering on the device
+ * with a surface-area distance (ploc.hip), ~3 ms, shadow and camera rays as fast as with the SAH tree -- the build for scenes
+ * that change.  SAH: binned surface-area heuristic on the host, ~0.15 s for 262 k triangles, fastest traversal -- the counterpart of
  * D3D12_RAYTRACING_ACCELERATION_STRUCTURE_BUILD_FLAG_PREFER_FAST_TRACE, which the reference asks for (blas_system.cpp:42-47) while
  * building only once (tlas_system.cpp:111-121).  AUTO: SAH above 64 triangles (smaller scenes are traced exhaustively). */
 typedef enum CapBvhBuild
 {
     CAP_BVH_BUILD_AUTO = 0,
     CAP_BVH_BUILD_LBVH = 1,
-    CAP_BVH_BUILD_SAH  = 2
+    CAP_BVH_BUILD_SAH  = 2,
+    CAP_BVH_BUILD_PLOC = 3 /* on the device: agglomerative clustering over the Morton order with a surface-area distance */
 } CapBvhBuild;
 int cap_set_bvh_build(CapContext* ctx, uint32_t mode);
 int cap_bvh_info(CapContext* ctx, CapBvhInfo* out);

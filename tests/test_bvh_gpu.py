@@ -78,7 +78,7 @@ def check_tree(nodes, leaves, tri_lo, tri_hi):
     return max_depth
 
 
-@pytest.mark.parametrize("build", [1, 2])  # on-device LBVH, host-side SAH: same layout, same invariants
+@pytest.mark.parametrize("build", [1, 2, 3])  # on-device LBVH, host-side SAH, on-device clustering: same layout, same invariants
 @pytest.mark.parametrize("seed,ntri", [(1, 1), (2, 2), (3, 3), (4, 33), (5, 1000), (6, 20000)])
 def test_lbvh_invariants(native_lib, bluenoise, seed, ntri, build):
     pos, nrm, uv, idx, meshes = soup(seed, ntri)
@@ -112,7 +112,7 @@ def test_duplicate_centroids_and_flat_scene(native_lib, bluenoise):
     r.close()
 
 
-@pytest.mark.parametrize("build", [1, 2])
+@pytest.mark.parametrize("build", [1, 2, 3])
 @pytest.mark.parametrize("seed,ntri,w,h,D", [(11, 1, 48, 48, 2), (12, 2, 48, 48, 2), (13, 300, 96, 96, 3), (14, 5000, 128, 96, 4),
                                             (15, 700, 61, 37, 3)])  # the last: partial tiles (idle lanes in the camera-ray packets)
 def test_triangle_soup_parity(native_lib, bluenoise, seed, ntri, w, h, D, build):
@@ -215,7 +215,7 @@ def test_fan_pairs_parity(native_lib, bluenoise, seed, nquads, nsingles, fold):
     r.close()
 
 
-@pytest.mark.parametrize("build", [1, 2])
+@pytest.mark.parametrize("build", [1, 2, 3])
 def test_geometric_progression_scene(native_lib, bluenoise, build):
     """Triangles whose size and distance grow geometrically: the SAH build wants to peel them off one by one (a tree as deep as
     the triangle count) and Morton codes collapse most of them into one cell.  Both builders must stay within the traversal
@@ -330,7 +330,7 @@ def test_textured_quad_parity(native_lib, bluenoise):
     r.close()
 
 
-@pytest.mark.parametrize("n,build", [(2, 1), (7, 1), (500, 1), (20000, 1), (20000, 2)])
+@pytest.mark.parametrize("n,build", [(2, 1), (7, 1), (500, 1), (20000, 1), (20000, 2), (2, 3), (7, 3), (1500, 3), (20000, 3)])
 def test_wide_view_structure_on_device(native_lib, n, build):
     """The compressed 8-wide view as cap_bvh_build leaves it on the device -- collapsed on the device itself for the device-built
     LBVH (bvh.hip k_wide_level), on the host for the SAH tree -- satisfies the structural and conservativeness checks of the host
