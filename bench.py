@@ -450,7 +450,7 @@ def main():
                 tree_variant = {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d 16spp depth=%d, reference shading" %
                                             (bi2.triangle_count, WIDTH, HEIGHT, DEPTH),
                                 "value": trays / tdt / 1e6, "unit": "Mrays/s", "ms_per_step": tdt / 2 * 1e3,
-                                "bvh": {"build": "host SAH + 8-wide collapse", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
+                                "bvh": {"build": "device PLOC + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
                                 "roofline": troof, "shade_roofline": sroof,
                                 "stage_ms": {"primary": tp.ms_primary, "trace_closest": tp.ms_trace_closest, "trace_any": tp.ms_trace_any,
                                              "shade": tp.ms_shade, "resolve": tp.ms_resolve, "total": tp.ms_total}}

@@ -351,7 +351,7 @@ class Renderer:
     BVH_BUILD_AUTO, BVH_BUILD_LBVH, BVH_BUILD_SAH, BVH_BUILD_PLOC = 0, 1, 2, 3  # CapBvhBuild
 
     def set_bvh_build(self, mode):
-        """0 auto, 1 LBVH on the device (fast build), 2 SAH on the host (fast trace)."""
+        """0 auto (clustering build on the device above 64 triangles), 1 Morton hierarchy on the device, 2 SAH on the host, 3 clustering."""
         _check(lib().cap_set_bvh_build(self.ctx, mode), "cap_set_bvh_build")
 
     def build_bvh(self):

@@ -10,7 +10,7 @@
 //            compact the array (order kept: it stays a space-filling-curve order)
 //   until one cluster is left.
 //
-// Every step is deterministic (ties to the lower position, node numbers from a prefix sum), so the tree is the same on every
+// Every step is deterministic (ties by a symmetric pair key, node numbers from a prefix sum), so the tree is the same on every
 // run.  Node numbers count down from n - 2: the last merge is node 0, the root all traversals start from.  While more than
 // kPlocTail clusters are left an iteration is four launches (search, count, scan, merge) and one 4-byte read-back; the rest
 // runs in one workgroup out of LDS.  Two passes then put the leaves into depth-first order (a subtree's triangles
@@ -72,6 +72,16 @@ __global__ __launch_bounds__(kPlocBlock) void k_ploc_init(PlocArgs a)
     a.lo[0][i] = lo, a.hi[0][i] = hi, a.ref[0][i] = ~(int)i;
 }
 
+// Equal distances (copies of one triangle, regular grids) are ordered by a key that is symmetric in the pair -- closer positions
+// first, then pairs whose lower position is even, then the lower position -- so that both ends of a pair agree on it: with every
+// distance equal, positions (0, 1), (2, 3), ... are mutual nearest neighbours and the array halves per iteration (an asymmetric
+// rule such as "the lower position wins" merges one pair per iteration there and builds a chain of depth n).
+__device__ __forceinline__ uint32_t ploc_tie_key(int i, int j)
+{
+    const uint32_t a = (uint32_t)(i < j ? i : j), d = (uint32_t)(i < j ? j - i : i - j);
+    return (d << 26) | ((a & 1u) << 25) | (a & 0x1ffffffu);  // d <= kPlocMaxRadius; the last term only orders equal (d, parity)
+}
+
 // the nearest neighbour of cluster `i` among positions [i - radius, i + radius] of an array of m; tile[] holds the boxes of
 // positions tile_first ...
 template <typename Box>
@@ -85,7 +95,7 @@ __device__ __forceinline__ int ploc_nearest(const Box* t_lo, const Box* t_hi, in
     {
         if (j == i) continue;
         const float ar = union_half_area(lo, hi, t_lo[j - tile_first], t_hi[j - tile_first]);
-        if (ar < best) best = ar, bj = j;  // ascending j, strict <: ties to the lower position
+        if (ar < best || (ar == best && ploc_tie_key(i, j) < ploc_tie_key(i, bj))) best = ar, bj = j;
     }
     if (bj < 0) bj = i > 0 ? i - 1 : i + 1;  // only if every area is inf / nan
     return bj;

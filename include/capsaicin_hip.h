@@ -171,7 +171,8 @@ int cap_bvh_build(CapContext* ctx);
  * with a surface-area distance (ploc.hip), ~3 ms, shadow and camera rays as fast as with the SAH tree -- the build for scenes
  * that change.  SAH: binned surface-area heuristic on the host, ~0.15 s for 262 k triangles, fastest traversal -- the counterpart of
  * D3D12_RAYTRACING_ACCELERATION_STRUCTURE_BUILD_FLAG_PREFER_FAST_TRACE, which the reference asks for (blas_system.cpp:42-47) while
- * building only once (tlas_system.cpp:111-121).  AUTO: SAH above 64 triangles (smaller scenes are traced exhaustively). */
+ * building only once (tlas_system.cpp:111-121).  AUTO: PLOC above 64 triangles (trace times within 1 % of the SAH tree's; smaller
+ * scenes are traced exhaustively and get the Morton hierarchy). */
 typedef enum CapBvhBuild
 {
     CAP_BVH_BUILD_AUTO = 0,

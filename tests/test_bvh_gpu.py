@@ -96,7 +96,25 @@ def test_lbvh_invariants(native_lib, bluenoise, seed, ntri, build):
     r.close()
 
 
-def test_duplicate_centroids_and_flat_scene(native_lib, bluenoise):
+@pytest.mark.parametrize("build", [1, 2, 3])
+def test_identical_triangles(native_lib, bluenoise, build):
+    # 3000 copies of one triangle: every Morton code, every box and every merge distance ties; the builders' index tie-breaks
+    # must still produce a complete tree of bounded depth (the clustering build: mutual nearest neighbours exist in every round)
+    n = 3000
+    pos = np.tile(np.float32([[0.25, -1, 0.5], [1, 0.5, -0.25], [-0.5, 1, 2]]), (n, 1))
+    r = capi.Renderer(0)
+    r.upload_scene(pos, np.tile(np.float32([0, 0, 1]), (len(pos), 1)), np.zeros((len(pos), 2), np.float32),
+                   np.arange(len(pos), dtype=np.uint32), np.uint32([[len(pos), 0, len(pos), 0, 0, 0xFFFFFFFF, 0, 0]]))
+    r.set_bvh_build(build)
+    info = r.build_bvh()
+    nodes, leaves = r.bvh_readback()
+    tri = pos.reshape(-1, 3, 3)
+    assert check_tree(nodes, leaves, tri.min(1), tri.max(1)) == info.max_depth and info.max_depth <= 64
+    r.close()
+
+
+@pytest.mark.parametrize("build", [0, 1, 3])
+def test_duplicate_centroids_and_flat_scene(native_lib, bluenoise, build):
     # all triangles share one centroid / lie in one plane: Morton codes collide, the index tie-break must still give a tree
     base = np.float32([[-1, -1, 0], [1, -1, 0], [0, 2, 0]])
     pos = np.concatenate([base * s for s in (1.0, 0.5, 0.25, 2.0, 1.5, 0.75, 1.25)]).astype(np.float32)
@@ -104,6 +122,7 @@ def test_duplicate_centroids_and_flat_scene(native_lib, bluenoise):
     r = capi.Renderer(0)
     r.upload_scene(pos, np.tile(np.float32([0, 0, 1]), (len(pos), 1)), np.zeros((len(pos), 2), np.float32),
                    np.arange(len(pos), dtype=np.uint32), np.uint32([[len(pos), 0, len(pos), 0, 0, 0xFFFFFFFF, 0, 0]]))
+    r.set_bvh_build(build)
     info = r.build_bvh()
     nodes, leaves = r.bvh_readback()
     tri = pos.reshape(-1, 3, 3)

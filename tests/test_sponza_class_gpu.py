@@ -53,11 +53,13 @@ def _setup(tmp, scale, tex_size):
     return geo, texs
 
 
-def test_small_scale_parity(native_lib, bluenoise, tmp_path):
+@pytest.mark.parametrize("build", [0, 1, 2])  # AUTO (device clustering), device Morton hierarchy, host SAH: same hits
+def test_small_scale_parity(native_lib, bluenoise, tmp_path, build):
     from oracle import cap_oracle as O
     geo, texs = _setup(tmp_path, 0.1, 64)
     w, h, D = 96, 64, 3
     r = capi.Renderer(0)
+    r.set_bvh_build(build)
     r.upload_geometry(geo)
     for i, t in enumerate(texs):
         r.upload_texture(i, t)
