@@ -56,6 +56,9 @@ struct ShadeArgs
 // feedback: vertices of bounce >= 1 that the previous frame saw take its shaded colour and end the path (rt_indirect.hlsl:116-145;
 // reference shading model only)
 void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext, bool feedback = false);
+// tree path, bounce 0: camera-ray packet walk + shading in one kernel (args.work = bounce 0's grab counters); false if the
+// configuration does not take the packet walk -- then launch_trace_primary + launch_shade do the same in two kernels
+bool launch_primary_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, float4* hits, bool ext);
 // small-scene path: exhaustive closest hit fused with the shading of the vertex found (bounce 0 generates the camera rays)
 void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, bool ext, bool feedback = false);
 

@@ -1096,14 +1096,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             fflush(stderr);
             return e == hipSuccess ? CAP_OK : CAP_ERR_HIP;
         };
-        if (!fused)
-        {
-            {
-                StageTimer t(c, ST_PRIMARY, st);
-                launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, c->hits.p, work_shade /* bounce 0's slot: unused by k_shade */);
-            }
-            if (aov_slot != ~0u) launch_geo_aov(cfg, scene, c->hits.p + (size_t)aov_slot * Ppad, Ppad, c->aov_geo.p);
-        }
+        bool primary_shaded = false;  // tree path: bounce 0's shading done by the camera-ray kernel
         for (uint32_t b = 0; b <= D; ++b)
         {
             const int pi = (int)(b & 1u), po = pi ^ 1;
@@ -1121,8 +1114,20 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             }
             else
             {
-                StageTimer t(c, ST_SHADE, st, b == 0 ? ST_DIRECT : ST_NONE);
-                launch_shade(cfg, sa, ext, feedback);
+                if (b == 0)
+                {
+                    {
+                        StageTimer t(c, ST_PRIMARY, st);
+                        primary_shaded = launch_primary_shade(cfg, bvh, sa, c->hits.p, ext);
+                        if (!primary_shaded) launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, c->hits.p, sa.work);
+                    }
+                    if (aov_slot != ~0u) launch_geo_aov(cfg, scene, c->hits.p + (size_t)aov_slot * Ppad, Ppad, c->aov_geo.p);
+                }
+                if (b != 0 || !primary_shaded)
+                {
+                    StageTimer t(c, ST_SHADE, st, b == 0 ? ST_DIRECT : ST_NONE);
+                    launch_shade(cfg, sa, ext, feedback);
+                }
                 ++c->stats.launches_shade;
             }
             {

@@ -1874,6 +1874,70 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
     flush_shaded(a.shaded_counter, n_shaded);
 }
 
+// Tree path, bounce 0: the camera rays' packet walk (k_trace_primary_packet) and the shading of the vertices it finds in one
+// kernel, like the small-scene path's k_trace_shade<FIRST>: the hit records (32 B per path written and read back) stay in
+// registers, and the shade stage's streaming writes -- three planes and two queue entries per path, the HBM-bound part --
+// overlap the packet walk's arithmetic of the other waves.  Only the AOV slot's hits are stored (launch_geo_aov reads them).
+#ifndef CAP_PS_BLOCKS
+#define CAP_PS_BLOCKS 8  // workgroups per CU (residency sweep 4 ... 8: 3.7, 3.25, 3.05, 2.86, 2.81 ms: the packet walk wants waves more than registers)
+#endif
+template <bool EXT>
+__global__ __launch_bounds__(kBlock, CAP_PS_BLOCKS) void k_primary_shade(BvhDev bvh, ShadeArgs a, float4* hits_out)
+{
+    __shared__ uint32_t   lds_wstack[(kBlock / 64) * kPacketStack];
+    __shared__ FrameConst lds_frames[kMaxFrameSlots];
+    stage_frames(a, lds_frames);  // ends with the workgroup barrier
+    uint32_t*      wstack   = lds_wstack + (threadIdx.x >> 6) * kPacketStack;
+    const uint32_t Ppad     = a.screen.pixels_padded;
+    const uint32_t cps      = Ppad >> 6;
+    const uint32_t chunks   = cps * a.n_slots;
+    const uint32_t my_class = wave_global_id() % kQueueClasses;
+    uint32_t       n_shaded = 0;
+    uint32_t       grab     = grab_issue(a.work, my_class);
+    Stamps         st;
+    st.start();
+    while (true)
+    {
+        const uint32_t chunk = grab_value(grab) * kQueueClasses + my_class;  // chunk % kQueueClasses: the paths' class, as k_shade<FIRST> assigns it
+        if (chunk >= chunks) break;
+        grab = grab_issue(a.work, my_class);
+        const uint32_t slot = chunk / cps;  // wave-uniform
+        const uint32_t pl   = (chunk - slot * cps) * 64 + (threadIdx.x & 63u);
+        uint32_t       x = 0, y = 0;
+        const bool     alive = local_pixel_to_xy(a.screen, pl, x, y);
+        const Ray      r     = make_ray(mk3(a.cam.position[0], a.cam.position[1], a.cam.position[2]),
+                                        alive ? primary_dir(a.cam, a.screen, lds_frames[slot], x, y) : mk3(0.f, 0.f, 1.f), 0.0f, kPrimaryFar);
+        float          t, u, v;
+        uint32_t       gid;
+        traverse_closest_packet(bvh, r, alive, wstack, t, u, v, gid);
+        const float4 hit = make_float4(alive ? u : 0.0f, alive ? v : 0.0f, u2f(gid), alive ? t : kPrimaryFar);
+        if (slot == a.aov_slot) hits_out[(size_t)slot * Ppad + pl] = hit;
+        const uint32_t pid = (slot << kPidShift) | pl;
+        const ShadePre pre = shade_prefetch<EXT>(a, lds_frames, true, pid);
+        if constexpr (EXT)
+            shade_vertex_ext<true>(a, a.scene.shade_tris, pre, my_class, pid, hit, mk3(1.0f, 1.0f, 1.0f), r.d, n_shaded);
+        else
+            shade_vertex<true, false, false, true>(a, a.scene.shade_tris, pre, my_class, pid, hit, mk3(1.0f, 1.0f, 1.0f), n_shaded, st);
+    }
+    flush_shaded(a.shaded_counter, n_shaded);
+}
+
+bool launch_primary_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, float4* hits, bool ext)
+{
+    static const bool off = getenv("CAP_NO_PRIMARY_FUSE") != nullptr || getenv("CAP_NO_PACKET") != nullptr;  // A/B switches
+    if (off || cfg.stack_entries == 0 || !args.work || bvh.tri_count < 2 || !cfg.cu_count) return false;
+    const uint32_t chunks = (args.screen.pixels_padded >> 6) * args.n_slots;
+    uint32_t       gx     = (chunks + 3) / 4;
+    const uint32_t cap    = ext ? resident_grid<k_primary_shade<true>>(cfg, ~0u) : resident_grid<k_primary_shade<false>>(cfg, ~0u);
+    if (gx > cap) gx = cap;
+    if (gx == 0) gx = 1;
+    if (ext)
+        hipLaunchKernelGGL(k_primary_shade<true>, dim3(gx), dim3(kBlock), 0, cfg.stream, bvh, args, hits);
+    else
+        hipLaunchKernelGGL(k_primary_shade<false>, dim3(gx), dim3(kBlock), 0, cfg.stream, bvh, args, hits);
+    return true;
+}
+
 void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext, bool feedback)
 {
     if (args.bounce == 0)
