@@ -9,7 +9,7 @@ python3 - <<PY
 import csv, glob, re
 f = glob.glob("$OUT/prof_tree/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-rows = [r for r in rows if re.search(r"k_trace|k_shade|k_resolve", r["Kernel_Name"])]
+rows = [r for r in rows if re.search(r"k_trace|k_shade|k_resolve|k_primary", r["Kernel_Name"])]
 # last batch only: from the last packet/primary launch on
 start = max(i for i, r in enumerate(rows) if "primary" in r["Kernel_Name"])
 for r in rows[start:]:
