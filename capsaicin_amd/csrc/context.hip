@@ -1127,8 +1127,8 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                 {
                     StageTimer t(c, ST_SHADE, st, b == 0 ? ST_DIRECT : ST_NONE);
                     launch_shade(cfg, sa, ext, feedback);
+                    ++c->stats.launches_shade;
                 }
-                ++c->stats.launches_shade;
             }
             {
                 StageTimer t(c, ST_ANY, st, b == 0 ? ST_DIRECT : ST_NONE);
