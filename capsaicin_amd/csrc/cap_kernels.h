@@ -51,6 +51,9 @@ struct ShadeArgs
     uint64_t*         shaded_counter;
     uint32_t*         work;        // fused kernels: kQueueClasses chunk-grab counters of this launch (zeroed), kCounterStride apart
     FeedbackDev       fb;          // read only by the feedback variants
+    // untextured scene, reference shading, accumulate-only render (nobody but the resolve reads the planes): the first vertex's albedo
+    // is one of four constants, so the albedo plane is not used and direct.w carries a code instead of 1 (kernels.hip shade_vertex)
+    uint32_t          albedo_in_w;
     uint32_t          cull_camera_pairs;  // bounce 0 of the small-scene path: the camera basis is orthonormal, so a tile may skip the pairs off its screen area
 };
 // feedback: vertices of bounce >= 1 that the previous frame saw take its shaded colour and end the path (rt_indirect.hlsl:116-145;
@@ -64,7 +67,8 @@ void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs
 
 // ---- accumulate / exchange ----
 // accum[pl] += sum over slots (in slot order) of color*albedo + direct; .w counts frames.
-void launch_resolve(const LaunchCfg& cfg, const Planes& planes, uint32_t n_slots, uint32_t pixels_padded, float4* accum);
+void launch_resolve(const LaunchCfg& cfg, const Planes& planes, uint32_t n_slots, uint32_t pixels_padded, float4* accum,
+                    bool albedo_in_w = false, float kd_untextured = 0.0f);
 // plane_kind: 0 copy, 1 combined (color*albedo+direct from the three planes at slot offset), 2 mean (xyz / w)
 void launch_untile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* src, const float4* albedo, const float4* direct,
                    int plane_kind, float4* image);

@@ -1082,6 +1082,9 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                                std::fabs(dotf(cd.up, cd.up) - 1.f) < 1e-4f && std::fabs(dotf(cd.forward, cd.forward) - 1.f) < 1e-4f;
             sa.cull_camera_pairs = (ortho && !no_cull) ? 1u : 0u;
         }
+        // Nobody reads this batch's planes but the resolve (plane read-backs and the reconstruction chain need CAP_RENDER_AOV)
+        static const bool no_albedo_w = getenv("CAP_NO_ALBEDO_IN_W") != nullptr;  // A/B switch
+        sa.albedo_in_w = (!no_albedo_w && !ext && !feedback && !lowres && !(flags & CAP_RENDER_AOV) && scene.texture_count == 0) ? 1u : 0u;
         if (feedback)  // g_color_history = combined_history[(frame_count + 1) % 2], raytracing_system.cpp:1754-1759
             sa.fb = FeedbackDev{camera_dev(c->prev_camera), c->post_prev_nd.p, c->post_chist[(frame_begin + 1) % 2].p};
         const bool fused = cfg.stack_entries == 0;  // small-scene path: closest hit and shading in one kernel per bounce
@@ -1150,7 +1153,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         if (!lowres)
         {
             StageTimer t(c, ST_RESOLVE, st);
-            launch_resolve(cfg, sa.planes, ns, Ppad, c->accum.p);
+            launch_resolve(cfg, sa.planes, ns, Ppad, c->accum.p, sa.albedo_in_w != 0u, scene.kd_untextured);
         }
         // queue lengths of this batch -> pinned host memory, summed at the next sync
         uint32_t* pinned = nullptr;

@@ -1462,8 +1462,8 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
         {
             // padding lane of a partial / absent tile: define the planes so the resolve adds exact zeros
             a.planes.color[plane_idx]  = make_float4(0, 0, 0, 0);
-            a.planes.direct[plane_idx] = make_float4(0, 0, 0, 0);
-            a.planes.albedo[plane_idx] = make_float4(0, 0, 0, 0);
+            a.planes.direct[plane_idx] = make_float4(0, 0, 0, 0);  // albedo_in_w: code 0
+            if (!a.albedo_in_w) a.planes.albedo[plane_idx] = make_float4(0, 0, 0, 0);
         }
         if (valid && gid == kInvalidId)
         {
@@ -1471,8 +1471,8 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
             {
                 // rt_direct_lighting.hlsl:53-59, rt_indirect.hlsl:75-79
                 a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
-                a.planes.direct[plane_idx] = make_float4(0.7f, 0.7f, 0.85f, 1.f);
-                a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);
+                a.planes.direct[plane_idx] = make_float4(0.7f, 0.7f, 0.85f, 1.f);  // albedo_in_w: code 1
+                if (!a.albedo_in_w) a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (slot == a.aov_slot) a.planes.aov_normal_depth[pl] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             else
@@ -1527,8 +1527,10 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
             if (FIRST)
             {
                 a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
-                a.planes.direct[plane_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
-                a.planes.albedo[plane_idx] = black ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(kd.x, kd.y, kd.z, 1.f);
+                // albedo_in_w (untextured scene, accumulate-only render): the albedo is one of four constants, so its plane is
+                // neither written nor read; direct.w carries which -- 0: (0,0,0) padding, 1: (1,1,1) sky, 2: the untextured kd, 3: black
+                a.planes.direct[plane_idx] = make_float4(0.f, 0.f, 0.f, a.albedo_in_w ? (black ? 3.f : 2.f) : 1.f);
+                if (!a.albedo_in_w) a.planes.albedo[plane_idx] = black ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(kd.x, kd.y, kd.z, 1.f);
                 if (slot == a.aov_slot)
                 {
                     float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2190,7 +2192,9 @@ void launch_trace_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs
 // Accumulate / exchange
 // ------------------------------------------------------------------------------------------------
 // combine_illumination.hlsl:29 per frame, then a plain running fp32 sum in frame order.
-__global__ __launch_bounds__(kBlock) void k_resolve(Planes planes, uint32_t n_slots, uint32_t Ppad, float4* accum)
+// ALBEDO_IN_W (ShadeArgs::albedo_in_w): no albedo plane; direct.w says which of the four constant albedos the path's first vertex has
+template <bool ALBEDO_IN_W>
+__global__ __launch_bounds__(kBlock) void k_resolve(Planes planes, uint32_t n_slots, uint32_t Ppad, float4* accum, float kd_untextured)
 {
     for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < Ppad; pl += gridDim.x * kBlock)
     {
@@ -2198,7 +2202,15 @@ __global__ __launch_bounds__(kBlock) void k_resolve(Planes planes, uint32_t n_sl
         for (uint32_t s = 0; s < n_slots; ++s)
         {
             const size_t idx = (size_t)s * Ppad + pl;
-            const float4 c = planes.color[idx], al = planes.albedo[idx], d = planes.direct[idx];
+            const float4 c = planes.color[idx], d = planes.direct[idx];
+            float4       al;
+            if (ALBEDO_IN_W)
+            {
+                const float k = d.w == 1.0f ? 1.0f : (d.w == 2.0f ? kd_untextured : 0.0f);
+                al            = make_float4(k, k, k, 0.f);
+            }
+            else
+                al = planes.albedo[idx];
             acc.x = acc.x + (c.x * al.x + d.x);
             acc.y = acc.y + (c.y * al.y + d.y);
             acc.z = acc.z + (c.z * al.z + d.z);
@@ -2208,11 +2220,15 @@ __global__ __launch_bounds__(kBlock) void k_resolve(Planes planes, uint32_t n_sl
     }
 }
 
-void launch_resolve(const LaunchCfg& cfg, const Planes& planes, uint32_t n_slots, uint32_t Ppad, float4* accum)
+void launch_resolve(const LaunchCfg& cfg, const Planes& planes, uint32_t n_slots, uint32_t Ppad, float4* accum, bool albedo_in_w,
+                    float kd_untextured)
 {
     uint32_t g = (Ppad + kBlock - 1) / kBlock;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_resolve, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, planes, n_slots, Ppad, accum);
+    if (albedo_in_w)
+        hipLaunchKernelGGL(k_resolve<true>, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, planes, n_slots, Ppad, accum, kd_untextured);
+    else
+        hipLaunchKernelGGL(k_resolve<false>, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, planes, n_slots, Ppad, accum, kd_untextured);
 }
 
 __global__ __launch_bounds__(kBlock) void k_untile(ScreenDev sc, const float4* src, const float4* albedo, const float4* direct,

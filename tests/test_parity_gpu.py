@@ -92,6 +92,30 @@ def test_accumulation_across_batches_bit_exact(cornell, bluenoise):
     assert_same(mean[..., :3], acc[..., :3] / np.float32(n), "mean")
 
 
+@pytest.mark.parametrize("traversal", [1, 2])  # tree kernels, exhaustive small-scene kernels
+def test_accumulate_only_render_equals_aov_render(cornell, bluenoise, traversal):
+    """A render nobody reads planes from (flags 0) of an untextured scene keeps no albedo plane: the first vertex's albedo is one of
+    four constants and travels as a code in direct.w (ShadeArgs::albedo_in_w); one with CAP_RENDER_AOV keeps the planes as the
+    reference defines them.  Same sums, same counters."""
+    r, sc, O = cornell
+    w, h, n, D = 160, 96, 6, 5
+    r.set_resolution(w, h)
+    r.set_shard(0, 1)
+    r.set_camera(capi.cornell_camera(w, h))
+    r.set_traversal(traversal)
+    out = []
+    for flags in (0, capi.RENDER_AOV):
+        r.accum_reset()
+        r.stats_reset()
+        r.render(7, n, D, flags)
+        s = r.stats()
+        out.append((r.readback(capi.BUF_ACCUM_SUM), (s.rays_primary, s.rays_extension, s.rays_shadow)))
+    r.set_traversal(0)
+    assert out[0][1] == out[1][1]
+    assert_same(out[0][0], out[1][0], "accumulate-only vs AOV render, traversal %d" % traversal)
+    assert float(out[0][0][..., :3].max()) > 0.0
+
+
 def test_sharded_render_equals_unsharded(cornell, bluenoise):
     """Tile sharding (one context per shard) + tile buffers: assembling the shards reproduces the single-GPU image."""
     import torch
