@@ -1084,7 +1084,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         }
         // Nobody reads this batch's planes but the resolve (plane read-backs and the reconstruction chain need CAP_RENDER_AOV)
         static const bool no_albedo_w = getenv("CAP_NO_ALBEDO_IN_W") != nullptr;  // A/B switch
-        sa.albedo_in_w = (!no_albedo_w && !ext && !feedback && !lowres && !(flags & CAP_RENDER_AOV) && scene.texture_count == 0) ? 1u : 0u;
+        sa.albedo_in_w = (!no_albedo_w && !feedback && !lowres && !(flags & CAP_RENDER_AOV) && (ext || scene.texture_count == 0)) ? 1u : 0u;  // (the EXT model's first-vertex albedo is 1: it folds kd into the throughput)
         if (feedback)  // g_color_history = combined_history[(frame_count + 1) % 2], raytracing_system.cpp:1754-1759
             sa.fb = FeedbackDev{camera_dev(c->prev_camera), c->post_prev_nd.p, c->post_chist[(frame_begin + 1) % 2].p};
         const bool fused = cfg.stack_entries == 0;  // small-scene path: closest hit and shading in one kernel per bounce

@@ -1670,7 +1670,7 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
     {
         a.planes.color[plane_idx]  = make_float4(0, 0, 0, 0);
         a.planes.direct[plane_idx] = make_float4(0, 0, 0, 0);
-        a.planes.albedo[plane_idx] = make_float4(0, 0, 0, 0);
+        if (!a.albedo_in_w) a.planes.albedo[plane_idx] = make_float4(0, 0, 0, 0);
     }
     if (valid && gid == kInvalidId)
     {
@@ -1679,7 +1679,7 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
             // black environment: the camera ray that leaves the scene carries nothing
             a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
             a.planes.direct[plane_idx] = make_float4(0.f, 0.f, 0.f, 1.f);
-            a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (!a.albedo_in_w) a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);  // else: direct.w == 1 says so
             if (slot == a.aov_slot) a.planes.aov_normal_depth[pl] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -1702,7 +1702,7 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
         {
             a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
             a.planes.direct[plane_idx] = make_float4(ke.x, ke.y, ke.z, 1.f);
-            a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (!a.albedo_in_w) a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);  // this model folds kd into the throughput
             if (slot == a.aov_slot)
             {
                 float4 nd;
