@@ -127,6 +127,7 @@ struct RayQueue
     float4*   thr_pid;   // (throughput.xyz, asfloat(path id))
     uint32_t* count;     // kQueueClasses device counters, kCounterStride apart
     uint32_t  class_capacity;  // entries per class, a multiple of 64
+    float4*   acc;       // ShadeArgs::inline_nee only: (radiance the path has gathered since bounce 1, -), else unused
 };
 // EXT model: (o.xyz, tmin) (d.xyz, tmax) (contribution.xyz, asfloat(path id)).  Reference model (directional light, constant
 // tmin / tmax, lighting.h:39-47): (o.xyz, asfloat(path id)) in org_tmin, (contribution.xyz, -) in contrib_pid, dir_tmax unused.

@@ -54,6 +54,11 @@ struct ShadeArgs
     // untextured scene, reference shading, accumulate-only render (nobody but the resolve reads the planes): the first vertex's albedo
     // is one of four constants, so the albedo plane is not used and direct.w carries a code instead of 1 (kernels.hip shade_vertex)
     uint32_t          albedo_in_w;
+    // EXT model on the small-scene path: the next-event shadow ray is tested inside the fused kernel (same exhaustive loop as the
+    // any-hit kernel's) and the path carries its gathered radiance in the extension queue (RayQueue::acc); the colour plane is
+    // written once, when the path ends, the direct plane once at bounce 0 -- no shadow queue, no any-hit launch, no scattered
+    // read-modify-write.  The sums are the same additions in the same (bounce) order.
+    uint32_t          inline_nee;
     uint32_t          cull_camera_pairs;  // bounce 0 of the small-scene path: the camera basis is orthonormal, so a tile may skip the pairs off its screen area
 };
 // feedback: vertices of bounce >= 1 that the previous frame saw take its shaded colour and end the path (rt_indirect.hlsl:116-145;

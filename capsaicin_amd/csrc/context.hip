@@ -1088,6 +1088,8 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         if (feedback)  // g_color_history = combined_history[(frame_count + 1) % 2], raytracing_system.cpp:1754-1759
             sa.fb = FeedbackDev{camera_dev(c->prev_camera), c->post_prev_nd.p, c->post_chist[(frame_begin + 1) % 2].p};
         const bool fused = cfg.stack_entries == 0;  // small-scene path: closest hit and shading in one kernel per bounce
+        static const bool no_inline_nee = getenv("CAP_NO_INLINE_NEE") != nullptr;  // A/B switch
+        sa.inline_nee = (ext && fused && !no_inline_nee) ? 1u : 0u;
         // CAP_TRACE_LAUNCHES=1: name every launch on stderr and drain the stream after it (fault localisation only)
         static const bool trace_launches = getenv("CAP_TRACE_LAUNCHES") != nullptr;
         auto              traced         = [&](const char* what, uint32_t b) -> int {
@@ -1104,8 +1106,11 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         {
             const int pi = (int)(b & 1u), po = pi ^ 1;
             sa.bounce    = b;
-            sa.in        = RayQueue{c->q_org[pi].p, c->q_dir[pi].p, c->q_thr[pi].p, b ? ext_count + (b - 1) * per_queue : nullptr, class_capacity};
-            sa.out       = RayQueue{c->q_org[po].p, c->q_dir[po].p, c->q_thr[po].p, ext_count + b * per_queue, class_capacity};
+            // (inline_nee: no shadow entries are written, so the shadow queue's two 16-byte planes carry the paths' gathered radiance)
+            sa.in        = RayQueue{c->q_org[pi].p, c->q_dir[pi].p, c->q_thr[pi].p, b ? ext_count + (b - 1) * per_queue : nullptr, class_capacity,
+                                    pi ? c->s_dir.p : c->s_org.p};
+            sa.out       = RayQueue{c->q_org[po].p, c->q_dir[po].p, c->q_thr[po].p, ext_count + b * per_queue, class_capacity,
+                                    po ? c->s_dir.p : c->s_org.p};
             sa.shadow    = ShadowQueue{c->s_org.p, c->s_dir.p, c->s_con.p, sh_count + b * per_queue, class_capacity};
             sa.work      = work_shade + b * per_queue;
             if (fused)
@@ -1133,6 +1138,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                     ++c->stats.launches_shade;
                 }
             }
+            if (!sa.inline_nee)
             {
                 StageTimer t(c, ST_ANY, st, b == 0 ? ST_DIRECT : ST_NONE);
                 launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p,

@@ -1646,10 +1646,12 @@ __device__ __forceinline__ ExtBsdf ext_bsdf(v3 kd, v3 ks, float a2, v3 nf, v3 wo
     return r;
 }
 
-template <bool FIRST>
+// INLINE (ShadeArgs::inline_nee, fused small-scene kernels only): bvh is traced for the shadow ray here; acc = what the path has
+// gathered so far
+template <bool FIRST, bool INLINE = false>
 __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float4* shade_tab, const ShadePre& pre, uint32_t klass,
                                                  uint32_t pid, float4 hit, v3 thr,
-                                                 v3 d, uint32_t& n_shaded)
+                                                 v3 d, uint32_t& n_shaded, const BvhDev* bvh = nullptr, v3 acc = mk3(0.f, 0.f, 0.f))
 {
     const uint32_t Ppad = a.screen.pixels_padded;
     const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
@@ -1663,7 +1665,7 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
     }
     const uint32_t gid = f2u(hit.z);
     bool  emit_shadow = false, emit_ext = false;
-    v3    p = mk3(0, 0, 0), dir = mk3(0, 0, 0), contrib = mk3(0, 0, 0), sdir = mk3(0, 0, 1);
+    v3    p = mk3(0, 0, 0), dir = mk3(0, 0, 0), contrib = mk3(0, 0, 0), sdir = mk3(0, 0, 1), first_ke = mk3(0, 0, 0);
     float stmax = 0.0f;
 
     if (FIRST && !valid)
@@ -1700,8 +1702,12 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
         const v3    nf = dot3(n, wo) < 0.0f ? mk3(-n.x, -n.y, -n.z) : n;
         if (FIRST)
         {
-            a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
-            a.planes.direct[plane_idx] = make_float4(ke.x, ke.y, ke.z, 1.f);
+            first_ke = ke;
+            if (!INLINE)  // (INLINE: both written below, once the shadow ray is known / the path ends)
+            {
+                a.planes.color[plane_idx]  = make_float4(0.f, 0.f, 0.f, 1.f);
+                a.planes.direct[plane_idx] = make_float4(ke.x, ke.y, ke.z, 1.f);
+            }
             if (!a.albedo_in_w) a.planes.albedo[plane_idx] = make_float4(1.f, 1.f, 1.f, 1.f);  // this model folds kd into the throughput
             if (slot == a.aov_slot)
             {
@@ -1785,10 +1791,29 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
         }
     }
     uint32_t ei, si;
-    wave_append2(emit_ext, emit_shadow, a.out.count + klass * kCounterStride, ei, si);
+    wave_append2(emit_ext, emit_shadow, a.out.count + klass * kCounterStride, ei, si);  // (INLINE: the shadow counter still counts the rays)
     ei += klass * a.out.class_capacity;
     si += klass * a.shadow.class_capacity;
-    if (emit_shadow)
+    if (INLINE)
+    {
+        // the any-hit kernel's test and its addition, here: lanes without a shadow ray trace an empty interval
+        const Ray  sr      = make_ray(p, sdir, kRayEps, emit_shadow ? stmax : kRayEps);
+        const bool visible = emit_shadow && !exhaustive_any<false>(*bvh, sr);
+        const bool on_surface = valid && gid != kInvalidId;
+        if (FIRST)
+        {
+            if (on_surface)
+                a.planes.direct[plane_idx] = visible ? make_float4(first_ke.x + contrib.x, first_ke.y + contrib.y, first_ke.z + contrib.z, 1.f)
+                                                     : make_float4(first_ke.x, first_ke.y, first_ke.z, 1.f);
+        }
+        else if (visible)
+            acc = mk3(acc.x + contrib.x, acc.y + contrib.y, acc.z + contrib.z);
+        // the path ends here unless it continues: its colour-plane entry is written exactly once (a camera ray that left the scene
+        // wrote it above)
+        if (valid && !emit_ext && (!FIRST || on_surface)) a.planes.color[plane_idx] = make_float4(acc.x, acc.y, acc.z, 1.f);
+        if (emit_ext) a.out.acc[ei] = make_float4(acc.x, acc.y, acc.z, 0.f);
+    }
+    else if (emit_shadow)
     {
         a.shadow.org_tmin[si]    = make_float4(p.x, p.y, p.z, kRayEps);
         a.shadow.dir_tmax[si]    = make_float4(sdir.x, sdir.y, sdir.z, stmax);
@@ -1974,13 +1999,16 @@ void launch_shade(const LaunchCfg& cfg, const ShadeArgs& args, bool ext, bool fe
 #ifndef CAP_TS_FIRST
 #define CAP_TS_FIRST 5  // workgroups per CU the bounce-0 kernel is register-allocated for
 #endif
+#ifndef CAP_TS_EXT
+#define CAP_TS_EXT 6  // ... and the EXT model's bounce >= 1 kernel
+#endif
 #ifndef CAP_TS_NEXT
 #define CAP_TS_NEXT 6  // ... and the bounce >= 1 kernel (8 fits in 64 VGPRs without spills but measured 8 % slower)
 #endif
 // LDS: scenes of at most kExhaustiveMax triangles keep their shading records (96 B each) and intersection records in LDS
 // (<= 10 KB per workgroup), so the gathers by hit triangle after the loop are ds_reads instead of a global round trip.
 template <bool FIRST, bool EXT, bool FB = false, bool LDS = false>
-__global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : CAP_TS_NEXT)) void k_trace_shade(BvhDev bvh, ShadeArgs a)
+__global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : (FIRST ? CAP_TS_FIRST : CAP_TS_NEXT))) void k_trace_shade(BvhDev bvh, ShadeArgs a)
 {
     constexpr bool CARRY    = !EXT;
     const uint32_t Ppad     = a.screen.pixels_padded;
@@ -2123,7 +2151,20 @@ __global__ __launch_bounds__(kBlock, (EXT || FB) ? 4 : (FIRST ? CAP_TS_FIRST : C
             a.planes.aov_geo[i] = g;
         }
         if constexpr (EXT)
-            shade_vertex_ext<FIRST>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
+        {
+            if (a.inline_nee)  // wave-uniform
+            {
+                v3 acc = mk3(0.f, 0.f, 0.f);
+                if (!FIRST && active)
+                {
+                    const float4 q = a.in.acc[i];
+                    acc            = mk3(q.x, q.y, q.z);
+                }
+                shade_vertex_ext<FIRST, true>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded, &bvh, acc);
+            }
+            else
+                shade_vertex_ext<FIRST>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
+        }
         else
             shade_vertex<FIRST, FB, CARRY>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded, st);
         STAMP(st, 4, false);  // stores issued
