@@ -12,6 +12,7 @@ struct LaunchCfg
     uint32_t    stack_entries;  // 32 or 64 (per-lane LDS traversal stack)
     uint32_t    cu_count = 0;   // compute units (0: unknown) -- persistent kernels with a static chunk assignment clamp their grid
                                 // to what is resident at once, see resident_grid() in kernels.hip
+    uint32_t    any_no_probe = 0;  // launch_trace_any: the producer already probed (ShadeArgs::inline_probe): plain per-chunk kernel
 };
 
 // ---- trace ----
@@ -59,6 +60,12 @@ struct ShadeArgs
     // written once, when the path ends, the direct plane once at bounce 0 -- no shadow queue, no any-hit launch, no scattered
     // read-modify-write.  The sums are the same additions in the same (bounce) order.
     uint32_t          inline_nee;
+    // Reference model on the small-scene path: the fused kernel tests every shadow ray it generates against ONE fan pair -- the one
+    // farthest along the batch's first light direction, which occludes most of them -- and only queues the survivors for the any-hit
+    // kernel (which then tests every pair, without a probe of its own).  Occlusion is an OR over the pairs: same result.
+    // probe_count: where the launch adds the number of shadow rays the probe answered (they are rays of the statistics, not entries)
+    uint32_t          inline_probe;
+    uint32_t*         probe_count;
     uint32_t          cull_camera_pairs;  // bounce 0 of the small-scene path: the camera basis is orthonormal, so a tile may skip the pairs off its screen area
 };
 // feedback: vertices of bounce >= 1 that the previous frame saw take its shaded colour and end the path (rt_indirect.hlsl:116-145;

@@ -266,6 +266,12 @@ int sync_and_collect(CapContext* c)
                     c->stats.rays_extension_bounce0 += pc.first[k * kCounterStride];
                     c->stats.rays_shadow_bounce0 += pc.first[k * kCounterStride + 1];
                 }
+                if (k == 0)
+                {
+                    // shadow rays the producer's probe answered (ShadeArgs::probe_count): rays, though never queue entries
+                    c->stats.rays_shadow += pc.first[b * per + 2];
+                    if (b == 0) c->stats.rays_shadow_bounce0 += pc.first[2];
+                }
             }
         c->pinned_pool.push_back(pc.first);
     }
@@ -1090,6 +1096,13 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         const bool fused = cfg.stack_entries == 0;  // small-scene path: closest hit and shading in one kernel per bounce
         static const bool no_inline_nee = getenv("CAP_NO_INLINE_NEE") != nullptr;  // A/B switch
         sa.inline_nee = (ext && fused && !no_inline_nee) ? 1u : 0u;
+        static const bool no_inline_probe = getenv("CAP_NO_INLINE_PROBE") != nullptr;  // A/B switch
+        sa.inline_probe = (!ext && !feedback && fused && !no_inline_probe && c->tri_count <= kExhaustiveMax && bvh.fan_pair_count >= 1 &&
+                           bvh.fan_pair_count <= kExhaustiveMax / 2)
+                              ? 1u
+                              : 0u;
+        LaunchCfg cfg_any    = cfg;
+        cfg_any.any_no_probe = sa.inline_probe;
         // CAP_TRACE_LAUNCHES=1: name every launch on stderr and drain the stream after it (fault localisation only)
         static const bool trace_launches = getenv("CAP_TRACE_LAUNCHES") != nullptr;
         auto              traced         = [&](const char* what, uint32_t b) -> int {
@@ -1113,6 +1126,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                                     po ? c->s_dir.p : c->s_org.p};
             sa.shadow    = ShadowQueue{c->s_org.p, c->s_dir.p, c->s_con.p, sh_count + b * per_queue, class_capacity};
             sa.work      = work_shade + b * per_queue;
+            sa.probe_count = sh_count + b * per_queue + 1;  // word 2 of class 0's counter line of this bounce: unused by the queues
             if (fused)
             {
                 StageTimer t(c, b == 0 ? ST_PRIMARY : ST_CLOSEST, st);
@@ -1141,7 +1155,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             if (!sa.inline_nee)
             {
                 StageTimer t(c, ST_ANY, st, b == 0 ? ST_DIRECT : ST_NONE);
-                launch_trace_any(cfg, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p,
+                launch_trace_any(cfg_any, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p,
                                  work_any + b * per_queue, /* next-event estimation: most shadow rays reach the light */ ext, frames);
                 ++c->stats.launches_trace_any;
                 if (traced("trace_any", b)) return fail(CAP_ERR_HIP, "trace_any failed");

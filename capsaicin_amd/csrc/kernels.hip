@@ -1178,7 +1178,7 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
     const uint32_t pre = (cfg.stack_entries == 0 && !mostly_unoccluded) ? pre_table_bytes(n_slots, bvh.fan_pair_count) : 0u;
     static const bool     no_probe = getenv("CAP_NO_ANY_PROBE") != nullptr;  // A/B switch
     static const uint32_t probe    = getenv("CAP_ANY_PROBE") ? (uint32_t)atoi(getenv("CAP_ANY_PROBE")) : (uint32_t)CAP_ANY_PROBE;
-    if (pre != 0u && work && !no_probe && bvh.fan_pair_count <= kExhaustiveMax / 2)
+    if (pre != 0u && work && !no_probe && !cfg.any_no_probe && bvh.fan_pair_count <= kExhaustiveMax / 2)
     {
         // (3 .. 8 workgroups per CU measure the same: what is left is the planes' scattered read-modify-write traffic)
         static const uint32_t per_cu = getenv("CAP_ANY_BLOCKS") ? (uint32_t)atoi(getenv("CAP_ANY_BLOCKS")) : 6u;
@@ -1437,9 +1437,18 @@ struct Stamps
 #endif
 
 // SKY_RMW: the sky term goes to the plane by load-add-store instead of three float atomics (the stand-alone shade stage)
-template <bool FIRST, bool FB = false, bool CARRY = false, bool SKY_RMW = false>
+// Probe (ShadeArgs::inline_probe, fused small-scene kernels): probe_rows = the PairPre rows of the probe pair per frame slot (two
+// float4 each, LDS), probe_pairs = BvhDev::fan_pairs, probe_k the pair; n_probed counts the shadow rays the probe answered
+struct ProbeArgs
+{
+    const float4* rows  = nullptr;
+    const float4* pairs = nullptr;
+    uint32_t      k     = 0;
+};
+template <bool FIRST, bool FB = false, bool CARRY = false, bool SKY_RMW = false, bool PROBE = false>
 __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* shade_tab, const ShadePre& pre, uint32_t klass,
-                                             uint32_t pid, float4 hit, v3 thr, uint32_t& n_shaded, Stamps& st)
+                                             uint32_t pid, float4 hit, v3 thr, uint32_t& n_shaded, Stamps& st,
+                                             const ProbeArgs probe = ProbeArgs(), uint32_t* n_probed = nullptr)
 {
     const uint32_t Ppad = a.screen.pixels_padded;
     const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
@@ -1593,6 +1602,18 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
             }
         }
 
+        if (PROBE)
+        {
+            if (probe.rows != nullptr)  // wave-uniform
+            {
+                // lanes without a shadow ray test an empty interval's worth of nothing: their result is discarded
+                const Ray    sr  = make_ray(p, pre.L, kRayEps, kRayFar);
+                const uint32_t ps = valid ? slot : 0u;
+                const float4   pa = probe.rows[2u * ps], pb = probe.rows[2u * ps + 1u];
+                const bool   occluded = pair_occludes_pre(sr, probe.pairs, probe.k, pa, pb);
+                if (emit_shadow && occluded) emit_shadow = false, ++*n_probed;
+            }
+        }
         // a.shadow.count == a.out.count + 1: both counters of a class share one 64-bit word (one atomic per wave for both queues)
         uint32_t ei, si;
         STAMP(st, 2, true);  // shading inputs arrived + shading ALU
@@ -2020,6 +2041,12 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
     __shared__ FrameConst lds_frames[kMaxFrameSlots];
     __shared__ float4     lds_shade[LDS ? kShadeRec * kExhaustiveMax : 1];
     __shared__ float4     lds_rec[LDS ? 4 * kExhaustiveMax : 1];
+    // the producer-side shadow probe (ShadeArgs::inline_probe): the probe pair's PairPre rows per frame slot
+    constexpr bool        PROBE = !EXT && !FB && LDS;
+    __shared__ float4     lds_probe[PROBE ? 2 * kMaxFrameSlots : 1];
+    __shared__ float      lds_pscore[PROBE ? kExhaustiveMax / 2 : 1];
+    __shared__ uint32_t   lds_probe_k;
+    uint32_t              n_probed = 0;
     constexpr bool        ORG = FIRST && LDS;  // camera rays of a small scene: per-pair origin terms from a table (pair_scaled<ORG>)
     __shared__ float4     lds_org[ORG ? kExhaustiveMax : 1];
     // ORG: pixel bounds (x0, y0, x1, y1) of every fan pair as the launch's camera sees it, grown by two pixels (the sub-pixel
@@ -2061,7 +2088,44 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
             }
         }
     }
+    if (PROBE && a.inline_probe)
+    {
+        // the pair whose four vertices reach farthest along the batch's first light direction (k_trace_any_small's first probe)
+        const uint32_t np = bvh.fan_pair_count;  // 1 .. kExhaustiveMax / 2, checked by the host
+        const float*   fp = reinterpret_cast<const float*>(bvh.fan_pairs);
+        if (threadIdx.x < np)
+        {
+            const float* rec = fp + 20 * (size_t)threadIdx.x;
+            const v3     L   = mk3(a.frames[0].light_dir[0], a.frames[0].light_dir[1], a.frames[0].light_dir[2]);
+            const v3     v0  = mk3(rec[0], rec[1], rec[2]);
+            float        sc  = dot3(v0, L);
+            for (int e = 0; e < 3; ++e) sc += dot3(v0 + mk3(rec[3 + 3 * e], rec[4 + 3 * e], rec[5 + 3 * e]), L);
+            lds_pscore[threadIdx.x] = sc;
+        }
+        __syncthreads();
+        if (threadIdx.x < np)
+        {
+            const float sc   = lds_pscore[threadIdx.x];
+            uint32_t    rank = 0;
+            for (uint32_t j = 0; j < np; ++j)
+            {
+                const float o = lds_pscore[j];
+                rank += (o > sc || (o == sc && j < threadIdx.x)) ? 1u : 0u;
+            }
+            if (rank == 0) lds_probe_k = threadIdx.x;
+        }
+        __syncthreads();
+        const float* rec = fp + 20 * (size_t)lds_probe_k;
+        for (uint32_t sl = threadIdx.x; sl < a.n_slots && sl < kMaxFrameSlots; sl += kBlock)
+        {
+            const v3 d = mk3(a.frames[sl].light_dir[0], a.frames[sl].light_dir[1], a.frames[sl].light_dir[2]);
+            lds_probe[2 * sl]     = tri_pre(d, mk3(rec[12], rec[13], rec[14]), kRayEps, kRayFar);
+            lds_probe[2 * sl + 1] = tri_pre(d, mk3(rec[15], rec[16], rec[17]), kRayEps, kRayFar);
+        }
+    }
     stage_frames(a, lds_frames);  // ends with the workgroup barrier
+    ProbeArgs probe;
+    if (PROBE && a.inline_probe) probe.rows = lds_probe, probe.pairs = bvh.fan_pairs, probe.k = lds_probe_k;
     const float4* shade_tab = LDS ? lds_shade : a.scene.shade_tris;
     const float4* rec_tab   = LDS ? lds_rec : bvh.tris_by_id;
     Stamps st;
@@ -2166,7 +2230,7 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
                 shade_vertex_ext<FIRST>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
         }
         else
-            shade_vertex<FIRST, FB, CARRY>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded, st);
+            shade_vertex<FIRST, FB, CARRY, false, PROBE>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded, st, probe, &n_probed);
         STAMP(st, 4, false);  // stores issued
     }
     if (!FIRST && !EXT && !FB) st.flush();
@@ -2178,6 +2242,11 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
     }
 #endif
     flush_shaded(a.shaded_counter, n_shaded);
+    if (PROBE && a.inline_probe)
+    {
+        for (int off = 32; off > 0; off >>= 1) n_probed += __shfl_down(n_probed, off);
+        if ((threadIdx.x & 63u) == 0 && n_probed) atomicAdd(a.probe_count, n_probed);
+    }
 }
 
 #ifdef CAP_STAMPS
