@@ -993,7 +993,10 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     }
 
     const uint32_t Ppad = c->screen.pixels_padded;
-    uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)32 << 20;  // measured on the headline workload: 8 Mi 39.6 ms, 16 Mi 35.1, 32 Mi 34.7, 64 Mi 35.8 per step
+    // paths in flight per batch; measured on the headline workload (tools/batch_sweep.sh, end of round 2): 8 Mi 31.0 ms, 16 Mi 25.5,
+    // 32 Mi 22.1, 64 Mi 21.2, 128 Mi 21.1 per step -- every launch has a fixed cost (grid start, tables, tail) that fewer, larger
+    // batches amortise; 64 Mi paths are ~14 GB of queues and planes
+    uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)64 << 20;
     uint32_t       slots  = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / std::max(1u, Ppad), kMaxFrameSlots));
     slots                 = std::min(slots, n_frames);
     // No host synchronisation with the previous call: everything it still uses is either ordered behind it on the stream (queues,
