@@ -313,15 +313,16 @@ def main():
             SH_ENTRY = 32  # reference-model shadow entry: (origin, path id) + (contribution, -); see DESIGN.md "Data layout"
             if fused:
                 # k_trace_shade (bounce >= 1): reads one 48-B queue entry (ray 32 + throughput/path id 16) per extension ray,
-                # writes one 48-B extension entry and one 32-B shadow entry per ray it emits (DESIGN.md "algorithmic bytes")
+                # writes one 48-B extension entry per ray it emits and one 32-B shadow entry per shadow ray its own probe does not
+                # answer (CapStats::shadow_entries; DESIGN.md "algorithmic bytes")
                 ext_out = sp.rays_extension - sp.rays_extension_bounce0
-                sh_out = sp.rays_shadow - sp.rays_shadow_bounce0
+                sh_out = sp.shadow_entries - sp.shadow_entries_bounce0
                 kernel_bytes = 48 * sp.rays_extension + 48 * ext_out + SH_ENTRY * sh_out
                 kernel_name, key = "k_trace_shade<bounce>=1> (exhaustive closest hit + shading, fused)", "headline"
                 # + bounce-0 kernel (3 planes + its queue writes), any-hit (16-B origin read per ray, 16-B contribution read and 12 B
                 # added per unoccluded ray: counted as 16 + 12 per ray, an upper bound), resolve (48 B per path)
-                all_bytes = kernel_bytes + 48 * sp.rays_extension_bounce0 + SH_ENTRY * sp.rays_shadow_bounce0 + 48 * sp.rays_primary + \
-                    (16 + 12) * sp.rays_shadow + 48 * sp.rays_primary
+                all_bytes = kernel_bytes + 48 * sp.rays_extension_bounce0 + SH_ENTRY * sp.shadow_entries_bounce0 + 48 * sp.rays_primary + \
+                    (16 + 12) * sp.shadow_entries + 48 * sp.rays_primary
             else:
                 kernel_bytes = BYTES_CLOSEST * sp.rays_extension
                 kernel_name, key = "k_trace_closest8", "tree"
@@ -382,8 +383,9 @@ def main():
             step(capi.RENDER_EXT_MATERIALS | capi.RENDER_STAGE_TIMERS)
             fence()
             ep = r.stats()
-            # EXT entries: extension 48 B, next-event shadow entry 48 B (origin/tmin, direction/tmax, contribution/path id)
-            ebytes = 48 * ep.rays_extension + 48 * (ep.rays_extension - ep.rays_extension_bounce0) + 48 * (ep.rays_shadow - ep.rays_shadow_bounce0)
+            # EXT entries: extension 48 B + the 16 B of radiance the path has gathered (the next-event shadow ray is traced where it is
+            # generated: no shadow entries, CapStats::shadow_entries == 0), read once and written once per ray that continues
+            ebytes = 64 * ep.rays_extension + 64 * (ep.rays_extension - ep.rays_extension_bounce0) + 48 * (ep.shadow_entries - ep.shadow_entries_bounce0)
             ext_variant = {"workload": "cornell_box.obj + cornell_box.mtl %dx%d %dspp depth=%d, Lambert+GGX, emissive lamp + NEE (EXT model)" %
                                        (WIDTH, HEIGHT, args.spp, DEPTH),
                            "value": erays / edt / 1e6, "unit": "Mrays/s", "ms_per_step": edt / args.steps * 1e3,

@@ -40,7 +40,8 @@ class Stats(C.Structure):
                 ("ms_resolve", C.c_double), ("launches_trace_closest", C.c_uint64), ("launches_trace_any", C.c_uint64),
                 ("launches_shade", C.c_uint64), ("rays_extension_bounce0", C.c_uint64), ("rays_shadow_bounce0", C.c_uint64),
                 ("guard_shade", C.c_uint64), ("guard_trace_any", C.c_uint64), ("guard_last", C.c_uint64), ("ms_post", C.c_double),
-                ("post_frames", C.c_uint64), ("ms_direct", C.c_double), ("ms_post_pass", C.c_double * 5)]
+                ("post_frames", C.c_uint64), ("ms_direct", C.c_double), ("ms_post_pass", C.c_double * 5), ("shadow_entries", C.c_uint64),
+                ("shadow_entries_bounce0", C.c_uint64)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n == "ms_post_pass" else getattr(self, n)) for n, _ in self._fields_}

@@ -254,17 +254,20 @@ int sync_and_collect(CapContext* c)
     c->post_marks.clear();
     for (auto& pc : c->pending)
     {
-        const uint32_t D = pc.second;
+        const uint32_t D = pc.second & 0xffffu;
+        const bool     queued = (pc.second >> 16) == 0u;  // false: the batch's shadow rays were traced where they were generated
         const size_t per = (size_t)kQueueClasses * kCounterStride;
         for (uint32_t b = 0; b <= D; ++b)
             for (uint32_t k = 0; k < kQueueClasses; ++k)
             {
                 c->stats.rays_extension += pc.first[b * per + k * kCounterStride];
                 c->stats.rays_shadow += pc.first[b * per + k * kCounterStride + 1];
+                if (queued) c->stats.shadow_entries += pc.first[b * per + k * kCounterStride + 1];
                 if (b == 0)
                 {
                     c->stats.rays_extension_bounce0 += pc.first[k * kCounterStride];
                     c->stats.rays_shadow_bounce0 += pc.first[k * kCounterStride + 1];
+                    if (queued) c->stats.shadow_entries_bounce0 += pc.first[k * kCounterStride + 1];
                 }
                 if (k == 0)
                 {
@@ -1188,7 +1191,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         else
             HIP_TRY(hipHostMalloc((void**)&pinned, sizeof(uint32_t) * 2 * 256 * kQueueClasses * kCounterStride, hipHostMallocDefault));
         HIP_TRY(hipMemcpyAsync(pinned, c->counters.p, sizeof(uint32_t) * counter_words, hipMemcpyDeviceToHost, c->stream));
-        c->pending.push_back({pinned, D});
+        c->pending.push_back({pinned, D | (sa.inline_nee ? 1u << 16 : 0u)});
         HIP_TRY(hipGetLastError());
 
         // primary rays: one per valid pixel per frame

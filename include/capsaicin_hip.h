@@ -128,6 +128,11 @@ typedef struct CapStats
     double   ms_direct;       /* "RT Direct lighting": shading of the camera vertex + its shadow rays (part of ms_primary on the fused
                                  small-scene path, of ms_shade / ms_trace_any otherwise; CAP_RENDER_STAGE_TIMERS) */
     double   ms_post_pass[5]; /* "Spatial gather", "Temporal upscale", "EAW", "Combine illumination", "TAA" (sum = ms_post) */
+    /* Shadow rays that travelled through the shadow queue to an any-hit launch.  rays_shadow counts every shadow ray traced; on the
+     * small-scene path the kernel that generates a shadow ray answers it itself when it can (reference model: a probe against the
+     * most likely occluder; EXT model: the whole test), and only the rest become queue entries. */
+    uint64_t shadow_entries;
+    uint64_t shadow_entries_bounce0;
 } CapStats;
 
 typedef struct CapBvhInfo
