@@ -66,8 +66,11 @@ def test_ext_cornell_parity(native_lib, bluenoise, tmp_path, ggx):
     r.set_traversal(0)
     r.set_batch_paths(2 * w * h)
     r.accum_reset()
+    r.stats_reset()
     r.render(0, 6, D, capi.RENDER_EXT_MATERIALS)
     assert np.array_equal(bits(r.readback(capi.BUF_ACCUM_SUM)[..., :3]), bits(acc[..., :3]))
+    s = r.stats()  # AUTO = the small-scene kernels: the next-event rays are traced where they are generated, none is queued
+    assert (s.rays_primary, s.rays_extension, s.rays_shadow) == rays and s.shadow_entries == 0 and s.launches_trace_any == 0
     r.close()
 
 

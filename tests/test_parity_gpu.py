@@ -113,6 +113,10 @@ def test_accumulate_only_render_equals_aov_render(cornell, bluenoise, traversal)
     r.set_traversal(0)
     assert out[0][1] == out[1][1]
     assert_same(out[0][0], out[1][0], "accumulate-only vs AOV render, traversal %d" % traversal)
+    # every shadow ray is counted; on the small-scene path most never become queue entries (the producer's probe answers them)
+    assert 0 < s.shadow_entries <= s.rays_shadow and s.shadow_entries_bounce0 <= s.rays_shadow_bounce0
+    if traversal == 2:
+        assert s.shadow_entries < s.rays_shadow // 2
     assert float(out[0][0][..., :3].max()) > 0.0
 
 
