@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 64, 8
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.3 TB/s is the measured achievable stream rate
+TREE_SPP = 32  # frames per step of the tree-path variant = one batch (tools/tree_trace.sh and tree_pmc.sh profile the same)
 BYTES_CLOSEST, BYTES_ANY, BYTES_VERTEX = 48, 36, 144  # SURVEY.md 8d algorithmic queue-stream bytes per ray / shaded vertex
 # vector-instruction issue peak: one wave64 instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0
@@ -397,7 +398,8 @@ def main():
                            "stage_ms": {"primary": ep.ms_primary, "trace_closest": ep.ms_trace_closest, "trace_any": ep.ms_trace_any,
                                         "resolve": ep.ms_resolve, "total": ep.ms_total}}
 
-        # the general path (tree traversal, textures) on the BASELINE configs[3] stand-in, 16 spp: extra line, N = 1 only.
+        # the general path (tree traversal, textures) on the BASELINE configs[3] stand-in, TREE_SPP spp per step (one batch of the
+        # default size: configs[3]'s 128 spp are four of them): extra line, N = 1 only.
         # These are the BVH-traversal-bound frames of the north star: its roofline object is for the closest-hit kernel.
         tree_variant = None
         if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant:
@@ -408,20 +410,20 @@ def main():
                 bi2 = r2.build_bvh()
                 r2.set_resolution(WIDTH, HEIGHT)
                 r2.set_camera(cam2)
-                r2.render(0, 16, DEPTH, 0)
+                r2.render(0, TREE_SPP, DEPTH, 0)
                 r2.sync()
                 r2.stats_reset()
                 t0 = time.perf_counter()
                 for _ in range(2):
                     r2.accum_reset()
-                    r2.render(0, 16, DEPTH, 0)
+                    r2.render(0, TREE_SPP, DEPTH, 0)
                 r2.sync()
                 tdt = time.perf_counter() - t0
                 ts = r2.stats()
                 trays = ts.rays_primary + ts.rays_extension + ts.rays_shadow
                 r2.stats_reset()
                 r2.accum_reset()
-                r2.render(0, 16, DEPTH, capi.RENDER_STAGE_TIMERS)
+                r2.render(0, TREE_SPP, DEPTH, capi.RENDER_STAGE_TIMERS)
                 r2.sync()
                 tp = r2.stats()
                 # (A) queue stream: 32-B ray read + 16-B hit written per ray; (B) traversal bytes per ray = nodes
@@ -452,8 +454,8 @@ def main():
                          "traffic_source": ssrc, "avg_launch_ms": shade_ms / shade_launches, "launches": int(shade_launches),
                          "bytes_per_vertex": BYTES_VERTEX, "vertices_per_step": int(shade_vertices)}
                 sroof["frac"] = sroof["achieved"] / HBM_PEAK_GBS
-                tree_variant = {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d 16spp depth=%d, reference shading" %
-                                            (bi2.triangle_count, WIDTH, HEIGHT, DEPTH),
+                tree_variant = {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d %dspp depth=%d, reference shading" %
+                                            (bi2.triangle_count, WIDTH, HEIGHT, TREE_SPP, DEPTH),
                                 "value": trays / tdt / 1e6, "unit": "Mrays/s", "ms_per_step": tdt / 2 * 1e3,
                                 "bvh": {"build": "device PLOC + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
                                 "roofline": troof, "shade_roofline": sroof,

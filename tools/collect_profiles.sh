@@ -11,7 +11,7 @@ python tools/make_traffic.py "$TAG" gpurun_out/w8_counts.json > /dev/null
 python tools/prof_summary.py > "profiles/${TAG}_rocprofv3_summary.txt" 2>&1
 cp "$(ls -t gpurun_out/prof_kt/*/*kernel_stats.csv | head -1)" "profiles/${TAG}_kernel_stats.csv"
 {
-    echo "# tools/tree_trace.sh: per-launch durations, one batch (16 spp) of the 262 k-triangle scene"
+    echo "# tools/tree_trace.sh: per-launch durations, one batch (32 spp) of the 262 k-triangle scene"
     cat gpurun_out/tree_trace.txt
     echo
     echo "# tools/tree_pmc.sh passes (same command, counters summed over the dispatches of the run)"

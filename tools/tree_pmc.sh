@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_tree_pmc
-timeout -k 5 200 rocprofv3 --pmc $1 --output-format csv -d $OUT/prof_tree_pmc -- python3 $ROOT/bench.py --scene sponza --spp 16 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_tree_pmc.log 2>&1 || { tail -5 $OUT/prof_tree_pmc.log; exit 1; }
+timeout -k 5 200 rocprofv3 --pmc $1 --output-format csv -d $OUT/prof_tree_pmc -- python3 $ROOT/bench.py --scene sponza --spp 32 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_tree_pmc.log 2>&1 || { tail -5 $OUT/prof_tree_pmc.log; exit 1; }
 python3 - <<PY
 import csv, glob, re, collections
 f = glob.glob("$OUT/prof_tree_pmc/**/*counter_collection.csv", recursive=True)[0]

@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_tree
-timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_tree -- python3 $ROOT/bench.py --scene sponza --spp 16 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_tree.log 2>&1 || exit 1
+timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_tree -- python3 $ROOT/bench.py --scene sponza --spp 32 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/prof_tree.log 2>&1 || exit 1
 python3 - <<PY
 import csv, glob, re
 f = glob.glob("$OUT/prof_tree/**/*kernel_trace.csv", recursive=True)[0]
