@@ -66,6 +66,9 @@ struct ShadeArgs
     // probe_count: where the launch adds the number of shadow rays the probe answered (they are rays of the statistics, not entries)
     uint32_t          inline_probe;
     uint32_t*         probe_count;
+    // ... and from bounce 1 on the survivors are traced by the wave that found them (k_trace_shade's per-wave ring): the only
+    // any-hit launch left on the small-scene path is bounce 0's
+    uint32_t          wave_ring;
     uint32_t          cull_camera_pairs;  // bounce 0 of the small-scene path: the camera basis is orthonormal, so a tile may skip the pairs off its screen area
 };
 // feedback: vertices of bounce >= 1 that the previous frame saw take its shaded colour and end the path (rt_indirect.hlsl:116-145;

@@ -422,9 +422,12 @@ int ensure_wavefront(CapContext* c, uint32_t slots, uint32_t bounces)
         HIP_TRY(c->q_dir[k].ensure(np));
         HIP_TRY(c->q_thr[k].ensure(np));
     }
-    HIP_TRY(c->s_org.ensure(np));
+    // the shadow queue's memory also holds the fused kernels' per-wave survivor rings (ShadeArgs::wave_ring): 128 entries for
+    // every wave of the largest persistent grid (8 workgroups per CU)
+    const size_t ring_np = (size_t)std::max(c->cu_count, 1) * 8 * (kBlock / 64) * 128;
+    HIP_TRY(c->s_org.ensure(std::max(np, ring_np)));
     HIP_TRY(c->s_dir.ensure(np));
-    HIP_TRY(c->s_con.ensure(np));
+    HIP_TRY(c->s_con.ensure(std::max(np, ring_np)));
     HIP_TRY(c->pl_color.ensure(planes_np));
     HIP_TRY(c->pl_direct.ensure(planes_np));
     HIP_TRY(c->pl_albedo.ensure(planes_np));
@@ -1107,6 +1110,8 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                            bvh.fan_pair_count <= kExhaustiveMax / 2)
                               ? 1u
                               : 0u;
+        static const bool no_wave_ring = getenv("CAP_NO_WAVE_RING") != nullptr;  // A/B switch
+        sa.wave_ring = (sa.inline_probe && !no_wave_ring && (size_t)cfg.grid_blocks * (kBlock / 64) * 128 <= std::min(c->s_org.n, c->s_con.n)) ? 1u : 0u;  // (a grid beyond what ensure_wavefront sized the rings for: CAP_BLOCKS_PER_CU)
         LaunchCfg cfg_any    = cfg;
         cfg_any.any_no_probe = sa.inline_probe;
         // CAP_TRACE_LAUNCHES=1: name every launch on stderr and drain the stream after it (fault localisation only)
@@ -1158,7 +1163,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                     ++c->stats.launches_shade;
                 }
             }
-            if (!sa.inline_nee)
+            if (!sa.inline_nee && !(fused && sa.wave_ring && b != 0))
             {
                 StageTimer t(c, ST_ANY, st, b == 0 ? ST_DIRECT : ST_NONE);
                 launch_trace_any(cfg_any, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p,

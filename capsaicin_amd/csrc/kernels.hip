@@ -1439,16 +1439,23 @@ struct Stamps
 // SKY_RMW: the sky term goes to the plane by load-add-store instead of three float atomics (the stand-alone shade stage)
 // Probe (ShadeArgs::inline_probe, fused small-scene kernels): probe_rows = the PairPre rows of the probe pair per frame slot (two
 // float4 each, LDS), probe_pairs = BvhDev::fan_pairs, probe_k the pair; n_probed counts the shadow rays the probe answered
+// Ring (ShadeArgs::wave_ring): the survivors of the probe are not queued for another launch but parked in a ring of 128 entries
+// that belongs to this wave alone (ring_org / ring_con: its slice of the shadow queue's memory); the kernel traces them 64 at a
+// time itself (k_trace_shade trace_ring).  ring_head / ring_n are wave-uniform.
 struct ProbeArgs
 {
     const float4* rows  = nullptr;
     const float4* pairs = nullptr;
     uint32_t      k     = 0;
+    float4*       ring_org = nullptr;
+    float4*       ring_con = nullptr;
 };
+constexpr uint32_t kWaveRing = 128;  // <= 63 parked + <= 64 new
 template <bool FIRST, bool FB = false, bool CARRY = false, bool SKY_RMW = false, bool PROBE = false>
 __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* shade_tab, const ShadePre& pre, uint32_t klass,
                                              uint32_t pid, float4 hit, v3 thr, uint32_t& n_shaded, Stamps& st,
-                                             const ProbeArgs probe = ProbeArgs(), uint32_t* n_probed = nullptr)
+                                             const ProbeArgs probe = ProbeArgs(), uint32_t* n_probed = nullptr, uint32_t ring_head = 0,
+                                             uint32_t* ring_n = nullptr)
 {
     const uint32_t Ppad = a.screen.pixels_padded;
     const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
@@ -1621,7 +1628,20 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
         STAMP(st, 3, true);  // append atomic returned
         ei += klass * a.out.class_capacity;
         si += klass * a.shadow.class_capacity;
-        if (emit_shadow)
+        if (PROBE && probe.ring_org != nullptr)  // wave-uniform
+        {
+            // the entry goes to this wave's own ring (the counter above still counted it: CapStats::shadow_entries)
+            const unsigned long long ms = __ballot(emit_shadow);
+            if (emit_shadow)
+            {
+                const uint32_t lane_ = threadIdx.x & 63u;
+                const uint32_t pos   = (ring_head + *ring_n + (uint32_t)__popcll(ms & ((1ull << lane_) - 1ull))) & (kWaveRing - 1u);
+                probe.ring_org[pos]  = make_float4(p.x, p.y, p.z, u2f(pid));
+                probe.ring_con[pos]  = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+            }
+            *ring_n += (uint32_t)__popcll(ms);
+        }
+        else if (emit_shadow)
         {
             // reference model: the shadow ray's direction is its frame's light and tmin / tmax are constants (lighting.h:39-47), so
             // the entry is 32 B -- (origin, path id) and the contribution; the any-hit kernel looks the direction up by frame slot
@@ -2046,6 +2066,7 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
     __shared__ float4     lds_probe[PROBE ? 2 * kMaxFrameSlots : 1];
     __shared__ float      lds_pscore[PROBE ? kExhaustiveMax / 2 : 1];
     __shared__ uint32_t   lds_probe_k;
+    __shared__ float4     lds_ring[(PROBE && !FIRST) ? (kBlock / 64) * kWaveRing : 1];  // per wave: (origin, path id) of its parked shadow rays
     uint32_t              n_probed = 0;
     constexpr bool        ORG = FIRST && LDS;  // camera rays of a small scene: per-pair origin terms from a table (pair_scaled<ORG>)
     __shared__ float4     lds_org[ORG ? kExhaustiveMax : 1];
@@ -2126,6 +2147,38 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
     stage_frames(a, lds_frames);  // ends with the workgroup barrier
     ProbeArgs probe;
     if (PROBE && a.inline_probe) probe.rows = lds_probe, probe.pairs = bvh.fan_pairs, probe.k = lds_probe_k;
+    // The probe's survivors stay with the wave that found them (ShadeArgs::wave_ring): parked in its own 128-entry ring and traced
+    // 64 at a time between chunks -- the any-hit kernel's loop on full waves, without its launch, its queue round trip, or any
+    // other wave.  No plane entry is shared: within one launch a path either escapes (sky term) or has a vertex (this shadow
+    // ray), and the previous bounce's additions were made by the previous launch.
+    uint32_t ring_head = 0, ring_n = 0;  // wave-uniform
+    if (PROBE && !FIRST && a.inline_probe && a.wave_ring)  // (bounce 0: more survivors per chunk, and a kernel short of registers: 2.4 -> 2.9 ms for the 0.35 ms of its any-hit launch)
+    {
+        probe.ring_org = lds_ring + (threadIdx.x >> 6) * kWaveRing;  // origins + path ids in LDS, the contributions in this wave's
+        probe.ring_con = a.shadow.contrib_pid + (size_t)wave_global_id() * kWaveRing;  // slice of the shadow queue's memory
+    }
+    auto trace_ring = [&](uint32_t count) {
+        const uint32_t lane_ = threadIdx.x & 63u;
+        const bool     on    = lane_ < count;
+        const uint32_t pos   = (ring_head + lane_) & (kWaveRing - 1u);
+        float4         o     = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) o = probe.ring_org[pos];
+        const uint32_t spid = f2u(o.w);
+        const bool     good = on && (spid >> kPidShift) < a.n_slots && (spid & kPidMask) < Ppad;
+        const FrameConst& fc = lds_frames[good ? (spid >> kPidShift) : 0u];
+        const Ray  sr = make_ray(mk3(o.x, o.y, o.z), mk3(fc.light_dir[0], fc.light_dir[1], fc.light_dir[2]), kRayEps, good ? kRayFar : kRayEps);
+        // what the probe left over is mostly unoccluded, and the path id came out of LDS: the contribution and the plane entry are
+        // requested before the test and arrive under it
+        float4* const target = a.bounce == 0 ? a.planes.direct : a.planes.color;
+        const size_t  idx    = good ? (size_t)(spid >> kPidShift) * Ppad + (spid & kPidMask) : 0;
+        float4        c = make_float4(0.f, 0.f, 0.f, 0.f), cur = c;
+        if (good) c = probe.ring_con[pos], cur = target[idx];
+        const bool occluded = exhaustive_any<false>(bvh, sr);
+        // lighting.h:57-60: unoccluded -> the contribution evaluated at shading time is added
+        if (good && !occluded) target[idx] = make_float4(cur.x + c.x, cur.y + c.y, cur.z + c.z, cur.w);
+        ring_head = (ring_head + count) & (kWaveRing - 1u);
+        ring_n -= count;
+    };
     const float4* shade_tab = LDS ? lds_shade : a.scene.shade_tris;
     const float4* rec_tab   = LDS ? lds_rec : bvh.tris_by_id;
     Stamps st;
@@ -2230,7 +2283,11 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
                 shade_vertex_ext<FIRST>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
         }
         else
-            shade_vertex<FIRST, FB, CARRY, false, PROBE>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded, st, probe, &n_probed);
+        {
+            shade_vertex<FIRST, FB, CARRY, false, PROBE>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, n_shaded, st, probe, &n_probed,
+                                                         ring_head, &ring_n);
+            if (PROBE && ring_n >= 64u) trace_ring(64u);
+        }
         STAMP(st, 4, false);  // stores issued
     }
     if (!FIRST && !EXT && !FB) st.flush();
@@ -2241,6 +2298,7 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
         g_wave_times[2 * wave_global_id() + 1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+    if (PROBE && ring_n != 0u) trace_ring(ring_n);  // what is left in this wave's ring
     flush_shaded(a.shaded_counter, n_shaded);
     if (PROBE && a.inline_probe)
     {
