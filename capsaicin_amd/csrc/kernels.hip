@@ -2158,6 +2158,7 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
         probe.ring_con = a.shadow.contrib_pid + (size_t)wave_global_id() * kWaveRing;  // slice of the shadow queue's memory
     }
     auto trace_ring = [&](uint32_t count) {
+        __builtin_amdgcn_wave_barrier();  // the ring entries other lanes of this wave stored come before the reads below
         const uint32_t lane_ = threadIdx.x & 63u;
         const bool     on    = lane_ < count;
         const uint32_t pos   = (ring_head + lane_) & (kWaveRing - 1u);
