@@ -26,16 +26,17 @@ TREE_SPP = 32  # frames per step of the tree-path variant = one batch (tools/tre
 BYTES_CLOSEST, BYTES_ANY, BYTES_VERTEX = 48, 36, 144  # SURVEY.md 8d algorithmic queue-stream bytes per ray / shaded vertex
 # vector-instruction issue peak: one wave64 instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0
-KERNEL_SOURCES = ("kernels.hip", "trace8.hip", "cap_trace.h", "cap_wide_trace.h", "cap_device.h", "cap_math.h", "context.hip",
-                  "wide_builder.cpp", "sah_builder.cpp")
-
-
 def kernel_source_sha():
-    """Hash of the sources the profiled kernels are built from: committed counter files are only quoted while it matches."""
+    """Hash of everything the profiled kernels and the trees they walk are built from -- every .hip / .h / .cpp of csrc and the
+    Makefile with its flags (a builder or a layout change moves traversal bytes just as a kernel change does): committed counter
+    files are only quoted while it matches."""
     import hashlib
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "capsaicin_amd", "csrc", f), "rb").read())
+    d = os.path.join(ROOT, "capsaicin_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
 
 
@@ -214,44 +215,69 @@ def main():
         # every rank uses torch.distributed, and the JSON line says which.
         exchange = "none" if world == 1 else "torch.distributed.gather"
         if world > 1 and backend == "nccl":
-            ok = torch.zeros(1, dtype=torch.int32, device="cuda")
+            # Agreement between the ranks travels over a gloo side group, on host memory: it does not queue behind a collective
+            # that one rank entered and another did not, which is exactly the situation it has to detect (a rank that
+            # raised inside the try skipped dist.gather while its peers waited in it).
+            ctl = dist.new_group(backend="gloo")
+
+            def agree(flag):
+                t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=ctl)
+                return bool(t.item())
+
+            def attempt(what, fn):
+                try:
+                    fn()
+                    return True
+                except capi.CapError as exc:
+                    sys.stderr.write("[bench] rank %d: %s failed: %s\n" % (rank, what, exc))
+                    return False
+
             try:
                 ids = [capi.comm_unique_id() if rank == 0 else None]
             except capi.CapError:
                 ids = [None]
             dist.broadcast_object_list(ids, src=0)
-            if ids[0] is not None:
-                # every rank must have its communicator before any rank enters the gather (a rank that failed would leave the
-                # others waiting in ncclGather): agree on the minimum of the ranks' results first
-                inited = torch.ones(1, dtype=torch.int32, device="cuda")
-                try:
-                    r.comm_init_rank(ids[0], rank, world)
-                except capi.CapError as exc:
-                    inited[0] = 0
-                    sys.stderr.write("[bench] rank %d: cap_comm_init_rank failed: %s\n" % (rank, exc))
-                dist.all_reduce(inited, op=dist.ReduceOp.MIN)
-                if int(inited.item()) == 1:
-                    try:
-                        r.accum_reset()
-                        r.render(0, 1, DEPTH, 0)
-                        r.comm_gather_frame()
-                        r.resolve_tiles(tile_buf.data_ptr())
-                        r.sync()
-                        torch.cuda.synchronize()
-                        dist.gather(tile_buf, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
-                        if rank == 0:
+            use_cap = ids[0] is not None
+            # every rank must have its communicator before any rank enters the gather
+            use_cap = use_cap and agree(attempt("cap_comm_init_rank", lambda: r.comm_init_rank(ids[0], rank, world)))
+            if use_cap:
+                # 1. the local render (no collective): agree before anybody enters one
+                def local():
+                    r.accum_reset()
+                    r.render(0, 1, DEPTH, 0)
+                    r.sync()
+                use_cap = agree(attempt("render", local))
+            if use_cap:
+                # 2. the C-ABI gather: only queued here; a rank that could not queue it tells the others, who then give their
+                #    communicator up without waiting for the stream (cap_comm_abort) instead of hanging in cap_sync
+                queued = agree(attempt("cap_comm_gather_frame", r.comm_gather_frame))
+                if not queued:
+                    attempt("cap_comm_abort", r.comm_abort)
+                    use_cap = False
+            if use_cap:
+                # 3. the same tiles through torch.distributed, compared on rank 0 with what the C ABI assembled
+                staged = agree(attempt("cap_resolve_tiles", lambda: (r.resolve_tiles(tile_buf.data_ptr()), r.sync())))
+                same = False
+                if staged:
+                    torch.cuda.synchronize()
+                    dist.gather(tile_buf, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+                    if rank == 0:
+                        def compare():
+                            nonlocal same
                             r.assemble_tiles(gathered.data_ptr(), world, image.data_ptr())
                             r.sync()
                             torch.cuda.synchronize()
                             a = r.comm_readback().reshape(-1)
-                            ok[0] = int(np.array_equal(a.view(np.uint32), image.cpu().numpy().view(np.uint32)))
-                    except capi.CapError as exc:
-                        sys.stderr.write("[bench] rank %d: cap_comm path unavailable: %s\n" % (rank, exc))
-                    dist.broadcast(ok, src=0)
-                    if int(ok.item()) == 1:
-                        exchange = "cap_comm_gather_frame (ncclGather, C ABI)"
-                if not exchange.startswith("cap_comm"):
-                    r.comm_destroy()
+                            same = bool(np.array_equal(a.view(np.uint32), image.cpu().numpy().view(np.uint32)))
+                        attempt("assemble / compare", compare)
+                    else:
+                        same = True
+                use_cap = agree(staged and same)
+            if use_cap:
+                exchange = "cap_comm_gather_frame (ncclGather, C ABI)"
+            elif ids[0] is not None:
+                attempt("cap_comm_destroy", r.comm_destroy)
 
         def step(flags=0):
             r.accum_reset()

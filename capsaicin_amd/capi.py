@@ -129,6 +129,7 @@ SYMBOLS = {
     "cap_comm_readback": (_i, [_vp, _vp]),
     "cap_comm_info": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32), C.POINTER(_u32)]),
     "cap_comm_destroy": (_i, [_vp]),
+    "cap_comm_abort": (_i, [_vp]),
     "cap_image_decode": (_i, [_vp, C.c_size_t, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_u32), C.POINTER(_u32)]),
     "cap_image_free": (None, [_vp]),
     "cap_host_sah_build": (_i, [_vp, _u32, _vp, _vp, C.POINTER(_u32)]),
@@ -500,3 +501,6 @@ class Renderer:
 
     def comm_destroy(self):
         _check(lib().cap_comm_destroy(self.ctx), "cap_comm_destroy")
+
+    def comm_abort(self):
+        _check(lib().cap_comm_abort(self.ctx), "cap_comm_abort")

@@ -81,6 +81,15 @@ __device__ __forceinline__ bool tri_occludes(const Ray& r, const float4 t0, cons
 // chunk is past the end leaves at once, so the grid always drains.
 __device__ __forceinline__ uint32_t wave_global_id() { return blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); }
 __device__ __forceinline__ uint32_t wave_total() { return gridDim.x * (kBlock / 64); }
+// Cross-lane hand-off inside ONE wave through LDS or global memory (per-wave rings and ray buffers): what the writers stored
+// before it is visible to the readers after it.  Wavefront-scope release + acquire (no instructions on gfx950: a wave's LDS and
+// vector-memory operations retire in issue order) plus a scheduling barrier; the fences are what binds the compiler.
+__device__ __forceinline__ void wave_handoff()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Dynamic chunk distribution.  A wave works on the chunk slots of ONE class (its index mod kQueueClasses) and takes them in order
 // from that class's work counter (64 counters on their own 128-B lines, zeroed per launch; <= 5 grabs per microsecond each).

@@ -13,10 +13,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <exception>
 #include <vector>
 
 namespace
 {
+// largest image the decoders allocate for: 64 Mi pixels (256 MB of RGBA8) -- sizes come from the file's header, before any data
+constexpr uint64_t kMaxPixels = 1ull << 26;
+
 typedef std::vector<uint8_t> Bytes;
 
 // ---------------------------------------------------------------- inflate (RFC 1950 / 1951)
@@ -88,7 +92,8 @@ struct Huffman
     }
 };
 
-bool inflate_blocks(BitReader& br, Bytes* out)
+// `limit`: the caller knows how many bytes the stream may produce (PNG: (stride + 1) * height); one byte more is a bomb or damage
+bool inflate_blocks(BitReader& br, Bytes* out, size_t limit)
 {
     static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint16_t lext[29]  = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -107,6 +112,7 @@ bool inflate_blocks(BitReader& br, Bytes* out)
             const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
             br.pos += 4;
             if ((len ^ 0xffffu) != nlen || br.pos + len > br.n) return false;
+            if (out->size() + len > limit) return false;
             out->insert(out->end(), br.p + br.pos, br.p + br.pos + len);
             br.pos += len;
             continue;
@@ -167,7 +173,10 @@ bool inflate_blocks(BitReader& br, Bytes* out)
             const int sym = lit.decode(br);
             if (sym < 0) return false;
             if (sym < 256)
+            {
+                if (out->size() >= limit) return false;
                 out->push_back((uint8_t)sym);
+            }
             else if (sym == 256)
                 break;
             else
@@ -178,7 +187,7 @@ bool inflate_blocks(BitReader& br, Bytes* out)
                 const int ds  = dist.decode(br);
                 if (ds < 0 || ds >= 30) return false;
                 const size_t d = dbase[ds] + br.get(dext[ds]);
-                if (br.fail || d > out->size()) return false;
+                if (br.fail || d > out->size() || out->size() + (size_t)len > limit) return false;
                 const size_t from = out->size() - d;
                 for (int k = 0; k < len; ++k) out->push_back((*out)[from + k]);
             }
@@ -187,11 +196,11 @@ bool inflate_blocks(BitReader& br, Bytes* out)
     return true;
 }
 
-bool zlib_inflate(const uint8_t* p, size_t n, Bytes* out)
+bool zlib_inflate(const uint8_t* p, size_t n, Bytes* out, size_t limit)
 {
     if (n < 6 || (p[0] & 0x0f) != 8 || ((p[0] << 8) | p[1]) % 31 != 0 || (p[1] & 0x20)) return false;
     BitReader br{p + 2, n - 2};
-    return inflate_blocks(br, out);  // the Adler-32 trailer is not checked: a damaged file fails the size / filter checks below
+    return inflate_blocks(br, out, limit);  // the Adler-32 trailer is not checked: a damaged file fails the size / filter checks below
 }
 
 // ---------------------------------------------------------------- PNG
@@ -229,7 +238,7 @@ bool decode_png(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
             end = true;
         pos += 12 + (size_t)len;
     }
-    if (!have_ihdr || !W || !H || W > 32768 || H > 32768 || interlace != 0) return false;
+    if (!have_ihdr || !W || !H || W > 32768 || H > 32768 || (uint64_t)W * H > kMaxPixels || interlace != 0) return false;
     int channels;
     switch (ctype)
     {
@@ -245,7 +254,7 @@ bool decode_png(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
     const size_t bpp_bits = (size_t)channels * depth, stride = (W * bpp_bits + 7) / 8, bpp = (bpp_bits + 7) / 8;
     Bytes        raw;
     raw.reserve((stride + 1) * H);
-    if (!zlib_inflate(idat.data(), idat.size(), &raw) || raw.size() < (stride + 1) * H) return false;
+    if (!zlib_inflate(idat.data(), idat.size(), &raw, (stride + 1) * H) || raw.size() < (stride + 1) * H) return false;
     // un-filter in place (PNG spec 9.2): a = left, b = up, c = upper left
     Bytes prev(stride, 0);
     for (uint32_t y = 0; y < H; ++y)
@@ -329,7 +338,10 @@ bool decode_tga(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
     const int      bits = d[16], desc = d[17];
     const bool     rle = type == 9 || type == 10 || type == 11;
     const int      base = rle ? type - 8 : type;
-    if (!(base == 1 || base == 2 || base == 3) || !W || !H) return false;
+    if (!(base == 1 || base == 2 || base == 3) || !W || !H || (uint64_t)W * H > kMaxPixels) return false;
+    // colour-map entries are expanded like pixels: only the depths expand() knows (anything else was read as 16 bits: wrong
+    // colours and a 1-byte over-read for an 8-bit map)
+    if (cmap_type == 1 && base == 1 && !(cmap_bits == 15 || cmap_bits == 16 || cmap_bits == 24 || cmap_bits == 32)) return false;
     if (base == 1 && (cmap_type != 1 || bits != 8)) return false;
     if (base == 2 && !(bits == 15 || bits == 16 || bits == 24 || bits == 32)) return false;
     if (base == 3 && !(bits == 8 || bits == 16)) return false;
@@ -424,7 +436,7 @@ bool decode_ppm(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
     };
     if (token() != "P6") return false;
     const long W = std::atol(token().c_str()), H = std::atol(token().c_str()), M = std::atol(token().c_str());
-    if (W <= 0 || H <= 0 || M != 255) return false;
+    if (W <= 0 || H <= 0 || M != 255 || W > 32768 || H > 32768 || (uint64_t)W * (uint64_t)H > kMaxPixels) return false;
     ++pos;  // single whitespace after maxval
     if (d.size() < pos + (size_t)W * H * 3) return false;
     rgba->resize((size_t)W * H * 4);
@@ -450,10 +462,13 @@ extern "C" int cap_image_decode(const uint8_t* bytes, size_t size, const char* n
         cap_set_error_("cap_image_decode: NULL argument");
         return CAP_ERR_INVALID_ARG;
     }
+    Bytes    rgba;
+    uint32_t w = 0, h = 0;
+    bool     ok = false;
+    try  // no exception crosses the C ABI: a header that asks for more memory than there is ends as a status, not std::terminate
+    {
     const Bytes d(bytes, bytes + size);
-    Bytes       rgba;
-    uint32_t    w = 0, h = 0;
-    bool        ok = decode_png(d, &rgba, &w, &h) || decode_ppm(d, &rgba, &w, &h);
+    ok = decode_png(d, &rgba, &w, &h) || decode_ppm(d, &rgba, &w, &h);
     if (!ok)
     {
         // TGA has no signature: only tried for a .tga name, or as a last resort without a name
@@ -461,6 +476,12 @@ extern "C" int cap_image_decode(const uint8_t* bytes, size_t size, const char* n
         for (auto& c : n) c = (char)std::tolower((unsigned char)c);
         const bool tga_name = n.size() >= 4 && n.compare(n.size() - 4, 4, ".tga") == 0;
         if (tga_name || n.empty()) ok = decode_tga(d, &rgba, &w, &h);
+    }
+    }
+    catch (const std::exception&)
+    {
+        cap_set_error_("cap_image_decode: out of memory");
+        return CAP_ERR_IO;
     }
     if (!ok)
     {

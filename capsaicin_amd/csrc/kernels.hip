@@ -910,12 +910,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_any_small(BvhDev bvh, ShadowQu
             surv_i[at] = i;
         }
         surv_n += (uint32_t)__popcll(m);
-        __builtin_amdgcn_wave_barrier();
+        wave_handoff();
         if (surv_n >= 64u)
         {
             surv_n -= 64u;
             finish(surv_n, 64u);
-            __builtin_amdgcn_wave_barrier();
+            wave_handoff();
         }
     }
     if (surv_n) finish(0u, surv_n);
@@ -1640,6 +1640,10 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
                 probe.ring_con[pos]  = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
             }
             *ring_n += (uint32_t)__popcll(ms);
+            // the entries are read by OTHER lanes of this wave (trace_ring): wavefront-scope release here, acquire there.  No code on
+            // gfx950 (same-wave LDS and vector-memory operations retire in issue order), but it is what forbids the compiler to move
+            // the stores below the loads -- ordering that until round 3 rested on a scheduling barrier alone.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
         else if (emit_shadow)
         {
@@ -2158,7 +2162,11 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
         probe.ring_con = a.shadow.contrib_pid + (size_t)wave_global_id() * kWaveRing;  // slice of the shadow queue's memory
     }
     auto trace_ring = [&](uint32_t count) {
-        __builtin_amdgcn_wave_barrier();  // the ring entries other lanes of this wave stored come before the reads below
+        // The ring is a cross-lane hand-off inside one wave: lane i stored entry `pos` (LDS origin, global contribution), lane j
+        // loads it here.  Commit 6a9000f put a scheduling barrier here after reading the ISA, not after a failure: nothing but
+        // may-alias analysis kept the compiler from hoisting these loads above the stores of the inlined shade_vertex.  The memory
+        // model's statement of the same thing: release after the stores (shade_vertex), acquire before the loads.
+        wave_handoff();
         const uint32_t lane_ = threadIdx.x & 63u;
         const bool     on    = lane_ < count;
         const uint32_t pos   = (ring_head + lane_) & (kWaveRing - 1u);

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
                     if (lane < pend_n) rbuf[lane] = pa, rbuf[64u + lane] = pb;
                     buf_n = pend_n, buf_pos = 0, buf_base = pend_base;
                     fetch();
-                    __builtin_amdgcn_wave_barrier();
+                    wave_handoff();
                 }
                 const unsigned long long idle = ~m_alive;
                 const uint32_t n_idle = (uint32_t)__popcll(idle), avail = buf_n - buf_pos;

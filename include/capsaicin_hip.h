@@ -128,9 +128,12 @@ typedef struct CapStats
     double   ms_direct;       /* "RT Direct lighting": shading of the camera vertex + its shadow rays (part of ms_primary on the fused
                                  small-scene path, of ms_shade / ms_trace_any otherwise; CAP_RENDER_STAGE_TIMERS) */
     double   ms_post_pass[5]; /* "Spatial gather", "Temporal upscale", "EAW", "Combine illumination", "TAA" (sum = ms_post) */
-    /* Shadow rays that travelled through the shadow queue to an any-hit launch.  rays_shadow counts every shadow ray traced; on the
-     * small-scene path the kernel that generates a shadow ray answers it itself when it can (reference model: a probe against the
-     * most likely occluder; EXT model: the whole test), and only the rest become queue entries. */
+    /* Shadow rays that were stored as an entry before being traced: in the shadow queue for an any-hit launch, or -- small-scene path,
+     * bounces >= 1 -- in the per-wave ring of the kernel that generated them (origin in LDS, the 16-B contribution in the wave's slice
+     * of the shadow queue's memory; bench.py prices either kind at 32 B: 16 + 16 written for a queue entry, 16 written + 16 read back
+     * for a ring entry).  rays_shadow counts every shadow ray traced; on the small-scene path the generating kernel answers a shadow
+     * ray itself when it can (reference model: a probe against the most likely occluder; EXT model: the whole test), and only the
+     * rest become entries. */
     uint64_t shadow_entries;
     uint64_t shadow_entries_bounce0;
 } CapStats;
@@ -259,6 +262,10 @@ int cap_comm_image(CapContext* ctx, float** device_image);
 int cap_comm_readback(CapContext* ctx, float* dst);
 int cap_comm_info(CapContext* ctx, uint32_t* rank, uint32_t* size, uint32_t* uses_rccl);
 int cap_comm_destroy(CapContext* ctx); /* also done by cap_ctx_destroy */
+/* Error path: gives the communicator up WITHOUT waiting for the stream (ncclCommAbort) -- for a rank whose peers failed before
+ * entering a collective this rank has already queued, where cap_comm_destroy's stream synchronisation would never return.  The
+ * communicator's asynchronous error state is polled once per frame by cap_comm_gather_frame* (ncclCommGetAsyncError). */
+int cap_comm_abort(CapContext* ctx);
 
 /* ---- reconstruction chain ----
  * The passes RaytracingSystem::Run records after the ray passes (raytracing_system.cpp:294-317):

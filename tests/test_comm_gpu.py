@@ -75,6 +75,48 @@ def test_shards_of_one_process(native_lib, bluenoise, cornell_path, n):
         s.close()
 
 
+def test_mismatched_shard_count_is_an_error_and_recoverable(native_lib, bluenoise, cornell_path):
+    """A context whose shard does not match its rank (cap_set_shard after cap_comm_init_*) must fail with a status, leave no RCCL
+    group open and no half-staged frame behind: the same contexts gather correctly once the shards are put right.  Both forms:
+    the one-process contexts of cap_comm_init_all and a one-rank RCCL communicator (cap_comm_init_rank)."""
+    w, h, spp, D, n = 203, 117, 2, 3, 3
+    whole = make(cornell_path, bluenoise, w, h)
+    whole.render(0, spp, D)
+    want = whole.readback(capi.BUF_ACCUM_MEAN)
+    shards = [make(cornell_path, bluenoise, w, h, (i, n)) for i in range(n)]
+    capi.comm_init_all(shards)
+    shards[2].set_shard(1, 2)  # deliberately wrong: renders shard 1 of 2 while being rank 2 of 3
+    for s in shards:
+        s.render(0, spp, D)
+    with pytest.raises(capi.CapError, match="renders shard 1 of 2 but is rank 2 of 3"):
+        capi.comm_gather_frame_all(shards)
+    with pytest.raises(capi.CapError, match="same order"):
+        capi.comm_gather_frame_all(shards[:2])  # wrong count
+    shards[2].set_shard(2, n)
+    for s in shards:
+        s.accum_reset()
+        s.render(0, spp, D)
+    capi.comm_gather_frame_all(shards)
+    capi.comm_gather_frame_all(shards)  # twice without a cap_sync in between: the shards' send buffers are fenced by events
+    assert np.array_equal(bits(shards[0].comm_readback()), bits(want))
+    for s in shards:
+        s.close()
+    # RCCL form: rank 0 of 1, then the shard is changed under the communicator
+    r = make(cornell_path, bluenoise, w, h)
+    r.comm_init_rank(capi.comm_unique_id(), 0, 1)
+    r.set_shard(0, 2)
+    r.render(0, spp, D)
+    with pytest.raises(capi.CapError, match="renders shard 0 of 2 but is rank 0 of 1"):
+        r.comm_gather_frame()
+    r.set_shard(0, 1)
+    r.accum_reset()
+    r.render(0, spp, D)
+    r.comm_gather_frame()  # the async-error poll of the second frame and the collective itself: clean
+    assert np.array_equal(bits(r.comm_readback()), bits(want))
+    r.close()
+    whole.close()
+
+
 @pytest.mark.skipif(capi.device_count() < 2, reason="needs two GPUs")
 def test_rccl_across_devices(native_lib, bluenoise, cornell_path):
     n = min(capi.device_count(), 4)

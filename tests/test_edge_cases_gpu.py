@@ -149,3 +149,84 @@ def test_depth_zero_and_max_depth(native_lib, bluenoise, cornell_path):
     with pytest.raises(capi.CapError, match="num_bounces"):
         r.render(0, 1, 256, 0)
     r.close()
+
+
+def _open_top_scene():
+    """A floor and two low walls under an open sky: the occluder the producer-side probe tests first (the pair farthest along the
+    light, which points up: lighting.h:20-33) shadows almost nothing, so nearly every shadow ray of bounces >= 1 survives the probe
+    and travels through its wave's 128-entry ring (kernels.hip trace_ring)."""
+    def quad(a, b, c, d):
+        return [[a, b, c], [a, c, d]]
+    tris = quad([-2, 0, 2], [2, 0, 2], [2, 0, -2], [-2, 0, -2])                    # floor, normal +y
+    tris += quad([-2, 0, -2], [2, 0, -2], [2, 0.6, -2], [-2, 0.6, -2])              # back wall, normal +z
+    tris += quad([-2, 0, 2], [-2, 0, -2], [-2, 0.6, -2], [-2, 0.6, 2])              # left wall, normal +x
+    tris += quad([0.2, 0, 0.2], [0.8, 0, 0.2], [0.8, 0.9, 0.2], [0.2, 0.9, 0.2])   # a panel, normal +z
+    return scene_arrays(tris)
+
+
+def _ring_camera(w, h):
+    cam = capi.CameraData()
+    f = np.float64([0.0, -0.55, -1.0])
+    f /= np.linalg.norm(f)
+    right = -np.cross(f, (0, 1, 0))
+    right /= np.linalg.norm(right)
+    cam.position[:] = (0.0, 2.2, 3.6)
+    cam.forward[:] = f
+    cam.right[:] = right
+    cam.up[:] = np.cross(f, right)
+    cam.focal_length = 0.03
+    cam.sensor_size[0] = 0.036
+    cam.sensor_size[1] = np.float32(0.036) * (np.float32(h) / np.float32(w))
+    return cam
+
+
+_RING_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + "/tests")
+from capsaicin_amd import capi
+import test_edge_cases_gpu as T
+w, h, frames, depth = (int(x) for x in sys.argv[3:7])
+bn = np.fromfile(sys.argv[1] + "/assets/bluenoise256.rgba", np.uint8).reshape(256, 256, 4)
+r = capi.Renderer(0)
+r.upload_scene(*T._open_top_scene()); r.upload_bluenoise(bn); r.build_bvh(); r.set_resolution(w, h); r.set_camera(T._ring_camera(w, h))
+r.set_traversal(2); r.render(0, frames, depth, 0)
+s = r.stats()
+np.savez(sys.argv[2], acc=r.readback(capi.BUF_ACCUM_SUM), rays=np.uint64([s.rays_primary, s.rays_extension, s.rays_shadow, s.shadow_entries]))
+"""
+
+
+def test_wave_ring_open_top_scene(native_lib, bluenoise, tmp_path):
+    """The per-wave ring as the ONLY route of the shadow rays: 32 frames of 1024x768 leave every persistent wave
+    (at most 256 CUs x 8 workgroups x 4) several hundred survivors per launch, so each 128-entry ring wraps several times.  Bit-exact against the oracle, and bit- and
+    counter-identical to a process that runs without the ring (CAP_NO_WAVE_RING: the any-hit launch traces the same entries)."""
+    import os
+    import subprocess
+    import sys
+    from oracle import cap_oracle as O
+    w, h, frames, depth = 1024, 768, 32, 3
+    arrays, cam = _open_top_scene(), _ring_camera(w, h)
+    r = capi.Renderer(0)
+    r.upload_scene(*arrays)
+    r.upload_bluenoise(bluenoise)
+    r.build_bvh()
+    r.set_resolution(w, h)
+    r.set_camera(cam)
+    r.set_traversal(2)
+    r.render(0, frames, depth, 0)
+    got, s = r.readback(capi.BUF_ACCUM_SUM), r.stats()
+    r.close()
+    acc, rays = O.Scene(*arrays).render_accumulate(ocam(O, cam), bluenoise, w, h, 0, frames, depth, threads=8)
+    assert np.array_equal(bits(got[..., :3]), bits(acc[..., :3])) and np.all(got[..., 3] == frames)
+    assert (s.rays_primary, s.rays_extension, s.rays_shadow) == rays and s.guard_shade == 0 and s.guard_trace_any == 0
+    # the scene does what it is for: the probe answers (almost) nothing, so the survivors -- counted in shadow_entries -- are most
+    # of the shadow rays, and there are enough of them to wrap every wave's ring
+    ring_entries = s.shadow_entries - s.shadow_entries_bounce0
+    assert s.shadow_entries > 0.8 * s.rays_shadow and ring_entries > 4 * 256 * 8 * 4 * 128
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "noring.npz")
+    env = dict(os.environ, CAP_NO_WAVE_RING="1")
+    subprocess.run([sys.executable, "-c", _RING_CHILD, root, out, str(w), str(h), str(frames), str(depth)], check=True, env=env, timeout=300)
+    z = np.load(out)
+    assert np.array_equal(bits(z["acc"]), bits(got))
+    assert tuple(int(x) for x in z["rays"]) == (s.rays_primary, s.rays_extension, s.rays_shadow, s.shadow_entries)

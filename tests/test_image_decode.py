@@ -94,3 +94,50 @@ def test_ppm(native_lib):
     buf = io.BytesIO()
     im.save(buf, "PPM")
     assert np.array_equal(capi.image_decode(buf.getvalue(), "t.ppm"), expected(im))
+
+
+def test_oversized_truncated_and_bomb_inputs_end_as_errors(native_lib):
+    """Sizes come out of a file's header before any data is seen: a 100-byte file must not be able to ask for
+    gigabytes, a deflate stream must stop at the size its header promised, a colour map must have a depth the expander knows, and
+    nothing may leave cap_image_decode as a C++ exception."""
+    import struct
+    import zlib
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+
+    def png(w, h, depth, ctype, payload):
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"IDAT", payload) + chunk(b"IEND", b"")
+    # 32768 x 32768 16-bit RGBA: 8 GiB by its header
+    with pytest.raises(capi.CapError):
+        capi.image_decode(png(32768, 32768, 16, 6, zlib.compress(b"\0" * 64)), "big.png")
+    # a zlib bomb behind a 4 x 4 header: 64 MiB of zeros where 52 bytes are due
+    with pytest.raises(capi.CapError):
+        capi.image_decode(png(4, 4, 8, 2, zlib.compress(b"\0" * (64 << 20), 9)), "bomb.png")
+    # truncated streams of a good file, every few bytes
+    im = image("RGBA", 21, 17, seed=4)
+    buf = io.BytesIO()
+    im.save(buf, "PNG")
+    good = buf.getvalue()
+    assert np.array_equal(capi.image_decode(good, "g.png"), expected(im))
+    for cut in range(8, len(good) - 12, 7):
+        try:
+            capi.image_decode(good[:cut], "cut.png")
+        except capi.CapError:
+            pass
+    # TGA: 65535 x 65535 x 32 bits uncompressed by its header; a colour map of a depth nobody defines; a truncated RLE body
+    hdr = struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, 65535, 65535, 32, 0)
+    with pytest.raises(capi.CapError):
+        capi.image_decode(hdr + b"\0" * 64, "big.tga")
+    hdr = struct.pack("<BBBHHBHHHHBB", 0, 1, 1, 0, 4, 8, 0, 0, 2, 2, 8, 0)
+    with pytest.raises(capi.CapError):
+        capi.image_decode(hdr + bytes(4) + bytes(4), "cmap8.tga")
+    buf = io.BytesIO()
+    image("RGB", 41, 19, seed=3).save(buf, "TGA", compression="tga_rle")
+    for cut in range(18, len(buf.getvalue()), 11):
+        try:
+            capi.image_decode(buf.getvalue()[:cut], "cut.tga")
+        except capi.CapError:
+            pass
+    with pytest.raises(capi.CapError):
+        capi.image_decode(b"P6\n40000 40000\n255\n" + b"\0" * 100, "big.ppm")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Host-code sanitizer pass (CPU only; GPU sanitizers are not available on this pool).
-#  1. sah_builder.cpp + obj_loader.cpp under ASan/UBSan with a small driver (random boxes, the Cornell OBJ, a missing file);
+#  1. sah_builder.cpp + obj_loader.cpp + image_decode.cpp under ASan/UBSan with a small driver (random boxes, the Cornell OBJ, a
+#     missing file; good, truncated, oversized-by-header and bomb PNG / TGA / PPM files);
 #  2. the oracle rebuilt with ASan/UBSan and the CPU oracle tests run against it (the regular .so is restored afterwards).
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -12,10 +13,13 @@ cat > "$W/main.cpp" <<'EOF'
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 extern "C" int  cap_host_sah_build(const float*, uint32_t, float*, uint32_t*, uint32_t*);
 extern "C" int  cap_obj_load(const char*, const char*, void**);
 extern "C" void cap_geometry_free(void*);
+extern "C" int  cap_image_decode(const uint8_t*, size_t, const char*, uint8_t**, uint32_t*, uint32_t*);
+extern "C" void cap_image_free(uint8_t*);
 extern "C" void cap_set_error_(const char* m) { fprintf(stderr, "  (error text: %s)\n", m); }
 extern "C" int  cap_scene_upload(void*, const float*, const float*, const float*, const uint32_t*, const void*, uint32_t, uint32_t, uint32_t) { return 0; }
 int main(int argc, char** argv)
@@ -40,6 +44,30 @@ int main(int argc, char** argv)
     }
     for (int i = 1; i < argc; ++i)
     {
+        const std::string a = argv[i];
+        if (a.size() > 4 && (a.substr(a.size() - 4) == ".png" || a.substr(a.size() - 4) == ".tga" || a.substr(a.size() - 4) == ".ppm"))
+        {
+            FILE* f = fopen(argv[i], "rb");
+            if (!f) return 1;
+            std::vector<uint8_t> d;
+            uint8_t              buf[65536];
+            size_t               n;
+            while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+            fclose(f);
+            int ok = 0, bad = 0;
+            // the whole file, then every prefix in steps of 5 bytes
+            for (size_t cut = d.size(); cut > 0; cut = cut == d.size() ? d.size() - 1 : (cut > 5 ? cut - 5 : 0))
+            {
+                std::vector<uint8_t> part(d.begin(), d.begin() + cut);  // exact-size heap block: over-reads are caught
+                uint8_t*  px = nullptr;
+                uint32_t  w = 0, h = 0;
+                const int rc = cap_image_decode(part.data(), part.size(), argv[i], &px, &w, &h);
+                (rc == 0 ? ok : bad)++;
+                if (px) cap_image_free(px);
+            }
+            printf("image %s: %d prefixes decoded, %d refused\n", argv[i], ok, bad);
+            continue;
+        }
         void*     g  = nullptr;
         const int rc = cap_obj_load(argv[i], "", &g);
         printf("obj %s rc=%d\n", argv[i], rc);
@@ -49,8 +77,28 @@ int main(int argc, char** argv)
 }
 EOF
 g++ -std=c++17 $SAN -I"$ROOT/include" -I"$ROOT/capsaicin_amd/csrc" "$W/main.cpp" \
-    "$ROOT/capsaicin_amd/csrc/sah_builder.cpp" "$ROOT/capsaicin_amd/csrc/obj_loader.cpp" -o "$W/host"
-"$W/host" "$ROOT/assets/cornell_box.obj" /nonexistent/none.obj
+    "$ROOT/capsaicin_amd/csrc/sah_builder.cpp" "$ROOT/capsaicin_amd/csrc/obj_loader.cpp" "$ROOT/capsaicin_amd/csrc/image_decode.cpp" -o "$W/host"
+python3 - "$W" <<'EOF'
+import io, struct, sys, zlib
+import numpy as np
+from PIL import Image
+w = sys.argv[1]
+rs = np.random.RandomState(1)
+a = (np.add.outer(np.arange(23) * 3, np.arange(37) * 5)[..., None] + rs.randint(0, 9, (23, 37, 4))) % 256
+Image.fromarray(a.astype(np.uint8), "RGBA").save(w + "/rgba.png")
+Image.fromarray(a[..., :3].astype(np.uint8), "RGB").save(w + "/rgb0.png", compress_level=0)
+p = Image.fromarray(rs.randint(0, 17, (23, 37)).astype(np.uint8), "P"); p.putpalette(rs.randint(0, 256, 51).astype(np.uint8).tolist()); p.save(w + "/pal.png")
+Image.fromarray(a[..., :3].astype(np.uint8), "RGB").save(w + "/rle.tga", compression="tga_rle")
+Image.fromarray(a.astype(np.uint8), "RGBA").save(w + "/raw.tga")
+Image.fromarray(a[..., :3].astype(np.uint8), "RGB").save(w + "/p6.ppm")
+def chunk(tag, body): return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+def png(wd, h, depth, ctype, payload): return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", wd, h, depth, ctype, 0, 0, 0)) + chunk(b"IDAT", payload) + chunk(b"IEND", b"")
+open(w + "/huge.png", "wb").write(png(32768, 32768, 16, 6, zlib.compress(b"\0" * 64)))
+open(w + "/bomb.png", "wb").write(png(4, 4, 8, 2, zlib.compress(b"\0" * (8 << 20), 9)))
+open(w + "/huge.tga", "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, 65535, 65535, 32, 0) + b"\0" * 64)
+open(w + "/cmap8.tga", "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 1, 1, 0, 4, 8, 0, 0, 2, 2, 8, 0) + bytes(8))
+EOF
+"$W/host" "$ROOT/assets/cornell_box.obj" /nonexistent/none.obj "$W"/*.png "$W"/*.tga "$W"/*.ppm
 
 g++ -std=c++17 $SAN -fPIC -ffp-contract=off -mfma -fno-fast-math -pthread -shared -o "$W/libcap_oracle.so" \
     "$ROOT/oracle/cap_oracle.cpp" "$ROOT/oracle/cap_oracle_post.cpp"

@@ -18,8 +18,20 @@ KERNELS = {"headline": "k_trace_shade<false, false, false, true>", "ext": "k_tra
            "tree": "k_trace_closest8", "tree_shade": "k_shade<"}
 
 
+def listed_passes():
+    m = os.path.join(root, "gpurun_out", "prof_manifest.txt")
+    if not os.path.exists(m):
+        sys.exit("no gpurun_out/prof_manifest.txt: run tools/prof.sh through gpurun first")
+    rows = [l.split(None, 1) for l in open(m)]
+    sha = [v.strip() for k, v in rows if k == "source_sha256"]
+    if sha != [bench.kernel_source_sha()]:
+        sys.exit("the passes in gpurun_out/ were taken on other kernel sources (%s) than the tree holds now" % sha)
+    return {v.strip() for k, v in rows if k == "pass"}
+
+
 def total(pass_glob, counter, kernel):
     fs = glob.glob(os.path.join(root, "gpurun_out", pass_glob, "**", "*counter_collection.csv"), recursive=True)
+    fs = [f for f in fs if os.path.relpath(f, os.path.join(root, "gpurun_out")).split(os.sep)[0] in PASSES]
     if not fs:
         return 0.0, 0
     s, n = 0.0, 0
@@ -31,6 +43,7 @@ def total(pass_glob, counter, kernel):
     return s, n
 
 
+PASSES = listed_passes()
 out = {"source_sha256": bench.kernel_source_sha(), "kernels": {},
        "method": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ block, each in its own run, no trace options) of `python3 "
                  "bench.py --steps 2 --warmup 1 --no-cpu-baseline` (tools/prof.sh); counters summed over the kernel's dispatches and "

@@ -8,10 +8,24 @@ def short(name):
     return name[:60]
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+# only the passes tools/prof.sh listed for its last run (gpurun merges into gpurun_out/ and never deletes: directories of earlier
+# rounds may still lie there)
+manifest = os.path.join(root, "prof_manifest.txt")
+if not os.path.exists(manifest):
+    sys.exit("no %s: run tools/prof.sh through gpurun first" % manifest)
+listed = set()
+for line in open(manifest):
+    k, v = line.split(None, 1)
+    if k == "source_sha256":
+        print("# kernel sources: sha256 %s" % v.strip())
+    elif k == "pass":
+        listed.add(v.strip())
 # kernel trace
 def newest_per_dir(pattern):
     by_dir = {}
     for f in glob.glob(pattern, recursive=True):
+        if os.path.relpath(f, root).split(os.sep)[0] not in listed:
+            continue
         d = f.split(os.sep)[1] if root == "gpurun_out" else os.path.dirname(os.path.dirname(f))
         if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
             by_dir[d] = f
