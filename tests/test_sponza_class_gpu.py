@@ -122,3 +122,102 @@ def test_full_scale_properties(native_lib, bluenoise, tmp_path):
         parts.append(tiles.extract(r.readback(capi.BUF_ACCUM_SUM), idx, 2))
     assert np.array_equal(bits(tiles.assemble(parts, w, h)), bits(a))
     r.close()
+
+
+PLANES = (("gbuffer_geo", capi.BUF_GBUFFER_GEO), ("albedo", capi.BUF_ALBEDO), ("direct", capi.BUF_DIRECT),
+          ("normal_depth", capi.BUF_NORMAL_DEPTH), ("indirect", capi.BUF_INDIRECT), ("combined", capi.BUF_COMBINED))
+
+
+def test_config4_at_its_own_size(native_lib, bluenoise, tmp_path):
+    """BASELINE configs[3] as it is written: the ~262 k-triangle textured scene at 1920x1080, depth 8, tree built by cap_bvh_build
+    AUTO (device clustering + 8-wide collapse: the depth-27 / depth-8 trees bench.py's tree_variant times), tile-sharded over
+    2 / 4 / 8 contexts through cap_comm_init_all + cap_comm_gather_frame_all (VERDICT r2 missing 1).  The sample count (128 spp) is
+    bench-sized; what does not depend on it is checked here on a few frames:
+      * two WHOLE frames (not crops: the oracle's BVH mode on all host cores does a 1080p frame of this scene in seconds), all
+        six planes and the three ray counters bit-exact against the oracle;
+      * an accumulated render: finite, .w == spp, guards silent, re-batched (one frame per batch) bit-identical with identical
+        counters, equal to the fp32 sum of its frames;
+      * 2, 4 and 8 shards: the gathered frame bit-identical to the unsharded one, the shards' counters summing to it."""
+    from oracle import cap_oracle as O
+    geo, texs = _setup(tmp_path, 1.0, 128)
+    ntri = geo.indices.size // 3
+    assert 250_000 < ntri < 275_000
+    w, h, D, spp = 1920, 1080, 8, 3
+
+    def make(shard=(0, 1), batch=0):
+        r = capi.Renderer(0)
+        r.upload_geometry(geo)
+        for i, t in enumerate(texs):
+            r.upload_texture(i, t)
+        r.upload_bluenoise(bluenoise)
+        info = r.build_bvh()
+        r.set_resolution(w, h)
+        r.set_shard(*shard)
+        r.set_camera(_camera(w, h))
+        if batch:
+            r.set_batch_paths(batch)
+        return r, info
+
+    r, info = make()
+    assert info.triangle_count == ntri and info.max_depth > 16  # a real tree, not the exhaustive small-scene path
+    cam = _camera(w, h)
+    sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes, textures=texs)
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1], cam.focal_length)
+    threads = min(64, os.cpu_count() or 8)
+    for frame in (0, 77):
+        r.accum_reset()
+        r.stats_reset()
+        r.render(frame, 1, D, capi.RENDER_AOV)
+        ref = sc.render_frame(ocam, bluenoise, w, h, frame, D, flags=O.FLAG_USE_BVH, threads=threads)
+        for name, kind in PLANES:
+            nbad = int((bits(r.readback(kind)) != bits(ref[name])).any(-1).sum())
+            assert nbad == 0, "frame %d, %s: %d pixels differ" % (frame, name, nbad)
+        s = r.stats()
+        assert (s.rays_primary, s.rays_extension, s.rays_shadow) == ref["rays"] and s.guard_shade == 0 and s.guard_trace_any == 0
+        assert s.launches_shade > 0  # the tree path's stand-alone shade stage ran (the fused small-scene kernels have none)
+    # accumulated render + re-batching + additivity
+    r.accum_reset()
+    r.stats_reset()
+    r.render(0, spp, D, 0)
+    a, s = r.readback(capi.BUF_ACCUM_SUM), r.stats()
+    assert np.isfinite(a).all() and (a[..., 3] == spp).all() and (a[..., :3] >= 0).all()
+    assert s.rays_primary == spp * w * h and s.guard_shade == 0 and s.guard_trace_any == 0
+    r.set_batch_paths(w * h)
+    r.accum_reset()
+    r.stats_reset()
+    r.render(0, spp, D, 0)
+    s1 = r.stats()
+    assert np.array_equal(bits(r.readback(capi.BUF_ACCUM_SUM)), bits(a))
+    assert (s1.rays_extension, s1.rays_shadow, s1.shaded_vertices) == (s.rays_extension, s.rays_shadow, s.shaded_vertices)
+    tot = np.zeros_like(a)
+    for f in range(spp):
+        r.accum_reset()
+        r.render(f, 1, D, 0)
+        tot = tot + r.readback(capi.BUF_ACCUM_SUM)
+    assert np.array_equal(bits(tot[..., :3]), bits(a[..., :3]))
+    r.set_batch_paths(0)
+    r.accum_reset()
+    r.render(0, spp, D, 0)
+    want = r.readback(capi.BUF_ACCUM_MEAN)
+    r.close()
+    # 2 / 4 / 8 shards through the C ABI's exchange (one device: copies instead of links, same staging and assembly)
+    shards = [make((i, 8), batch=8 << 20)[0] for i in range(8)]
+    for n in (2, 4, 8):
+        for i in range(n):
+            shards[i].set_shard(i, n)
+        capi.comm_init_all(shards[:n])
+        for x in shards[:n]:
+            x.accum_reset()
+            x.stats_reset()
+            x.render(0, spp, D, 0)
+        capi.comm_gather_frame_all(shards[:n])
+        got = shards[0].comm_readback()
+        assert np.array_equal(bits(got), bits(want)), "%d shards" % n
+        st = [x.stats() for x in shards[:n]]
+        for field in ("rays_primary", "rays_extension", "rays_shadow", "shaded_vertices"):
+            assert sum(getattr(x, field) for x in st) == getattr(s, field), (n, field)
+        assert all(x.guard_shade == 0 and x.guard_trace_any == 0 for x in st)
+        for x in shards[:n]:
+            x.comm_destroy()
+    for x in shards:
+        x.close()
