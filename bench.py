@@ -145,6 +145,28 @@ def load_sponza_class(r, rank=0):
     return camera
 
 
+def shard_cost(make_renderer, spp, depth, reps=3):
+    """The compute side of the 1 -> 8 GPU curve, measured on ONE device: ms per step for shard 0 of N (tiles t = 0 mod N of every
+    frame, exactly what rank 0 of N renders -- every rank's share is the same to within a tile row) and the parallel efficiency it
+    predicts before a byte is exchanged, T(1) / (N * T(0 of N)).  `make_renderer()` returns a Renderer with scene, tree, camera and
+    resolution set."""
+    r = make_renderer()
+    out = {}
+    for n in (1, 2, 4, 8):
+        r.set_shard(0, n)
+        r.render(0, spp, depth, 0)
+        r.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r.accum_reset()
+            r.render(0, spp, depth, 0)
+        r.sync()
+        out[n] = (time.perf_counter() - t0) / reps * 1e3
+    r.close()
+    return {"ms_shard0_of_N": {str(n): out[n] for n in out},
+            "predicted_parallel_efficiency": {str(n): out[1] / (n * out[n]) for n in out}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -491,6 +513,33 @@ def main():
             except Exception as exc:  # the extra line must never cost the contract line
                 tree_variant = {"error": str(exc)}
 
+        # the compute side of the scaling curve on this one device: extra key, N = 1 only
+        shard_costs = None
+        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant:
+            try:
+                def make_cornell():
+                    rc = capi.Renderer(device_index, stream.cuda_stream)
+                    rc.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
+                    rc.upload_bluenoise(capi.load_bluenoise())
+                    rc.build_bvh()
+                    rc.set_resolution(WIDTH, HEIGHT)
+                    rc.set_camera(capi.cornell_camera(WIDTH, HEIGHT))
+                    return rc
+
+                def make_tree():
+                    rt = capi.Renderer(device_index, stream.cuda_stream)
+                    camt = load_sponza_class(rt)
+                    rt.upload_bluenoise(capi.load_bluenoise())
+                    rt.build_bvh()
+                    rt.set_resolution(WIDTH, HEIGHT)
+                    rt.set_camera(camt)
+                    return rt
+                shard_costs = {"what": "ms per step of shard 0 of N on ONE MI355X (no exchange): the compute side of the 1 -> N curve",
+                               "cornell_64spp": shard_cost(make_cornell, SPP, DEPTH),
+                               "sponza_class_32spp": shard_cost(make_tree, TREE_SPP, DEPTH, reps=2)}
+            except Exception as exc:  # the extra key must never cost the contract line
+                shard_costs = {"error": str(exc)}
+
         if rank == 0:
             # sanity of the product of the timed region: finite image, every pixel accumulated spp frames
             img = (r.comm_readback() if exchange.startswith("cap_comm") else image.cpu().numpy()).reshape(HEIGHT, WIDTH, 4)
@@ -503,7 +552,7 @@ def main():
                               "triangles": int(bvh.triangle_count), "bvh_depth": int(bvh.max_depth),
                               "rays_per_step": {"primary": rays_p / args.steps, "extension": rays_e / args.steps, "shadow": rays_s / args.steps},
                               "parallelism": "tiles%d" % world, "exchange": exchange},
-                   "roofline": roofline, "ext_variant": ext_variant, "tree_variant": tree_variant}
+                   "roofline": roofline, "ext_variant": ext_variant, "tree_variant": tree_variant, "shard_cost": shard_costs}
             out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()  # rank 0, N = 1 only
             print(json.dumps(out), flush=True)
         r.close()

@@ -22,6 +22,7 @@ constexpr uint32_t kBlock      = 256;  // threads per workgroup (4 waves, one pe
 // and never changes, so sub-queue k can never hold more than the class-k paths: static capacity, no overflow handling.
 constexpr uint32_t kQueueClasses  = 64;
 constexpr uint32_t kCounterStride = 32;  // uint32 words between two class counters (128 B)
+// Words 2 and 3 of a class's counter line: shadow rays answered by the producer's probe, shaded vertices (flush_stats)
 constexpr uint32_t kShadeRec      = 8;   // float4 per shading record
 constexpr uint32_t kExhaustiveMax = 64;  // scenes up to this many triangles are traced exhaustively (kernels.hip)
 constexpr int      kNoChild        = 0x7fffffff;  // unused slot of a wide node

@@ -63,9 +63,9 @@ struct ShadeArgs
     // Reference model on the small-scene path: the fused kernel tests every shadow ray it generates against ONE fan pair -- the one
     // farthest along the batch's first light direction, which occludes most of them -- and only queues the survivors for the any-hit
     // kernel (which then tests every pair, without a probe of its own).  Occlusion is an OR over the pairs: same result.
-    // probe_count: where the launch adds the number of shadow rays the probe answered (they are rays of the statistics, not entries)
+    // The shadow rays the probe answered are rays of the statistics, not entries: the launch adds their number to word 2 of its
+    // classes' counter lines (flush_stats).
     uint32_t          inline_probe;
-    uint32_t*         probe_count;
     // ... and from bounce 1 on the survivors are traced by the wave that found them (k_trace_shade's per-wave ring): the only
     // any-hit launch left on the small-scene path is bounce 0's
     uint32_t          wave_ring;
@@ -163,6 +163,8 @@ struct PostSettingsDev  // SettingsComponent subset, gui_system.h:20-37
     float gather_normal_sigma, gather_depth_sigma, gather_luma_sigma;
     float temporal_upscale_feedback, taa_feedback;
     int   lowres_indirect;  // UPSCALE2X: `indirect` is the (W/2, H/2) image of this frame's interleave offset
+    int   use_variance;     // USE_VARIANCE of eaw_blur.hlsl
+    int   fast_weights;     // hardware exp / log / rcp in the edge-stopping weights (toleranced mode)
 };
 struct PostChainArgs
 {

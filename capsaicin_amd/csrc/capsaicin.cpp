@@ -174,7 +174,8 @@ void run_raytracing(World& w)
                                (s.lowres_indirect ? (uint32_t)CAP_RENDER_LOWRES_INDIRECT : 0u);
         check(cap_render(w.ctx, w.frame_count, 1, (uint32_t)std::max(0, s.num_diffuse_bounces), flags), "RaytracingSystem");
         CapPostSettings ps{s.gather, s.denoise, s.eaw5, s.eaw_normal_sigma, s.eaw_depth_sigma, s.eaw_luma_sigma, s.gather_normal_sigma,
-                           s.gather_depth_sigma, s.gather_luma_sigma, s.temporal_upscale_feedback, s.taa_feedback, s.lowres_indirect};
+                           s.gather_depth_sigma, s.gather_luma_sigma, s.temporal_upscale_feedback, s.taa_feedback, s.lowres_indirect,
+                           s.use_variance, s.fast_weights};
         CapCameraData   prev;
         std::memcpy(&prev, &w.prev_camera, sizeof(prev));
         check(cap_post_frame(w.ctx, &ps, w.frame_count, &prev), "RaytracingSystem");

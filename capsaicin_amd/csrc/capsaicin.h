@@ -37,6 +37,8 @@ struct Settings
     bool  reconstruct               = false;
     bool  gbuffer_feedback          = true;    // RaytracingOptions::gbuffer_feedback, raytracing_system.h:26
     bool  lowres_indirect           = false;   // RaytracingOptions::lowres_indirect, raytracing_system.h:24 (even window sizes)
+    bool  use_variance              = true;    // RaytracingOptions::use_variance, raytracing_system.h:25
+    bool  fast_weights              = false;   // not a reference option: CapPostSettings::fast_weights (toleranced chain)
     bool  gather                    = true;    // gui_system.h:20-37
     bool  denoise                   = true;
     bool  eaw5                      = true;

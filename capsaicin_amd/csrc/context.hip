@@ -269,12 +269,10 @@ int sync_and_collect(CapContext* c)
                     c->stats.rays_shadow_bounce0 += pc.first[k * kCounterStride + 1];
                     if (queued) c->stats.shadow_entries_bounce0 += pc.first[k * kCounterStride + 1];
                 }
-                if (k == 0)
-                {
-                    // shadow rays the producer's probe answered (ShadeArgs::probe_count): rays, though never queue entries
-                    c->stats.rays_shadow += pc.first[b * per + 2];
-                    if (b == 0) c->stats.rays_shadow_bounce0 += pc.first[2];
-                }
+                // word 2: shadow rays the producer's probe answered (rays, though never queue entries); word 3: shaded vertices
+                c->stats.rays_shadow += pc.first[b * per + k * kCounterStride + 2];
+                if (b == 0) c->stats.rays_shadow_bounce0 += pc.first[k * kCounterStride + 2];
+                c->stats.shaded_vertices += pc.first[b * per + k * kCounterStride + 3];
             }
         c->pinned_pool.push_back(pc.first);
     }
@@ -282,7 +280,6 @@ int sync_and_collect(CapContext* c)
     if (c->pinned_shaded && c->shaded_counter.p)
     {
         HIP_TRY(hipMemcpy(c->pinned_shaded, c->shaded_counter.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        c->stats.shaded_vertices = c->pinned_shaded[0];
         c->stats.guard_shade     = c->pinned_shaded[1];
         c->stats.guard_trace_any = c->pinned_shaded[2];
         c->stats.guard_last      = c->pinned_shaded[3];
@@ -1137,7 +1134,6 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                                     po ? c->s_dir.p : c->s_org.p};
             sa.shadow    = ShadowQueue{c->s_org.p, c->s_dir.p, c->s_con.p, sh_count + b * per_queue, class_capacity};
             sa.work      = work_shade + b * per_queue;
-            sa.probe_count = sh_count + b * per_queue + 1;  // word 2 of class 0's counter line of this bounce: unused by the queues
             if (fused)
             {
                 StageTimer t(c, b == 0 ? ST_PRIMARY : ST_CLOSEST, st);
@@ -1348,7 +1344,8 @@ static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t fram
 {
     PostChainArgs a{};
     a.settings = PostSettingsDev{s->gather, s->denoise, s->eaw5, s->eaw_normal_sigma, s->eaw_depth_sigma, s->eaw_luma_sigma, s->gather_normal_sigma,
-                                 s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback, s->lowres_indirect};
+                                 s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback, s->lowres_indirect,
+                                 s->use_variance, s->fast_weights};
     a.width = c->screen.width, a.height = c->screen.height, a.frame_count = frame_count;
     a.camera = camera_dev(c->camera), a.prev_camera = camera_dev(*prev_camera);
     a.indirect = c->post_in[0].p, a.direct = c->post_in[1].p, a.albedo = c->post_in[2].p, a.normal_depth = c->post_in[3].p;

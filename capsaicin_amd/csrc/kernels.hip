@@ -1872,11 +1872,19 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
     }
 }
 
-// statistics: shaded vertices, one atomic per wave
-__device__ __forceinline__ void flush_shaded(uint64_t* counter, uint32_t n_shaded)
+// Statistics of a launch: shaded vertices and (small-scene path) the shadow rays the producer's probe answered -- ONE 64-bit atomic
+// per wave into words 2 (probed) and 3 (shaded) of the counter line of the wave's queue class, whose words 0 and 1 are the
+// bounce's extension / shadow queue lengths (context.hip reads all four from the batch's counter copy).
+// Until round 3 every wave of the grid added to ONE word at the end of every launch (and a second one for the probe count): a
+// device-scope atomic on one address retires ~88 per microsecond (MI355X_MICROARCH.md "dequeue"), so the 6144 waves of a launch
+// with little work -- which all finish together -- queued for 70 us behind each other: the whole "fixed cost" of the persistent
+// launches that round 2's batch-size sweep measured (tools/tiny_trace.sh: 77 us per fused launch whatever its work, 6 us for
+// the any-hit kernel, which has no such flush), and 17 % of a rank's step at eight shards.
+__device__ __forceinline__ void flush_stats(uint32_t* class_line, uint32_t n_shaded, uint32_t n_probed = 0)
 {
-    for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off);
-    if ((threadIdx.x & 63u) == 0 && n_shaded) atomicAdd((unsigned long long*)counter, (unsigned long long)n_shaded);
+    for (int off = 32; off > 0; off >>= 1) n_shaded += __shfl_down(n_shaded, off), n_probed += __shfl_down(n_probed, off);
+    if ((threadIdx.x & 63u) == 0 && (n_shaded | n_probed))
+        atomicAdd(reinterpret_cast<unsigned long long*>(class_line + 2), ((unsigned long long)n_shaded << 32) | (unsigned long long)n_probed);
 }
 
 // Stand-alone shade stage (used with the LBVH stack traversal): consumes the hit records of the preceding trace kernel.
@@ -1943,7 +1951,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
         else
             shade_vertex<FIRST, FB, false, true>(a, a.scene.shade_tris, pre, klass, pid, hit, thr, n_shaded, st);
     }
-    flush_shaded(a.shaded_counter, n_shaded);
+    flush_stats(a.out.count + (size_t)(wave_global_id() % kQueueClasses) * kCounterStride, n_shaded);
 }
 
 // Tree path, bounce 0: the camera rays' packet walk (k_trace_primary_packet) and the shading of the vertices it finds in one
@@ -1991,7 +1999,7 @@ __global__ __launch_bounds__(kBlock, CAP_PS_BLOCKS) void k_primary_shade(BvhDev 
         else
             shade_vertex<true, false, false, true>(a, a.scene.shade_tris, pre, my_class, pid, hit, mk3(1.0f, 1.0f, 1.0f), n_shaded, st);
     }
-    flush_shaded(a.shaded_counter, n_shaded);
+    flush_stats(a.out.count + (size_t)my_class * kCounterStride, n_shaded);
 }
 
 bool launch_primary_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, float4* hits, bool ext)
@@ -2308,12 +2316,7 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
     }
 #endif
     if (PROBE && ring_n != 0u) trace_ring(ring_n);  // what is left in this wave's ring
-    flush_shaded(a.shaded_counter, n_shaded);
-    if (PROBE && a.inline_probe)
-    {
-        for (int off = 32; off > 0; off >>= 1) n_probed += __shfl_down(n_probed, off);
-        if ((threadIdx.x & 63u) == 0 && n_probed) atomicAdd(a.probe_count, n_probed);
-    }
+    flush_stats(a.out.count + (size_t)my_class * kCounterStride, n_shaded, n_probed);
 }
 
 #ifdef CAP_STAMPS

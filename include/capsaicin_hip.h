@@ -287,6 +287,14 @@ typedef struct CapPostSettings
     float   taa_feedback;              /* 0.9   */
     int32_t lowres_indirect;           /* false: RaytracingOptions::lowres_indirect, UPSCALE2X in Gather and Accumulate
                                           (spatial_gather.hlsl:36-46, temporal_accumulation.hlsl:228-235, 307-313) */
+    int32_t use_variance;              /* true: RaytracingOptions::use_variance (raytracing_system.h:25): the USE_VARIANCE define of
+                                          eaw_blur.hlsl:68,114,127,162 (raytracing_system.cpp:669-673).  Off: no luma edge-stopping and
+                                          no a-trous kernel weights in Blur, variance channel 0 */
+    int32_t fast_weights;              /* false.  Not a reference option: evaluates the edge-stopping weights with the hardware's
+                                          v_exp_f32 / v_log_f32 / v_rcp_f32 instead of the arithmetic contract's polynomials and IEEE
+                                          divisions.  The exact mode (0) is bit-identical to the oracle; this one is held to a stated
+                                          tolerance against it (tests/test_post_gpu.py: 2e-3 relative + 1e-4 absolute on the chain's
+                                          output over a multi-frame sequence) and runs the chain about twice as fast */
 } CapPostSettings;
 /* Runs the chain on the planes of the last frame rendered with CAP_RENDER_AOV (frame_count = that frame's index; the
  * camera is the one set for it; prev_camera = the previous frame's, CameraComponent/prev_camera of

@@ -151,6 +151,8 @@ typedef struct OraclePostSettings
     float taa_feedback;              /* 0.9   */
     int   lowres_indirect;           /* false: RaytracingOptions::lowres_indirect (UPSCALE2X in Gather and Accumulate); the
                                         `indirect` argument of oracle_post_frame is then the (W/2)*(H/2) image */
+    int   use_variance;              /* true: RaytracingOptions::use_variance (raytracing_system.h:25) = the USE_VARIANCE define of
+                                        eaw_blur.hlsl (raytracing_system.cpp:669-673); CALCULATE_VARIANCE (cpp:618-622) is read by no shader */
 } OraclePostSettings;
 
 void* oracle_post_create(uint32_t width, uint32_t height);

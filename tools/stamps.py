@@ -8,7 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from capsaicin_amd import capi  # noqa: E402
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-w, h, spp, depth = 1920, 1080, 64, 8
+w, h, depth = 1920, 1080, 8
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 r = capi.Renderer(0)
 r.upload_geometry(capi.Geometry(os.path.join(root, "assets", "cornell_box.obj")))
 r.upload_bluenoise(capi.load_bluenoise())
