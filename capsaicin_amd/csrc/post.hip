@@ -71,17 +71,39 @@ __device__ __forceinline__ float cubic(float x, float b, float c)
 // temporal_accumulation.hlsl:39-66.  The taps sit at whole-pixel offsets of the sample point, where cubic(1, 0, 0.5) is
 // exactly 0: unless (c + 1) - c rounds away from 1, only the centre tap carries weight.  A tap whose kernel weight is
 // exactly 0 adds +0 to both sums (history values are finite and non-negative), so it is skipped before its four loads.
-__device__ __forceinline__ v3 resample_bicubic(const Img& t, f2 uv)
+// The kernel weight of tap (i, j) is cubic(|cur.x - c.x|) * cubic(|cur.y - c.y|) with cur = c + (i, j): three distinct values per
+// axis.  They are evaluated once per sample point (BicubicTaps) instead of once per tap -- 6 cubics instead of 18 -- and shared by
+// the images resampled at the same point (Accumulate's colour and moments histories: 6 instead of 36).  Same expressions on the
+// same operands, so the same bits.
+struct BicubicTaps
+{
+    f2    c;
+    float kx[3], ky[3];
+};
+__device__ __forceinline__ BicubicTaps bicubic_taps(f2 uv, uint32_t w, uint32_t h)
+{
+    BicubicTaps t;
+    t.c = uv_to_xy(uv, w, h);
+#pragma unroll
+    for (int i = -1; i <= 1; ++i)
+    {
+        const float cx = t.c.x + (float)i, cy = t.c.y + (float)i;
+        t.kx[i + 1] = cubic(fabsf(cx - t.c.x), 0.0f, 0.5f);
+        t.ky[i + 1] = cubic(fabsf(cy - t.c.y), 0.0f, 0.5f);
+    }
+    return t;
+}
+__device__ __forceinline__ v3 resample_bicubic(const Img& t, const BicubicTaps& b)
 {
     v3       filtered = mk3(0.f, 0.f, 0.f);
-    const f2 c        = uv_to_xy(uv, t.w, t.h);
+    const f2 c        = b.c;
     float    tw       = 0.0f;
     for (int i = -1; i <= 1; ++i)
         for (int j = -1; j <= 1; ++j)
         {
             const f2 cur = f2{c.x + (float)i, c.y + (float)j};
             if (cur.x < 0.0f || cur.y < 0.0f || cur.x >= (float)t.w || cur.y >= (float)t.h) continue;
-            const float kxy = cubic(fabsf(cur.x - c.x), 0.0f, 0.5f) * cubic(fabsf(cur.y - c.y), 0.0f, 0.5f);
+            const float kxy = b.kx[i + 1] * b.ky[j + 1];
             if (kxy == 0.0f) continue;
             const v3    value = sample_bilinear(t, xy_to_uv(cur, t.w, t.h));
             const float w     = kxy * (1.0f / (1.0f + luminance(value)));
@@ -90,6 +112,7 @@ __device__ __forceinline__ v3 resample_bicubic(const Img& t, f2 uv)
         }
     return tw > 1e-5f ? div3(filtered, tw) : mk3(0.f, 0.f, 0.f);
 }
+__device__ __forceinline__ v3 resample_bicubic(const Img& t, f2 uv) { return resample_bicubic(t, bicubic_taps(uv, t.w, t.h)); }
 // math_functions.h:49-57
 __device__ __forceinline__ v3 oct_decode(float fx, float fy)
 {
@@ -108,6 +131,33 @@ __device__ __forceinline__ float depth_weight(float dc, float dp, float s)
     return exp_neg(-t);
 }
 __device__ __forceinline__ float luma_weight(float lc, float lp, float s) { return exp_neg(-(fabsf(lc - lp) / s)); }
+
+// CapPostSettings::fast_weights: the same three weights through the hardware's transcendental instructions -- v_log_f32 / v_exp_f32
+// (base 2, 1 ulp) and v_rcp_f32 instead of the contract's polynomials and IEEE divisions: ~12 instructions where the exact forms
+// take ~110.  Not bit-comparable with the oracle; held to the tolerance stated in the header (tests/test_post_gpu.py).  The
+// per-pixel reciprocals are hoisted: `neg_inv_s` = -log2(e) / sigma, or 0 where the reference's sigma is 0 (weight 1).
+constexpr float kLog2e = 1.44269504088896341f;
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_neg_inv(float s) { return s == 0.0f ? 0.0f : -kLog2e * fast_rcp(s); }
+__device__ __forceinline__ float fast_normal_weight(v3 n0, v3 n1, float s)
+{
+    // log2(0) = -inf, s * -inf = -inf, exp2(-inf) = 0: the exact form's pow(0, s) = 0 without a branch
+    return __builtin_amdgcn_exp2f(s * __builtin_amdgcn_logf(fmaxf(dot3(n0, n1), 0.0f)));
+}
+__device__ __forceinline__ float fast_exp_weight(float a, float b, float neg_inv_s) { return __builtin_amdgcn_exp2f(fabsf(a - b) * neg_inv_s); }
+// 1 / length(float2(dx, dy)) of the 7 x 7 taps, 0 for the centre (the reference's sigma * 0: weight 1)
+struct TapInv7
+{
+    float v[7][7];
+};
+constexpr TapInv7 make_inv7()
+{
+    TapInv7 t{};
+    for (int dy = -3; dy <= 3; ++dy)
+        for (int dx = -3; dx <= 3; ++dx) t.v[dy + 3][dx + 3] = (dx || dy) ? 1.0f / csqrt((float)(dx * dx + dy * dy)) : 0.0f;
+    return t;
+}
+__constant__ TapInv7 kInv7 = make_inv7();
 // color_space.h
 __device__ __forceinline__ v3 rgb2ycocg(v3 c)
 {
@@ -153,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_decode_normals(const float4* nd, flo
 // UP (UPSCALE2X, :36-46, :83-87): the grid and `color` are half resolution and the G-buffer is read at (xy << 1) + (ox, oy).
 // The taps are bounded by the FULL window size, as the host passes it (raytracing_system.cpp:1562-1569): a tap beyond the
 // half-resolution image reads a G-buffer texel outside the window, i.e. depth 0, and is skipped as background.
-template <bool UP>
+template <bool UP, bool FAST = false>
 __global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color, Img nd, float4* out, int ox, int oy)
 {
     uint32_t x, y;
@@ -169,6 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color,
     else
     {
         const float s_depth = cd * s.gather_depth_sigma, s_normal = s.gather_normal_sigma, s_luma = s.gather_luma_sigma;
+        const float f_depth = FAST ? fast_neg_inv(s_depth) : 0.f, f_luma = FAST ? fast_neg_inv(s_luma) : 0.f, lcc = luminance(cc);
         v3          filtered = mk3(0.f, 0.f, 0.f);
         float       total    = 0.0f;
         for (int dy = -3; dy <= 3; ++dy)
@@ -180,12 +231,15 @@ __global__ __launch_bounds__(kBlock) void k_gather(PostSettingsDev s, Img color,
                 const float4 g = UP ? ldi(nd, (sx << 1) + ox, (sy << 1) + oy) : ldi(nd, sx, sy);
                 if (g.w < 1e-5f) continue;
                 const v3    n   = xyz(g);
-                const float len = kLen7.v[dy + 3][dx + 3];
-                const float wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * len) * luma_weight(luminance(cc), luminance(c), s_luma);
+                float       wgt;
+                if (FAST)
+                    wgt = fast_normal_weight(cn, n, s_normal) * fast_exp_weight(cd, g.w, f_depth * kInv7.v[dy + 3][dx + 3]) * fast_exp_weight(lcc, luminance(c), f_luma);
+                else
+                    wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * kLen7.v[dy + 3][dx + 3]) * luma_weight(lcc, luminance(c), s_luma);
                 filtered = filtered + c * wgt;
                 total += wgt;
             }
-        const v3 r = (total < kEpsPost) ? cc : div3(filtered, total);
+        const v3 r = (total < kEpsPost) ? cc : (FAST ? filtered * fast_rcp(total) : div3(filtered, total));
         res        = make_float4(r.x, r.y, r.z, 1.0f);
     }
     out[(size_t)y * color.w + x] = res;
@@ -253,7 +307,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32
         return;
     }
     float          alpha    = s.temporal_upscale_feedback;
-    const v3       history  = resample_bicubic(color_history, puv);
+    const BicubicTaps taps  = bicubic_taps(puv, color_history.w, color_history.h);  // both histories are W x H images
+    const v3       history  = resample_bicubic(color_history, taps);
     uint32_t       hist_len = sat_uint(ld(moments_history, sat_uint(floorf(pxy.x)), sat_uint(floorf(pxy.y))).w);
     if (hist_len < 256u)
     {
@@ -265,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32
         alpha = 1.0f;
         hist_len -= 1u;  // uint: a length of 0 wraps and the + 1 below brings it back to 0
     }
-    const v3    mh = resample_bicubic(moments_history, puv);
+    const v3    mh = resample_bicubic(moments_history, taps);
     const float m0 = lerp1(l, mh.x, alpha), m1 = lerp1(l * l, mh.y, alpha);
     const float variance = fabsf(m1 - m0 * m0);
     out_moments[o]   = make_float4(m0, m1, 0.0f, (float)(hist_len + 1));
@@ -275,7 +330,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32
 
 __device__ __forceinline__ v3 remove_fireflies(float4 v) { return mk3(fminf(v.x, 10.0f), fminf(v.y, 10.0f), fminf(v.z, 10.0f)); }
 
-// eaw_blur.hlsl:142-223
+// eaw_blur.hlsl:142-223.  USE_VAR = the USE_VARIANCE define (:162-165): without it the pass-through pixels carry variance 0.
+template <bool USE_VAR, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_blur_disocclusion(PostSettingsDev s, Img color, Img nd, Img moments, float4* out)
 {
     uint32_t x, y;
@@ -286,10 +342,11 @@ __global__ __launch_bounds__(kBlock) void k_blur_disocclusion(PostSettingsDev s,
     const float  cd   = cg.w;
     const float4 cv   = ld(color, x, y);
     const v3     cc   = remove_fireflies(cv);
-    float4       res  = make_float4(cc.x, cc.y, cc.z, cv.w);
+    float4       res  = make_float4(cc.x, cc.y, cc.z, USE_VAR ? cv.w : 0.0f);
     if (!(cd < 1e-5f || hist >= 8.0f))
     {
         const float s_depth = cd * s.eaw_depth_sigma, s_normal = s.eaw_normal_sigma, s_luma = s.eaw_luma_sigma;
+        const float f_depth = FAST ? fast_neg_inv(s_depth) : 0.f, f_luma = FAST ? fast_neg_inv(s_luma) : 0.f, lcc = luminance(cc);
         v3          filtered = mk3(0.f, 0.f, 0.f);
         float       fm0 = 0.0f, fm1 = 0.0f, total = 0.0f;
         for (int dy = -3; dy <= 3; ++dy)
@@ -302,22 +359,30 @@ __global__ __launch_bounds__(kBlock) void k_blur_disocclusion(PostSettingsDev s,
                 const float4 m = ldi(moments, sx, sy);
                 if (g.w < 1e-5f) continue;
                 const v3    n   = xyz(g);
-                const float len = kLen7.v[dy + 3][dx + 3];
-                const float wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * len) * luma_weight(luminance(cc), luminance(c), s_luma);
+                float       wgt;
+                if (FAST)
+                    wgt = fast_normal_weight(cn, n, s_normal) * fast_exp_weight(cd, g.w, f_depth * kInv7.v[dy + 3][dx + 3]) * fast_exp_weight(lcc, luminance(c), f_luma);
+                else
+                    wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * kLen7.v[dy + 3][dx + 3]) * luma_weight(lcc, luminance(c), s_luma);
                 filtered = filtered + c * wgt;
                 fm0 += wgt * m.x, fm1 += wgt * m.y;
                 total += wgt;
             }
-        const v3    r  = (total < kEpsPost) ? cc : div3(filtered, total);
-        const float m0 = (total < kEpsPost) ? 0.0f : fm0 / total, m1 = (total < kEpsPost) ? 0.0f : fm1 / total;
-        const float boost = 8.0f / hist;
+        const float rt = FAST ? fast_rcp(total) : 0.f;
+        const v3    r  = (total < kEpsPost) ? cc : (FAST ? filtered * rt : div3(filtered, total));
+        const float m0 = (total < kEpsPost) ? 0.0f : (FAST ? fm0 * rt : fm0 / total), m1 = (total < kEpsPost) ? 0.0f : (FAST ? fm1 * rt : fm1 / total);
+        const float boost = FAST ? 8.0f * fast_rcp(hist) : 8.0f / hist;
         res = make_float4(r.x, r.y, r.z, boost * fabsf(m1 - m0 * m0));
     }
     out[(size_t)y * color.w + x] = res;
 }
 
-// eaw_blur.hlsl:48-137
-__global__ __launch_bounds__(kBlock) void k_blur(PostSettingsDev s, uint32_t stride, Img color, Img nd, float4* out)
+// eaw_blur.hlsl:48-137.  USE_VAR = the USE_VARIANCE define (:68, :114, :127).  COMBINE: the chain's last a-trous pass also does
+// CombineIllumination (combine_illumination.hlsl:16-30, type 0) on its result -- the operations of k_combine on the same
+// operands, so the same bits, and the blurred image is neither written nor read back in between.
+template <bool USE_VAR, bool FAST, bool COMBINE>
+__global__ __launch_bounds__(kBlock) void k_blur(PostSettingsDev s, uint32_t stride, Img color, Img nd, float4* out, const float4* albedo,
+                                                 const float4* direct)
 {
     uint32_t x, y;
     if (!pixel_of_thread(color.w, color.h, x, y)) return;
@@ -326,13 +391,14 @@ __global__ __launch_bounds__(kBlock) void k_blur(PostSettingsDev s, uint32_t str
     const float  cd   = cg.w;
     const float4 cv   = ld(color, x, y);
     const v3     cc   = remove_fireflies(cv);
-    const float  cvar = cv.w;
+    const float  cvar = USE_VAR ? cv.w : 0.0f;
     float4       res  = make_float4(cc.x, cc.y, cc.z, cvar);
     if (!(cd < 1e-5f))
     {
         const float kw[3]   = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
         const float s_depth = cd * (float)stride * s.eaw_depth_sigma, s_normal = s.eaw_normal_sigma;
         const float s_luma  = s.eaw_luma_sigma * sqrtf(fmaxf(0.0f, cvar + kEpsPost));
+        const float f_depth = FAST ? fast_neg_inv(s_depth) : 0.f, f_luma = FAST ? fast_neg_inv(s_luma) : 0.f, lcc = luminance(cc);
         v3          filtered = mk3(0.f, 0.f, 0.f);
         float       fvar = 0.0f, total = 0.0f;
 #pragma unroll
@@ -347,20 +413,362 @@ __global__ __launch_bounds__(kBlock) void k_blur(PostSettingsDev s, uint32_t str
                 const float4 g = ldi(nd, sx, sy);
                 if (g.w < 1e-5f) continue;
                 const v3    n   = xyz(g);
-                const float lw  = luma_weight(luminance(cc), luminance(c), s_luma);
-                const float hw  = kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy];
-                const float len = sqrtf((float)(dx * dx + dy * dy));
-                const float wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * len);
+                float       lw = 1.0f, hw = 1.0f, wgt;
+                if (USE_VAR)
+                {
+                    lw = FAST ? fast_exp_weight(lcc, luminance(c), f_luma) : luma_weight(lcc, luminance(c), s_luma);
+                    hw = kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy];
+                }
+                if (FAST)
+                    wgt = fast_normal_weight(cn, n, s_normal) * fast_exp_weight(cd, g.w, f_depth * kInv7.v[dy + 3][dx + 3]);
+                else
+                    wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * sqrtf((float)(dx * dx + dy * dy)));
                 const float k   = wgt * hw * lw;
                 filtered = filtered + c * k;
                 total += k;
-                fvar += hw * hw * wgt * wgt * lw * lw * v.w;
+                if (USE_VAR) fvar += hw * hw * wgt * wgt * lw * lw * v.w;
             }
-        const v3    r  = (total < kEpsPost) ? cc : div3(filtered, total);
-        const float rv = (total < kEpsPost) ? cvar : fvar / (total * total);
+        const float rt = FAST ? fast_rcp(total) : 0.f;
+        const v3    r  = (total < kEpsPost) ? cc : (FAST ? filtered * rt : div3(filtered, total));
+        const float rv = (total < kEpsPost) ? cvar : (FAST ? fvar * (rt * rt) : fvar / (total * total));
         res = make_float4(r.x, r.y, r.z, rv);
     }
-    out[(size_t)y * color.w + x] = res;
+    const size_t o = (size_t)y * color.w + x;
+    if (COMBINE)
+    {
+        const float4 a = albedo[o], d = direct[o];
+        res = make_float4(res.x * a.x + d.x, res.y * a.y + d.y, res.z * a.z + d.z, 1.0f * a.w + d.w);
+    }
+    out[o] = res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CapPostSettings::fast_weights: the three 7x7 / 5x5 stencils restructured for the toleranced mode.  With the weights at ~12
+// instructions the per-pixel kernels above are no longer bound by arithmetic but by their control flow (two skip branches per tap,
+// each followed by dependent loads: 90 us per a-trous pass against 143 exact, where the instruction count fell 2.7 x) and by the
+// CU's 64 B/clk load path (50 x 16 B per pixel).  So:
+//   * no branches in the tap loop: a tap outside the image or on the background gets weight 0 by a select;
+//   * stride 1 (Gather, BlurDisocclusion, the first a-trous pass): the workgroup's 32 x 8 pixels + halo are staged once in LDS --
+//     (colour | variance) and (normal | depth) as two float4 tiles, texels outside the image stored as background -- and the taps
+//     are ds_read_b128 at compile-time offsets;
+//   * strides 3 / 5 / 7: the same loop on global loads with clamped coordinates (all in bounds, so the compiler batches them).
+// Same formulas as the exact kernels, other evaluation order nowhere: only the weights' arithmetic differs.
+// ------------------------------------------------------------------------------------------------
+enum FastKind
+{
+    kFastGather = 0,
+    kFastDisocclusion,
+    kFastBlur
+};
+
+struct FastCenter
+{
+    v3    cn, cc;
+    float cd, lcc, f_depth, f_luma, s_normal;
+};
+
+// weight of one tap (0 when it does not take part); hw = the a-trous kernel weight where the pass has one
+// The product of the three weights as ONE exponential: 2^(s_n log2(n.n') - |d - d'| / s_d - |l - l'| / s_l) -- one v_log_f32 and one
+// v_exp_f32 per tap (quarter rate: a transcendental costs four plain instructions) instead of one and three.  log2(0) = -inf
+// carries a normal weight of 0 through the sum.
+template <bool LUMA>
+__device__ __forceinline__ float fast_tap_weight(const FastCenter& k, float4 g, v3 c, float inv_len, bool inside)
+{
+    float e = k.s_normal * __builtin_amdgcn_logf(fmaxf(dot3(k.cn, xyz(g)), 0.0f));
+    e       = fmaf(fabsf(k.cd - g.w), k.f_depth * inv_len, e);
+    if (LUMA) e = fmaf(fabsf(k.lcc - luminance(c)), k.f_luma, e);
+    const float w = __builtin_amdgcn_exp2f(e);
+    return (inside && !(g.w < 1e-5f)) ? w : 0.0f;
+}
+
+template <int KIND, int R, bool USE_VAR, bool COMBINE>
+__global__ __launch_bounds__(kBlock) void k_stencil_fast_lds(PostSettingsDev s, Img color, Img nd, Img moments, float4* out, const float4* albedo,
+                                                             const float4* direct)
+{
+    constexpr int TW = 32 + 2 * R, TH = 8 + 2 * R;
+    __shared__ float4 t_col[TW * TH], t_nd[TW * TH];
+    __shared__ float2 t_mom[KIND == kFastDisocclusion ? TW * TH : 1];
+    const int W = (int)color.w, H = (int)color.h;
+    const int x0 = (int)(blockIdx.x * 32u) - R, y0 = (int)(blockIdx.y * 8u) - R;
+    uint32_t  x, y;
+    const bool in_image = pixel_of_thread(color.w, color.h, x, y);
+    // BlurDisocclusion passes most pixels through once the history is eight frames long: a workgroup of such pixels stages nothing
+    bool needs_taps = true;
+    if (KIND == kFastDisocclusion)
+    {
+        const bool mine = in_image && !(ld(nd, x, y).w < 1e-5f || ld(moments, x, y).w >= 8.0f);
+        needs_taps      = __syncthreads_or(mine ? 1 : 0) != 0;
+    }
+    if (needs_taps)
+    {
+        for (int e = (int)threadIdx.x; e < TW * TH; e += (int)kBlock)
+        {
+            const int  sx = x0 + e % TW, sy = y0 + e / TW;
+            const bool in = sx >= 0 && sy >= 0 && sx < W && sy < H;
+            float4     c = make_float4(0.f, 0.f, 0.f, 0.f), g = c;
+            float2     mm = make_float2(0.f, 0.f);
+            if (in)
+            {
+                const size_t o = (size_t)sy * W + sx;
+                c = color.p[o], g = nd.p[o];
+                if (KIND != kFastGather) c = make_float4(fminf(c.x, 10.0f), fminf(c.y, 10.0f), fminf(c.z, 10.0f), c.w);  // remove_fireflies
+                if (KIND == kFastDisocclusion)
+                {
+                    const float4 m = moments.p[o];
+                    mm             = make_float2(m.x, m.y);
+                }
+            }
+            // outside the image: depth 0 = background, skipped by the taps like the exact kernels' bounds test -- EVERY plane of the
+            // entry is defined: a tap of weight 0 still multiplies what it reads (0 x a stale NaN left in LDS by another kernel
+            // poisoned the border's moments when this entry kept whatever the LDS held)
+            t_col[e] = c, t_nd[e] = g;
+            if (KIND == kFastDisocclusion) t_mom[e] = mm;
+        }
+        __syncthreads();
+    }
+    if (!in_image) return;
+    const size_t o  = (size_t)y * W + x;
+    const int    lc = ((int)(threadIdx.x >> 5) + R) * TW + (int)(threadIdx.x & 31u) + R;
+    float4       cv, cg;
+    if (needs_taps)
+        cv = t_col[lc], cg = t_nd[lc];
+    else
+    {
+        cv = color.p[o], cg = nd.p[o];
+        cv = make_float4(fminf(cv.x, 10.0f), fminf(cv.y, 10.0f), fminf(cv.z, 10.0f), cv.w);
+    }
+    FastCenter k;
+    k.cn = xyz(cg), k.cd = cg.w, k.cc = xyz(cv), k.lcc = luminance(k.cc);
+    const float cvar = (KIND == kFastGather) ? 0.0f : (USE_VAR ? cv.w : 0.0f);
+    float4      res  = make_float4(k.cc.x, k.cc.y, k.cc.z, cvar);
+    const float hist = KIND == kFastDisocclusion ? ld(moments, x, y).w : 0.0f;
+    const bool  pass = k.cd < 1e-5f || (KIND == kFastDisocclusion && hist >= 8.0f);
+    if (KIND == kFastGather) res.w = pass ? 0.0f : 1.0f;
+    if (!pass)
+    {
+        const float sd = KIND == kFastGather ? s.gather_depth_sigma : s.eaw_depth_sigma;
+        float       sl = KIND == kFastGather ? s.gather_luma_sigma : s.eaw_luma_sigma;
+        if (KIND == kFastBlur) sl *= sqrtf(fmaxf(0.0f, cvar + kEpsPost));
+        k.s_normal = KIND == kFastGather ? s.gather_normal_sigma : s.eaw_normal_sigma;
+        k.f_depth = fast_neg_inv(k.cd * sd), k.f_luma = fast_neg_inv(sl);
+        constexpr bool LUMA = KIND != kFastBlur || USE_VAR;
+        const float    kw[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
+        v3             filtered = mk3(0.f, 0.f, 0.f);
+        float          total = 0.0f, a0 = 0.0f, a1 = 0.0f;  // a0: variance sum (Blur) or first moment (Disocclusion); a1: second moment
+#pragma unroll
+        for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+            for (int dx = -R; dx <= R; ++dx)
+            {
+                const int    e = lc + dy * TW + dx;
+                const float4 v = t_col[e], g = t_nd[e];
+                const v3     c = xyz(v);
+                const float  w = fast_tap_weight<LUMA>(k, g, c, kInv7.v[dy + 3][dx + 3], true);
+                const float  hw = (KIND == kFastBlur && USE_VAR) ? kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy] : 1.0f;
+                const float  kk = w * hw;
+                filtered = filtered + c * kk;
+                total += kk;
+                if (KIND == kFastBlur && USE_VAR) a0 += (kk * kk) * v.w;
+                if (KIND == kFastDisocclusion)
+                {
+                    const float2 m = t_mom[e];
+                    a0 += w * m.x, a1 += w * m.y;
+                }
+            }
+        const bool  empty = total < kEpsPost;
+        const float rt    = fast_rcp(total);
+        const v3    r     = empty ? k.cc : filtered * rt;
+        float       rw    = res.w;
+        if (KIND == kFastBlur) rw = empty ? cvar : a0 * (rt * rt);
+        if (KIND == kFastDisocclusion)
+        {
+            const float m0 = empty ? 0.0f : a0 * rt, m1 = empty ? 0.0f : a1 * rt;
+            rw             = (8.0f * fast_rcp(hist)) * fabsf(m1 - m0 * m0);
+        }
+        res = make_float4(r.x, r.y, r.z, rw);
+    }
+    if (COMBINE)
+    {
+        const float4 a = albedo[o], d = direct[o];
+        res = make_float4(res.x * a.x + d.x, res.y * a.y + d.y, res.z * a.z + d.z, 1.0f * a.w + d.w);
+    }
+    out[o] = res;
+}
+
+// The a-trous passes of stride 3, 5, 7 from an LDS tile.  From global memory (k_blur_fast_strided below, kept as the fallback
+// for images narrower than a tile) these passes sit at 74 us whatever is done to their instruction stream: a 32 x 8 workgroup's 25
+// taps span (32 + 4 s) x (8 + 4 s) texels, more than the CU's 32-KB L1 holds beside its neighbours', so the 800 B per pixel come
+// from L2 (22 TB/s achieved).  A 64 x 16 workgroup stages that footprint once -- 4.0 texels per pixel at stride 7 instead of 25,
+// 129 KB of the CU's 160 KB of LDS -- and its taps are ds_read_b128.
+constexpr int kFastTileW = 64, kFastTileH = 16;
+// (STRIDE is a template parameter so that the tile is a static array: 68, 97 and 129.5 KB for strides 3, 5, 7 -- no dynamic-LDS
+// attribute to set before the launch)
+template <int STRIDE, bool USE_VAR, bool COMBINE>
+__global__ __launch_bounds__(kFastTileW * kFastTileH) void k_blur_fast_tile(PostSettingsDev s, Img color, Img nd, float4* out, const float4* albedo,
+                                                                            const float4* direct)
+{
+    constexpr int stride = STRIDE, halo = 2 * STRIDE;
+    constexpr int TW = kFastTileW + 2 * halo, TH = kFastTileH + 2 * halo;
+    __shared__ float4 t_col[TW * TH], t_nd[TW * TH];
+    const int W = (int)color.w, H = (int)color.h;
+    const int x0 = (int)blockIdx.x * kFastTileW - halo, y0 = (int)blockIdx.y * kFastTileH - halo;
+    for (int e = (int)threadIdx.x; e < TW * TH; e += kFastTileW * kFastTileH)
+    {
+        const int  ty = e / TW, tx = e - ty * TW;
+        const int  sx = x0 + tx, sy = y0 + ty;
+        float4     c = make_float4(0.f, 0.f, 0.f, 0.f), g = c;
+        if (sx >= 0 && sy >= 0 && sx < W && sy < H)
+        {
+            const size_t o = (size_t)sy * W + sx;
+            c = color.p[o], g = nd.p[o];
+            c = make_float4(fminf(c.x, 10.0f), fminf(c.y, 10.0f), fminf(c.z, 10.0f), c.w);  // remove_fireflies
+        }
+        t_col[e] = c, t_nd[e] = g;  // outside the image: depth 0 = background
+    }
+    __syncthreads();
+    const int lx = (int)(threadIdx.x % kFastTileW), ly = (int)(threadIdx.x / kFastTileW);
+    const int x = (int)blockIdx.x * kFastTileW + lx, y = (int)blockIdx.y * kFastTileH + ly;
+    if (x >= W || y >= H) return;
+    const size_t o  = (size_t)y * W + x;
+    const int    lc = (ly + halo) * TW + lx + halo;
+    const float4 cv = t_col[lc], cg = t_nd[lc];
+    FastCenter   k;
+    k.cn = xyz(cg), k.cd = cg.w, k.cc = xyz(cv), k.lcc = luminance(k.cc);
+    const float cvar = USE_VAR ? cv.w : 0.0f;
+    float4      res  = make_float4(k.cc.x, k.cc.y, k.cc.z, cvar);
+    if (!(k.cd < 1e-5f))
+    {
+        k.s_normal = s.eaw_normal_sigma;
+        k.f_depth  = fast_neg_inv(k.cd * (float)stride * s.eaw_depth_sigma);
+        k.f_luma   = fast_neg_inv(s.eaw_luma_sigma * sqrtf(fmaxf(0.0f, cvar + kEpsPost)));
+        const float kw[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
+        v3          filtered = mk3(0.f, 0.f, 0.f);
+        float       total = 0.0f, fvar = 0.0f;
+        constexpr int row_step = stride * TW;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx)
+            {
+                const int    e = lc + dy * row_step + dx * stride;
+                const float4 v = t_col[e], g = t_nd[e];
+                const v3     c = xyz(v);
+                const float  w = fast_tap_weight<USE_VAR>(k, g, c, kInv7.v[dy + 3][dx + 3], true);
+                const float  hw = USE_VAR ? kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy] : 1.0f;
+                const float  kk = w * hw;
+                filtered = filtered + c * kk;
+                total += kk;
+                if (USE_VAR) fvar += (kk * kk) * v.w;
+            }
+        const bool  empty = total < kEpsPost;
+        const float rt    = fast_rcp(total);
+        const v3    r     = empty ? k.cc : filtered * rt;
+        res = make_float4(r.x, r.y, r.z, empty ? cvar : fvar * (rt * rt));
+    }
+    if (COMBINE)
+    {
+        const float4 a = albedo[o], d = direct[o];
+        res = make_float4(res.x * a.x + d.x, res.y * a.y + d.y, res.z * a.z + d.z, 1.0f * a.w + d.w);
+    }
+    out[o] = res;
+}
+
+// the a-trous passes of stride 3, 5, 7
+template <bool USE_VAR, bool COMBINE>
+__global__ __launch_bounds__(kBlock, 4) void k_blur_fast_strided(PostSettingsDev s, int stride, Img color, Img nd, float4* out, const float4* albedo,
+                                                                  const float4* direct)
+{
+    uint32_t x, y;
+    if (!pixel_of_thread(color.w, color.h, x, y)) return;
+    const int    W = (int)color.w, H = (int)color.h;
+    const size_t o = (size_t)y * W + x;
+    const float4 cg = nd.p[o], cv0 = color.p[o];
+    FastCenter   k;
+    k.cn = xyz(cg), k.cd = cg.w, k.cc = remove_fireflies(cv0), k.lcc = luminance(k.cc);
+    const float cvar = USE_VAR ? cv0.w : 0.0f;
+    float4      res  = make_float4(k.cc.x, k.cc.y, k.cc.z, cvar);
+    if (!(k.cd < 1e-5f))
+    {
+        k.s_normal = s.eaw_normal_sigma;
+        k.f_depth  = fast_neg_inv(k.cd * (float)stride * s.eaw_depth_sigma);
+        k.f_luma   = fast_neg_inv(s.eaw_luma_sigma * sqrtf(fmaxf(0.0f, cvar + kEpsPost)));
+        const float kw[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
+        v3          filtered = mk3(0.f, 0.f, 0.f);
+        float       total = 0.0f, fvar = 0.0f;
+        // One row of taps (ten loads) at a time, the NEXT row's loads issued before this row's arithmetic (fully unrolled, the 50
+        // independent loads are all hoisted and 128 registers spill; row by row without the prefetch every row exposes a full L2
+        // round trip: 81 us per pass)
+        float4 v[5], g[5], vn[5], gn[5];
+        // a tap outside the image is loaded from the clamped position and turned into a background texel (depth 0, colour 0) on the
+        // spot: no per-tap flags to keep (ten lane masks per row in flight exhausted the scalar registers)
+        // the five tap columns are the same in every row: clamped offsets and in-image masks once per pixel
+        uint32_t cx[5], mx[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+        {
+            const int sx = (int)x + (i - 2) * stride;
+            cx[i]        = (uint32_t)max(0, min(sx, W - 1));
+            mx[i]        = (sx >= 0 && sx < W) ? ~0u : 0u;
+        }
+        auto load_row = [&](int dy, float4* rv, float4* rg) {
+            const int      sy  = (int)y + dy * stride;
+            const uint32_t my  = (sy >= 0 && sy < H) ? ~0u : 0u;
+            const size_t   row = (size_t)max(0, min(sy, H - 1)) * W;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+            {
+                const size_t t = row + cx[i];
+                const float4 c = color.p[t], n = nd.p[t];
+                // (bit masks, not selects: the compiler turns a select of a loaded value into a branch around the load)
+                const uint32_t m = mx[i] & my;
+                rv[i] = make_float4(u2f(f2u(c.x) & m), u2f(f2u(c.y) & m), u2f(f2u(c.z) & m), u2f(f2u(c.w) & m));
+                rg[i] = make_float4(n.x, n.y, n.z, u2f(f2u(n.w) & m));
+            }
+        };
+        auto tap_row = [&](int dy, const float4* rv, const float4* rg) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+            {
+                const int   dx = i - 2;
+                const v3    c  = remove_fireflies(rv[i]);
+                const float w  = fast_tap_weight<USE_VAR>(k, rg[i], c, kInv7.v[dy + 3][dx + 3], true);
+                const float hw = USE_VAR ? kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy] : 1.0f;
+                const float kk = w * hw;
+                filtered = filtered + c * kk;
+                total += kk;
+                if (USE_VAR) fvar += (kk * kk) * rv[i].w;
+            }
+        };
+        // straight-line ping-pong over the five rows: a row's loads are in flight under the previous row's arithmetic; the
+        // scheduling barriers keep the compiler from hoisting later rows' loads (three rows live spill)
+        load_row(-2, v, g);
+        load_row(-1, vn, gn);
+        __builtin_amdgcn_sched_barrier(0);
+        tap_row(-2, v, g);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row(0, v, g);
+        __builtin_amdgcn_sched_barrier(0);
+        tap_row(-1, vn, gn);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row(1, vn, gn);
+        __builtin_amdgcn_sched_barrier(0);
+        tap_row(0, v, g);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row(2, v, g);
+        __builtin_amdgcn_sched_barrier(0);
+        tap_row(1, vn, gn);
+        tap_row(2, v, g);
+        const bool  empty = total < kEpsPost;
+        const float rt    = fast_rcp(total);
+        const v3    r     = empty ? k.cc : filtered * rt;
+        res = make_float4(r.x, r.y, r.z, empty ? cvar : fvar * (rt * rt));
+    }
+    if (COMBINE)
+    {
+        const float4 a = albedo[o], d = direct[o];
+        res = make_float4(res.x * a.x + d.x, res.y * a.y + d.y, res.z * a.z + d.z, 1.0f * a.w + d.w);
+    }
+    out[o] = res;
 }
 
 // combine_illumination.hlsl:16-30, type 0, in place
@@ -477,11 +885,24 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     const uint32_t IW = up ? W >> 1 : W, IH = up ? H >> 1 : H;
     const Img      indirect_in{a.indirect, IW, IH};
     const int      ox = (int)((a.frame_count % 4u) / 2u), oy = (int)((a.frame_count % 4u) % 2u);
+    const bool fast = a.settings.fast_weights != 0, use_var = a.settings.use_variance != 0;
     if (a.settings.gather && up)
-        hipLaunchKernelGGL(k_gather<true>, dim3((IW + 31) / 32, (IH + 7) / 8), block, 0, stream, a.settings, indirect_in, img(a.normals),
-                           a.indirect_temp, ox, oy);
+    {
+        if (fast)
+            hipLaunchKernelGGL((k_gather<true, true>), dim3((IW + 31) / 32, (IH + 7) / 8), block, 0, stream, a.settings, indirect_in, img(a.normals),
+                               a.indirect_temp, ox, oy);
+        else
+            hipLaunchKernelGGL((k_gather<true, false>), dim3((IW + 31) / 32, (IH + 7) / 8), block, 0, stream, a.settings, indirect_in, img(a.normals),
+                               a.indirect_temp, ox, oy);
+    }
     else if (a.settings.gather)
-        hipLaunchKernelGGL(k_gather<false>, grid, block, 0, stream, a.settings, indirect_in, img(a.normals), a.indirect_temp, 0, 0);
+    {
+        if (fast)
+            hipLaunchKernelGGL((k_stencil_fast_lds<kFastGather, 3, true, false>), grid, block, 0, stream, a.settings, indirect_in, img(a.normals),
+                               Img{nullptr, 0, 0}, a.indirect_temp, nullptr, nullptr);
+        else
+            hipLaunchKernelGGL((k_gather<false, false>), grid, block, 0, stream, a.settings, indirect_in, img(a.normals), a.indirect_temp, 0, 0);
+    }
     else
         (void)hipMemcpyAsync(a.indirect_temp, a.indirect, sizeof(float4) * (size_t)IW * IH, hipMemcpyDeviceToDevice, stream);
     // IntegrateTemporally (cpp:1283-1342)
@@ -493,21 +914,82 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     mark(2);
     if (a.settings.denoise)
     {
-        hipLaunchKernelGGL(k_blur_disocclusion, grid, block, 0, stream, a.settings, img(a.indirect_history[dst]), img(a.normals),
-                           img(a.moments_history[dst]), a.temp[0]);
-        hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 1u, img(a.temp[0]), img(a.normals), a.temp[1]);
-        hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 3u, img(a.temp[1]), img(a.normals), a.temp[0]);
+        // (USE_VAR, FAST) variants; the last a-trous pass combines (its own timestamp label then covers nothing: the reference's
+        // "Combine illumination" span is part of "EAW" here)
+        auto blur = [&](uint32_t stride, const float4* in, float4* out, bool last) {
+            if (fast)
+            {
+                const Img none{nullptr, 0, 0};
+                if (stride == 1u && use_var)
+                    hipLaunchKernelGGL((k_stencil_fast_lds<kFastBlur, 2, true, false>), grid, block, 0, stream, a.settings, img(in), img(a.normals), none, out, nullptr, nullptr);
+                else if (stride == 1u)
+                    hipLaunchKernelGGL((k_stencil_fast_lds<kFastBlur, 2, false, false>), grid, block, 0, stream, a.settings, img(in), img(a.normals), none, out, nullptr, nullptr);
+                else if (W >= (uint32_t)kFastTileW && H >= (uint32_t)kFastTileH && (stride == 3u || stride == 5u || stride == 7u))
+                {
+                    const dim3 tgrid((W + kFastTileW - 1) / kFastTileW, (H + kFastTileH - 1) / kFastTileH), tblock(kFastTileW * kFastTileH);
+#define CAP_TILE(S, UV, CB)                                                                                                            \
+    hipLaunchKernelGGL((k_blur_fast_tile<S, UV, CB>), tgrid, tblock, 0, stream, a.settings, img(in), img(a.normals), out, (CB) ? a.albedo : nullptr, \
+                       (CB) ? a.direct : nullptr)
+#define CAP_TILE_S(S)                                                                                                                  \
+    {                                                                                                                                  \
+        if (use_var && last) CAP_TILE(S, true, true);                                                                                  \
+        else if (use_var) CAP_TILE(S, true, false);                                                                                    \
+        else if (last) CAP_TILE(S, false, true);                                                                                       \
+        else CAP_TILE(S, false, false);                                                                                                \
+    }
+                    if (stride == 3u) CAP_TILE_S(3)
+                    else if (stride == 5u) CAP_TILE_S(5)
+                    else CAP_TILE_S(7)
+#undef CAP_TILE_S
+#undef CAP_TILE
+                }
+                else if (use_var && last)
+                    hipLaunchKernelGGL((k_blur_fast_strided<true, true>), grid, block, 0, stream, a.settings, (int)stride, img(in), img(a.normals), out, a.albedo, a.direct);
+                else if (use_var)
+                    hipLaunchKernelGGL((k_blur_fast_strided<true, false>), grid, block, 0, stream, a.settings, (int)stride, img(in), img(a.normals), out, nullptr, nullptr);
+                else if (last)
+                    hipLaunchKernelGGL((k_blur_fast_strided<false, true>), grid, block, 0, stream, a.settings, (int)stride, img(in), img(a.normals), out, a.albedo, a.direct);
+                else
+                    hipLaunchKernelGGL((k_blur_fast_strided<false, false>), grid, block, 0, stream, a.settings, (int)stride, img(in), img(a.normals), out, nullptr, nullptr);
+                return;
+            }
+#define CAP_BLUR(UV, F)                                                                                                                            \
+    if (last)                                                                                                                                      \
+        hipLaunchKernelGGL((k_blur<UV, F, true>), grid, block, 0, stream, a.settings, stride, img(in), img(a.normals), out, a.albedo, a.direct);   \
+    else                                                                                                                                           \
+        hipLaunchKernelGGL((k_blur<UV, F, false>), grid, block, 0, stream, a.settings, stride, img(in), img(a.normals), out, nullptr, nullptr)
+            if (use_var) { CAP_BLUR(true, false); }
+            else { CAP_BLUR(false, false); }
+#undef CAP_BLUR
+        };
+#define CAP_DISOCC(UV, F)                                                                                                                     \
+    hipLaunchKernelGGL((k_blur_disocclusion<UV, F>), grid, block, 0, stream, a.settings, img(a.indirect_history[dst]), img(a.normals),        \
+                       img(a.moments_history[dst]), a.temp[0])
+        if (fast && use_var)
+            hipLaunchKernelGGL((k_stencil_fast_lds<kFastDisocclusion, 3, true, false>), grid, block, 0, stream, a.settings, img(a.indirect_history[dst]),
+                               img(a.normals), img(a.moments_history[dst]), a.temp[0], nullptr, nullptr);
+        else if (fast)
+            hipLaunchKernelGGL((k_stencil_fast_lds<kFastDisocclusion, 3, false, false>), grid, block, 0, stream, a.settings, img(a.indirect_history[dst]),
+                               img(a.normals), img(a.moments_history[dst]), a.temp[0], nullptr, nullptr);
+        else if (use_var) { CAP_DISOCC(true, false); }
+        else { CAP_DISOCC(false, false); }
+#undef CAP_DISOCC
+        blur(1u, a.temp[0], a.temp[1], false);
+        blur(3u, a.temp[1], a.temp[0], !a.settings.eaw5);
         if (a.settings.eaw5)
         {
-            hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 5u, img(a.temp[0]), img(a.normals), a.temp[1]);
-            hipLaunchKernelGGL(k_blur, grid, block, 0, stream, a.settings, 7u, img(a.temp[1]), img(a.normals), a.temp[0]);
+            blur(5u, a.temp[0], a.temp[1], false);
+            blur(7u, a.temp[1], a.temp[0], true);
         }
+        mark(3);
     }
     else
+    {
         (void)hipMemcpyAsync(a.temp[0], a.indirect_history[dst], bytes, hipMemcpyDeviceToDevice, stream);
-    // CombineIllumination (cpp:1400-1435)
-    mark(3);
-    hipLaunchKernelGGL(k_combine, dim3(cg), block, 0, stream, a.temp[0], a.albedo, a.direct, W * H);
+        // CombineIllumination (cpp:1400-1435)
+        mark(3);
+        hipLaunchKernelGGL(k_combine, dim3(cg), block, 0, stream, a.temp[0], a.albedo, a.direct, W * H);
+    }
     // ApplyTAA (cpp:1344-1398)
     mark(4);
     hipLaunchKernelGGL(k_taa, grid, block, 0, stream, a.settings, a.camera, a.prev_camera, img(a.temp[0]), img(a.normal_depth),

@@ -293,8 +293,9 @@ typedef struct CapPostSettings
     int32_t fast_weights;              /* false.  Not a reference option: evaluates the edge-stopping weights with the hardware's
                                           v_exp_f32 / v_log_f32 / v_rcp_f32 instead of the arithmetic contract's polynomials and IEEE
                                           divisions.  The exact mode (0) is bit-identical to the oracle; this one is held to a stated
-                                          tolerance against it (tests/test_post_gpu.py: 2e-3 relative + 1e-4 absolute on the chain's
-                                          output over a multi-frame sequence) and runs the chain about twice as fast */
+                                          tolerance against it over a multi-frame sequence (tests/test_post_gpu.py), per colour channel
+                                          with e = |fast - exact| / (|exact| + 1e-3): median e <= 2e-5, 99 % of the channels
+                                          e <= 4e-3, every channel e <= 3e-2 (TAA's variance clipping amplifies in flat regions) */
 } CapPostSettings;
 /* Runs the chain on the planes of the last frame rendered with CAP_RENDER_AOV (frame_count = that frame's index; the
  * camera is the one set for it; prev_camera = the previous frame's, CameraComponent/prev_camera of

@@ -6,7 +6,7 @@
  * pass order and buffers: src/systems/raytracing_system.cpp:262-317, 1283-1604, 1700-1790).
  *
  * The reference's default configuration (raytracing_system.h:22-27: LOWRES_INDIRECT / UPSCALE2X off, CALCULATE_VARIANCE and
- * USE_VARIANCE on) and, with OraclePostSettings::lowres_indirect, the half-resolution one (UPSCALE2X Gather and Accumulate,
+ * USE_VARIANCE on or off: OraclePostSettings::use_variance) and, with OraclePostSettings::lowres_indirect, the half-resolution one (UPSCALE2X Gather and Accumulate,
  * spatial_gather.hlsl:36-46, temporal_accumulation.hlsl:228-235, 307-313).  PARITY UNPINNED against the real renderer (no tests, no golden images; the
  * reference stores these buffers as RGBA16F, this build keeps fp32).  Stated choices where HLSL/D3D leave room:
  *   - uint(x) of a negative float saturates to 0; int(x) truncates; an out-of-bounds texture read returns 0;
@@ -405,7 +405,7 @@ void blur_disocclusion(const OraclePostSettings& s, const Image& color, const Im
             float cd   = cg.w;
             f4    cv   = color.load(x, y);
             f3    cc   = remove_fireflies(cv);
-            float cvar = cv.w;
+            float cvar = s.use_variance ? cv.w : 0.0f;  // eaw_blur.hlsl:160-165: center_variance stays 0 without USE_VARIANCE
             if (cd < 1e-5f || hist >= 8.0f)
             {
                 out.store(x, y, f4{cc.x, cc.y, cc.z, cvar});
@@ -449,7 +449,7 @@ void blur(const OraclePostSettings& s, uint32_t stride, const Image& color, cons
             float cd   = cg.w;
             f4    cv   = color.load(x, y);
             f3    cc   = remove_fireflies(cv);
-            float cvar = cv.w;
+            float cvar = s.use_variance ? cv.w : 0.0f;  // eaw_blur.hlsl:66-70
             if (cd < 1e-5f)
             {
                 out.store(x, y, f4{cc.x, cc.y, cc.z, cvar});
@@ -469,14 +469,15 @@ void blur(const OraclePostSettings& s, uint32_t stride, const Image& color, cons
                     f4 g = nd.loadi(sx, sy);
                     if (g.w < 1e-5f) continue;
                     f3    n  = oct_decode(g.x, g.y);
-                    float lw = luma_weight(luminance(cc), luminance(c), s_luma);
-                    float hw = kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy];
+                    // eaw_blur.hlsl:110-118: without USE_VARIANCE both stay 1 and no variance is filtered
+                    float lw = s.use_variance ? luma_weight(luminance(cc), luminance(c), s_luma) : 1.0f;
+                    float hw = s.use_variance ? kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy] : 1.0f;
                     float len = sqrtf((float)(dx * dx + dy * dy));
                     float wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * len);
                     float k   = wgt * hw * lw;
                     filtered = filtered + c * k;
                     total += k;
-                    fvar += hw * hw * wgt * wgt * lw * lw * v.w;
+                    if (s.use_variance) fvar += hw * hw * wgt * wgt * lw * lw * v.w;
                 }
             f3    r  = (total < kEps) ? cc : filtered / total;
             float rv = (total < kEps) ? cvar : fvar / (total * total);

@@ -71,12 +71,12 @@ def hlsl_gather(s, color, nd, x, y):  # spatial_gather.hlsl:28-109, UPSCALE2X of
     return np.append(cc if tw < EPS else fc / tw, 1.0)
 
 
-def hlsl_blur(s, stride, color, nd, x, y):  # eaw_blur.hlsl:48-137, USE_VARIANCE on
+def hlsl_blur(s, stride, color, nd, x, y):  # eaw_blur.hlsl:48-137; s.use_variance = the USE_VARIANCE define (:68, :114, :127)
     h, w = color.shape[:2]
     cg = load(nd, x, y)
     cn, cd = oct_decode(cg[:2]), cg[3]
     cv = load(color, x, y)
-    cc, cvar = np.minimum(cv[:3], 10.0), cv[3]
+    cc, cvar = np.minimum(cv[:3], 10.0), (cv[3] if s.use_variance else 0.0)
     if cd < 1e-5:
         return np.append(cc, cvar)
     kw = (1.0, 2.0 / 3.0, 1.0 / 6.0)
@@ -94,12 +94,15 @@ def hlsl_blur(s, stride, color, nd, x, y):  # eaw_blur.hlsl:48-137, USE_VARIANCE
             g = load(nd, sx, sy)
             if g[3] < 1e-5:
                 continue
-            lw = w_luma(luminance(cc), luminance(c), s_luma)
-            hw = kw[abs(dx)] * kw[abs(dy)]
+            lw, hw = 1.0, 1.0
+            if s.use_variance:
+                lw = w_luma(luminance(cc), luminance(c), s_luma)
+                hw = kw[abs(dx)] * kw[abs(dy)]
             wgt = w_normal(cn, oct_decode(g[:2]), s_normal) * w_depth(cd, g[3], s_depth * math.hypot(dx, dy))
             fc += wgt * hw * lw * c
             tw += wgt * hw * lw
-            fv += hw * hw * wgt * wgt * lw * lw * v[3]
+            if s.use_variance:
+                fv += hw * hw * wgt * wgt * lw * lw * v[3]
     if tw < EPS:
         return np.append(cc, cvar)
     return np.append(fc / tw, fv / (tw * tw))
@@ -111,7 +114,7 @@ def hlsl_blur_disocclusion(s, color, nd, moments, x, y):  # eaw_blur.hlsl:142-22
     cg = load(nd, x, y)
     cn, cd = oct_decode(cg[:2]), cg[3]
     cv = load(color, x, y)
-    cc, cvar = np.minimum(cv[:3], 10.0), cv[3]
+    cc, cvar = np.minimum(cv[:3], 10.0), (cv[3] if s.use_variance else 0.0)  # :160-165
     if cd < 1e-5 or hist >= 8:
         return np.append(cc, cvar)
     s_depth, s_normal, s_luma = cd * s.eaw_depth_sigma, s.eaw_normal_sigma, s.eaw_luma_sigma
@@ -341,18 +344,20 @@ def test_gather():
         close(out[y, x], hlsl_gather(s, color, nd, x, y), "Gather (%d, %d)" % (x, y))
 
 
+@pytest.mark.parametrize("use_variance", [1, 0])
 @pytest.mark.parametrize("stride", [1, 3, 7])
-def test_blur(stride):
+def test_blur(stride, use_variance):
     color, nd, _ = scene(2)
-    s = O.PostSettings(eaw_luma_sigma=2.0, eaw_depth_sigma=1.5, eaw_normal_sigma=32.0)
+    s = O.PostSettings(eaw_luma_sigma=2.0, eaw_depth_sigma=1.5, eaw_normal_sigma=32.0, use_variance=use_variance)
     out, _ = O.post_pass(3, s, [color, nd], arg=stride)
     for x, y in PIXELS:
         close(out[y, x], hlsl_blur(s, stride, color, nd, x, y), "Blur stride %d (%d, %d)" % (stride, x, y))
 
 
-def test_blur_disocclusion():
+@pytest.mark.parametrize("use_variance", [1, 0])
+def test_blur_disocclusion(use_variance):
     color, nd, moments = scene(3)
-    s = O.PostSettings()
+    s = O.PostSettings(use_variance=use_variance)
     out, _ = O.post_pass(2, s, [color, nd, moments])
     for x, y in PIXELS:
         close(out[y, x], hlsl_blur_disocclusion(s, color, nd, moments, x, y), "BlurDisocclusion (%d, %d)" % (x, y))
