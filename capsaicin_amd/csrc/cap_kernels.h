@@ -171,8 +171,16 @@ struct PostChainArgs
     PostSettingsDev settings;
     uint32_t        width, height, frame_count;
     CameraDev       camera, prev_camera;
-    // this frame's ray-pass outputs, row-major W*H
+    // this frame's ray-pass outputs, row-major W*H ...
     const float4 *indirect, *direct, *albedo, *normal_depth;
+    // ... or, on an unsharded context (cap_post_frame), straight from the render's tile-ordered planes: `tiled` = the screen's tile
+    // columns (0 = row-major inputs as above).  Then `tiled_indirect` / `tiled_normal_depth` are untiled by the chain's first
+    // kernel -- which decodes the normals on the way, so `normal_depth` is not needed row-major at all -- and Combine reads
+    // `direct` / `albedo` in tile order: three image round trips less per frame.
+    uint32_t      tiled;
+    const float4 *tiled_indirect, *tiled_normal_depth;
+    float4*       indirect_rowmajor;  // where the untiled indirect plane goes (the chain's `indirect` when tiled)
+    ScreenDev     screen;
     // persistent state (raytracing_system.cpp:262-317)
     float4 *indirect_history[2], *moments_history[2], *combined_history[2], *prev_normal_depth;
     // scratch

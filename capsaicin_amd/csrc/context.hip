@@ -1339,8 +1339,14 @@ int cap_post_reset(CapContext* c)
     return CAP_OK;
 }
 
-// Common tail of cap_post_frame / cap_post_frame_gathered: the chain on post_in[0..3].
-static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t frame_count, const CapCameraData* prev_camera)
+// Common tail of cap_post_frame / cap_post_frame_gathered: the chain on post_in[0..3] (row-major, assembled from the ranks'
+// gathered tiles), or -- `tiled` -- on this context's own tile-ordered planes
+struct PostTiledInputs
+{
+    const float4 *indirect, *direct, *albedo, *normal_depth;
+};
+static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t frame_count, const CapCameraData* prev_camera,
+                          const PostTiledInputs* tiled = nullptr)
 {
     PostChainArgs a{};
     a.settings = PostSettingsDev{s->gather, s->denoise, s->eaw5, s->eaw_normal_sigma, s->eaw_depth_sigma, s->eaw_luma_sigma, s->gather_normal_sigma,
@@ -1349,6 +1355,12 @@ static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t fram
     a.width = c->screen.width, a.height = c->screen.height, a.frame_count = frame_count;
     a.camera = camera_dev(c->camera), a.prev_camera = camera_dev(*prev_camera);
     a.indirect = c->post_in[0].p, a.direct = c->post_in[1].p, a.albedo = c->post_in[2].p, a.normal_depth = c->post_in[3].p;
+    if (tiled)
+    {
+        a.tiled = c->screen.tiles_x, a.screen = c->screen;
+        a.tiled_indirect = tiled->indirect, a.tiled_normal_depth = tiled->normal_depth, a.indirect_rowmajor = c->post_in[0].p;
+        a.direct = tiled->direct, a.albedo = tiled->albedo, a.normal_depth = nullptr;
+    }
     for (int k = 0; k < 2; ++k)
         a.indirect_history[k] = c->post_ihist[k].p, a.moments_history[k] = c->post_mhist[k].p, a.combined_history[k] = c->post_chist[k].p,
         a.temp[k] = c->post_temp[k].p;
@@ -1366,6 +1378,7 @@ static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t fram
         (void)hipEventRecord(m->e[pass], m->c->stream);
     };
     launch_post_chain(c->stream, a);
+    std::swap(c->post_prev_nd, c->post_normals);  // this frame's decoded normal/depth image is the next frame's previous one
     c->post_marks.push_back({marks.e[0], marks.e[1], marks.e[2], marks.e[3], marks.e[4], marks.e[5]});
     HIP_TRY(hipGetLastError());
     ++c->stats.post_frames;
@@ -1488,9 +1501,10 @@ int cap_post_frame(CapContext* c, const CapPostSettings* s, uint32_t frame_count
         launch_decimate2x(c->stream, c->image_tmp.p, c->screen.width, c->screen.height, (frame_count % 4u) / 2u, (frame_count % 4u) % 2u,
                           c->post_in[0].p);
     }
-    launch_untile4(cfg, c->screen, lowres ? nullptr : c->pl_color.p + off, c->pl_direct.p + off, c->pl_albedo.p + off, c->aov_nd.p, c->post_in[0].p,
-                   c->post_in[1].p, c->post_in[2].p, c->post_in[3].p);
-    return run_post_chain(c, s, frame_count, prev_camera);
+    // the chain takes the render's tile-ordered planes as they are (PostChainArgs::tiled): its first kernel untiles the indirect
+    // plane and decodes the normals in one pass, Combine reads direct / albedo in tile order
+    PostTiledInputs ti{lowres ? nullptr : c->pl_color.p + off, c->pl_direct.p + off, c->pl_albedo.p + off, c->aov_nd.p};
+    return run_post_chain(c, s, frame_count, prev_camera, &ti);
 }
 
 int cap_post_readback(CapContext* c, float* dst)
