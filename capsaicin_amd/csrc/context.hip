@@ -169,6 +169,16 @@ struct CapContext
         accum, image_tmp;
     DevBuf<uint32_t>   counters;  // per batch: ext[0..D], shadow[0..D]
     DevBuf<uint64_t>   shaded_counter;
+    // Second working set for batches in flight beside the first (cap_render "two lanes"): queues, planes, counters and traversal
+    // spill slices of its own, on a stream of its own.  Lane 0 is the set above on `stream`; the LAST batch of a call always runs
+    // there, so everything that reads a finished frame's planes (AOV read-backs, the reconstruction chain) finds them where it did.
+    struct Lane
+    {
+        DevBuf<float4>   hits, q_org[2], q_dir[2], q_thr[2], s_org, s_dir, s_con, pl_color, pl_direct, pl_albedo;
+        DevBuf<uint32_t> counters, stack_spill;
+    } lane1;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t  lane_ev[2] = {nullptr, nullptr}, fork_ev = nullptr, join_ev = nullptr;
     // per-frame constants of a cap_render call: a ring of device buffers fed from pinned staging, so that a call need not wait
     // for the previous one (which may still be reading its own slot)
     static constexpr int kFrameRing = 4;
@@ -445,6 +455,41 @@ int ensure_wavefront(CapContext* c, uint32_t slots, uint32_t bounces)
     }
     return CAP_OK;
 }
+
+// the second lane's working set (same sizes as lane 0's), its stream and the events that order the two
+int ensure_lane1(CapContext* c, uint32_t slots, uint32_t bounces)
+{
+    CapContext::Lane& L = c->lane1;
+    const size_t planes_np = (size_t)slots * c->screen.pixels_padded;
+    const size_t np        = planes_np + (size_t)kQueueClasses * 64;
+    HIP_TRY(L.hits.ensure(np));
+    for (int k = 0; k < 2; ++k)
+    {
+        HIP_TRY(L.q_org[k].ensure(np));
+        HIP_TRY(L.q_dir[k].ensure(np));
+        HIP_TRY(L.q_thr[k].ensure(np));
+    }
+    const size_t ring_np = (size_t)std::max(c->cu_count, 1) * 8 * (kBlock / 64) * 128;
+    HIP_TRY(L.s_org.ensure(std::max(np, ring_np)));
+    HIP_TRY(L.s_dir.ensure(np));
+    HIP_TRY(L.s_con.ensure(std::max(np, ring_np)));
+    HIP_TRY(L.pl_color.ensure(planes_np));
+    HIP_TRY(L.pl_direct.ensure(planes_np));
+    HIP_TRY(L.pl_albedo.ensure(planes_np));
+    HIP_TRY(L.counters.ensure(3 * (size_t)(bounces + 1) * kQueueClasses * kCounterStride));
+    if (c->stack_spill.n) HIP_TRY(L.stack_spill.ensure(c->stack_spill.n));
+    if (!c->stream2)
+    {
+        // (A/B switch: the second lane's stream priority -- streams of different priority never share a hardware queue)
+        if (const char* e = getenv("CAP_LANE1_PRIORITY"))
+            HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, atoi(e)));
+        else
+            HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    }
+    for (hipEvent_t* e : {&c->lane_ev[0], &c->lane_ev[1], &c->fork_ev, &c->join_ev})
+        if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return CAP_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -510,6 +555,9 @@ void cap_ctx_destroy(CapContext* c)
         if (c->frames_pinned[k]) (void)hipHostFree(c->frames_pinned[k]);
         if (c->frames_event[k]) (void)hipEventDestroy(c->frames_event[k]);
     }
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2), (void)hipStreamDestroy(c->stream2);
+    for (hipEvent_t e : {c->lane_ev[0], c->lane_ev[1], c->fork_ev, c->join_ev})
+        if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1002,6 +1050,26 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)64 << 20;
     uint32_t       slots  = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / std::max(1u, Ppad), kMaxFrameSlots));
     slots                 = std::min(slots, n_frames);
+    // Two lanes (CapContext::Lane): consecutive batches alternate between two working sets on two streams, so that the tail of
+    // one batch's launch -- the last chunks, a workgroup at a time, with most of the chip idle -- is filled by the other batch's
+    // next launch instead of waiting for the stream's next kernel (measured with two contexts side by side, tools/dual_test.py:
+    // 21.0 -> 20.55 ms per step on the headline, 3.30 -> 3.05 ms for shard 0 of 8, 28.3 -> 27.1 ms on the 262 k scene).  A call
+    // that fits one batch is cut in two halves when the halves are still large.  Per-stage timers need one stream.
+    static const bool no_two_lanes = getenv("CAP_NO_TWO_LANES") != nullptr;  // A/B switch
+    // Only on the tree path: its bounces are three launches each, and from the third bounce on they are short (the 262 k scene: 27
+    // launches per batch, the last 15 under 0.2 ms each) -- 28.3 -> 26.4 ms per 32 spp.  The small-scene path's nine long fused
+    // launches gain nothing measurable (20.45 -> 20.25 ms with the context's own stream, 20.56 -> 20.9 beside a torch stream).
+    const bool tree_path = c->traversal_mode == CAP_TRAVERSAL_EXHAUSTIVE ? false
+                                                                         : !(c->traversal_mode == CAP_TRAVERSAL_AUTO && c->tri_count <= kExhaustiveMax);
+    bool two_lanes = !no_two_lanes && tree_path && c->bvh_info.stack_entries != 0 && !(flags & CAP_RENDER_STAGE_TIMERS) &&
+                     !(flags & CAP_RENDER_GBUFFER_FEEDBACK) && !(flags & CAP_RENDER_LOWRES_INDIRECT) && !getenv("CAP_TRACE_LAUNCHES") && n_frames >= 2;
+    if (two_lanes && slots >= n_frames)
+    {
+        if ((uint64_t)n_frames * Ppad >= ((uint64_t)8 << 20))
+            slots = (n_frames + 1) / 2;
+        else
+            two_lanes = false;
+    }
     // No host synchronisation with the previous call: everything it still uses is either ordered behind it on the stream (queues,
     // counters, planes) or lives in another slot of the constants ring.  Only a long backlog of unread events / counters is
     // drained (what cap_sync / cap_stats_get do anyway), and a growing allocation (which frees the old buffers).
@@ -1014,6 +1082,15 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         if (grows) HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (ensure_wavefront(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
+    if (two_lanes)
+    {
+        if (c->lane1.pl_color.n < (size_t)slots * Ppad || c->lane1.counters.n < c->counters.n)
+        {
+            HIP_TRY(hipStreamSynchronize(c->stream));  // growing frees the old buffers
+            if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
+        }
+        if (ensure_lane1(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
+    }
     const uint32_t ring = c->frames_next;
     c->frames_next      = (c->frames_next + 1) % CapContext::kFrameRing;
     if (!c->frames_event[ring]) HIP_TRY(hipEventCreateWithFlags(&c->frames_event[ring], hipEventDisableTiming));
@@ -1056,24 +1133,53 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     uint32_t blocks_per_cu = stack_entries == 0 ? 6u : (stack_entries <= 32 ? 5u : 2u);  // measured: 4..8 within 4 %, 6 best
     if (const char* e = getenv("CAP_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)std::max(1, atoi(e));
     LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * blocks_per_cu, stack_entries, (uint32_t)c->cu_count};
-    const BvhDev    bvh   = bvh_dev(c);
+    BvhDev          bvh   = bvh_dev(c);
     const SceneDev  scene = scene_dev(c);
     const CameraDev cam   = camera_dev(c->camera);
     const uint32_t  D     = num_bounces;
     std::unique_ptr<StageTimer> total(new StageTimer(c, ST_COUNT));  // its destructor closes the span on every exit path
 
-    for (uint32_t done = 0; done < n_frames; done += slots)
+    // per-lane view of the batch working set
+    struct LaneView
     {
+        float4 *  hits, *q_org[2], *q_dir[2], *q_thr[2], *s_org, *s_dir, *s_con, *pl_color, *pl_direct, *pl_albedo;
+        uint32_t *counters, *spill;
+        size_t    ring_n;
+        hipStream_t stream;
+    };
+    const LaneView views[2] = {
+        {c->hits.p, {c->q_org[0].p, c->q_org[1].p}, {c->q_dir[0].p, c->q_dir[1].p}, {c->q_thr[0].p, c->q_thr[1].p}, c->s_org.p, c->s_dir.p, c->s_con.p,
+         c->pl_color.p, c->pl_direct.p, c->pl_albedo.p, c->counters.p, c->stack_spill.p, std::min(c->s_org.n, c->s_con.n), c->stream},
+        {c->lane1.hits.p, {c->lane1.q_org[0].p, c->lane1.q_org[1].p}, {c->lane1.q_dir[0].p, c->lane1.q_dir[1].p},
+         {c->lane1.q_thr[0].p, c->lane1.q_thr[1].p}, c->lane1.s_org.p, c->lane1.s_dir.p, c->lane1.s_con.p, c->lane1.pl_color.p,
+         c->lane1.pl_direct.p, c->lane1.pl_albedo.p, c->lane1.counters.p, c->lane1.stack_spill.p, std::min(c->lane1.s_org.n, c->lane1.s_con.n),
+         c->stream2}};
+    const uint32_t n_batches = (n_frames + slots - 1) / slots;
+    if (two_lanes)
+    {
+        // lane 1 starts behind everything queued on the context's stream so far (the frame constants' upload, earlier calls)
+        HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
+    }
+    hipEvent_t last_resolve = nullptr;  // the accumulation buffer takes the batches in frame order, whichever lane ran them
+    uint32_t   batch        = 0;
+
+    for (uint32_t done = 0; done < n_frames; done += slots, ++batch)
+    {
+        const uint32_t  lane = two_lanes ? ((n_batches - 1u - batch) & 1u) : 0u;  // the last batch on lane 0
+        const LaneView& L    = views[lane];
+        cfg.stream           = L.stream;
+        bvh.stack_spill      = L.spill;
         const uint32_t ns = std::min(slots, n_frames - done);
         const FrameConst* frames = c->frames_ring[ring].p + done;
         const size_t   per_queue     = (size_t)kQueueClasses * kCounterStride;  // counter words of one queue
         // per bounce and class one 64-bit word: low half = extension entries, high half = shadow entries (one atomic serves both)
         const size_t   counter_words = (size_t)(D + 1) * per_queue;
-        HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(uint32_t) * 3 * counter_words, c->stream));
-        uint32_t*      ext_count = c->counters.p;
-        uint32_t*      sh_count  = c->counters.p + 1;
-        uint32_t*      work_shade = c->counters.p + counter_words;      // + b * per_queue: grab counters of bounce b's fused launch
-        uint32_t*      work_any   = c->counters.p + 2 * counter_words;  // ... and of its any-hit launch
+        HIP_TRY(hipMemsetAsync(L.counters, 0, sizeof(uint32_t) * 3 * counter_words, L.stream));
+        uint32_t*      ext_count = L.counters;
+        uint32_t*      sh_count  = L.counters + 1;
+        uint32_t*      work_shade = L.counters + counter_words;      // + b * per_queue: grab counters of bounce b's fused launch
+        uint32_t*      work_any   = L.counters + 2 * counter_words;  // ... and of its any-hit launch
         const uint32_t total_chunks   = ns * (Ppad >> 6);
         const uint32_t class_capacity = ((total_chunks + kQueueClasses - 1) / kQueueClasses) * 64u;
         const bool     last_batch = done + ns >= n_frames;
@@ -1081,8 +1187,8 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         const uint32_t max_count  = ns * Ppad;
 
         ShadeArgs sa{};
-        sa.scene = scene, sa.cam = cam, sa.screen = c->screen, sa.frames = frames, sa.hits = c->hits.p;
-        sa.planes = Planes{c->pl_color.p, c->pl_direct.p, c->pl_albedo.p, c->aov_geo.p, c->aov_nd.p};
+        sa.scene = scene, sa.cam = cam, sa.screen = c->screen, sa.frames = frames, sa.hits = L.hits;
+        sa.planes = Planes{L.pl_color, L.pl_direct, L.pl_albedo, c->aov_geo.p, c->aov_nd.p};
         sa.n_slots = ns, sa.num_bounces = D, sa.max_count = max_count, sa.aov_slot = aov_slot, sa.shaded_counter = c->shaded_counter.p;
         {
             // screen-space culling of bounce 0 inverts primary_dir (camera.h:39-63), which needs an orthonormal basis
@@ -1108,7 +1214,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                               ? 1u
                               : 0u;
         static const bool no_wave_ring = getenv("CAP_NO_WAVE_RING") != nullptr;  // A/B switch
-        sa.wave_ring = (sa.inline_probe && !no_wave_ring && (size_t)cfg.grid_blocks * (kBlock / 64) * 128 <= std::min(c->s_org.n, c->s_con.n)) ? 1u : 0u;  // (a grid beyond what ensure_wavefront sized the rings for: CAP_BLOCKS_PER_CU)
+        sa.wave_ring = (sa.inline_probe && !no_wave_ring && (size_t)cfg.grid_blocks * (kBlock / 64) * 128 <= L.ring_n) ? 1u : 0u;  // (a grid beyond what ensure_wavefront sized the rings for: CAP_BLOCKS_PER_CU)
         LaunchCfg cfg_any    = cfg;
         cfg_any.any_no_probe = sa.inline_probe;
         // CAP_TRACE_LAUNCHES=1: name every launch on stderr and drain the stream after it (fault localisation only)
@@ -1128,11 +1234,11 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             const int pi = (int)(b & 1u), po = pi ^ 1;
             sa.bounce    = b;
             // (inline_nee: no shadow entries are written, so the shadow queue's two 16-byte planes carry the paths' gathered radiance)
-            sa.in        = RayQueue{c->q_org[pi].p, c->q_dir[pi].p, c->q_thr[pi].p, b ? ext_count + (b - 1) * per_queue : nullptr, class_capacity,
-                                    pi ? c->s_dir.p : c->s_org.p};
-            sa.out       = RayQueue{c->q_org[po].p, c->q_dir[po].p, c->q_thr[po].p, ext_count + b * per_queue, class_capacity,
-                                    po ? c->s_dir.p : c->s_org.p};
-            sa.shadow    = ShadowQueue{c->s_org.p, c->s_dir.p, c->s_con.p, sh_count + b * per_queue, class_capacity};
+            sa.in        = RayQueue{L.q_org[pi], L.q_dir[pi], L.q_thr[pi], b ? ext_count + (b - 1) * per_queue : nullptr, class_capacity,
+                                    pi ? L.s_dir : L.s_org};
+            sa.out       = RayQueue{L.q_org[po], L.q_dir[po], L.q_thr[po], ext_count + b * per_queue, class_capacity,
+                                    po ? L.s_dir : L.s_org};
+            sa.shadow    = ShadowQueue{L.s_org, L.s_dir, L.s_con, sh_count + b * per_queue, class_capacity};
             sa.work      = work_shade + b * per_queue;
             if (fused)
             {
@@ -1147,10 +1253,10 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                 {
                     {
                         StageTimer t(c, ST_PRIMARY, st);
-                        primary_shaded = launch_primary_shade(cfg, bvh, sa, c->hits.p, ext);
-                        if (!primary_shaded) launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, c->hits.p, sa.work);
+                        primary_shaded = launch_primary_shade(cfg, bvh, sa, L.hits, ext);
+                        if (!primary_shaded) launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, L.hits, sa.work);
                     }
-                    if (aov_slot != ~0u) launch_geo_aov(cfg, scene, c->hits.p + (size_t)aov_slot * Ppad, Ppad, c->aov_geo.p);
+                    if (aov_slot != ~0u) launch_geo_aov(cfg, scene, L.hits + (size_t)aov_slot * Ppad, Ppad, c->aov_geo.p);
                 }
                 if (b != 0 || !primary_shaded)
                 {
@@ -1162,7 +1268,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             if (!sa.inline_nee && !(fused && sa.wave_ring && b != 0))
             {
                 StageTimer t(c, ST_ANY, st, b == 0 ? ST_DIRECT : ST_NONE);
-                launch_trace_any(cfg_any, bvh, sa.shadow, max_count, b == 0 ? c->pl_direct.p : c->pl_color.p, Ppad, ns, c->shaded_counter.p,
+                launch_trace_any(cfg_any, bvh, sa.shadow, max_count, b == 0 ? L.pl_direct : L.pl_color, Ppad, ns, c->shaded_counter.p,
                                  work_any + b * per_queue, /* next-event estimation: most shadow rays reach the light */ ext, frames);
                 ++c->stats.launches_trace_any;
                 if (traced("trace_any", b)) return fail(CAP_ERR_HIP, "trace_any failed");
@@ -1171,16 +1277,22 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             {
                 StageTimer t(c, ST_CLOSEST, st);
                 if (bvh.wide8_ok)  // bounce b + 1's slot of the fused kernels' grab counters is free on this path
-                    launch_trace_closest8(cfg, bvh, sa.out, max_count, c->hits.p, work_shade + (b + 1) * per_queue);
+                    launch_trace_closest8(cfg, bvh, sa.out, max_count, L.hits, work_shade + (b + 1) * per_queue);
                 else
-                    launch_trace_closest(cfg, bvh, sa.out, max_count, c->hits.p);
+                    launch_trace_closest(cfg, bvh, sa.out, max_count, L.hits);
                 ++c->stats.launches_trace_closest;
             }
         }
         if (!lowres)
         {
             StageTimer t(c, ST_RESOLVE, st);
+            if (two_lanes && last_resolve) HIP_TRY(hipStreamWaitEvent(L.stream, last_resolve, 0));  // frame order of the additions
             launch_resolve(cfg, sa.planes, ns, Ppad, c->accum.p, sa.albedo_in_w != 0u, scene.kd_untextured);
+            if (two_lanes)
+            {
+                HIP_TRY(hipEventRecord(c->lane_ev[lane], L.stream));
+                last_resolve = c->lane_ev[lane];
+            }
         }
         // queue lengths of this batch -> pinned host memory, summed at the next sync
         uint32_t* pinned = nullptr;
@@ -1191,7 +1303,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         }
         else
             HIP_TRY(hipHostMalloc((void**)&pinned, sizeof(uint32_t) * 2 * 256 * kQueueClasses * kCounterStride, hipHostMallocDefault));
-        HIP_TRY(hipMemcpyAsync(pinned, c->counters.p, sizeof(uint32_t) * counter_words, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(pinned, L.counters, sizeof(uint32_t) * counter_words, hipMemcpyDeviceToHost, L.stream));
         c->pending.push_back({pinned, D | (sa.inline_nee ? 1u << 16 : 0u)});
         HIP_TRY(hipGetLastError());
 
@@ -1215,9 +1327,16 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         if (c->spans.size() > 4096)
         {
             total.reset();
+            if (two_lanes) HIP_TRY(hipStreamSynchronize(c->stream2));
             if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
             total.reset(new StageTimer(c, ST_COUNT));
         }
+    }
+    if (two_lanes)
+    {
+        // the context's stream -- the one callers order their work behind -- ends the call behind lane 1 as well
+        HIP_TRY(hipEventRecord(c->join_ev, c->stream2));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev, 0));
     }
     total.reset();
     HIP_TRY(hipEventRecord(c->frames_event[ring], c->stream));
