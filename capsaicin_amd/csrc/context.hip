@@ -1065,7 +1065,8 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                      !(flags & CAP_RENDER_GBUFFER_FEEDBACK) && !(flags & CAP_RENDER_LOWRES_INDIRECT) && !getenv("CAP_TRACE_LAUNCHES") && n_frames >= 2;
     if (two_lanes && slots >= n_frames)
     {
-        if ((uint64_t)n_frames * Ppad >= ((uint64_t)8 << 20))
+        static const uint64_t split_min = getenv("CAP_LANE_SPLIT_MIN") ? (uint64_t)atoll(getenv("CAP_LANE_SPLIT_MIN")) : ((uint64_t)4 << 20);  // A/B switch (shard 0 of 8 of the 262 k scene: 4.55 -> 4.35 ms with halves of 4 Mi paths)
+        if ((uint64_t)n_frames * Ppad >= split_min)
             slots = (n_frames + 1) / 2;
         else
             two_lanes = false;
