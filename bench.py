@@ -502,6 +502,13 @@ def main():
                          "traffic_source": ssrc, "avg_launch_ms": shade_ms / shade_launches, "launches": int(shade_launches),
                          "bytes_per_vertex": BYTES_VERTEX, "vertices_per_step": int(shade_vertices)}
                 sroof["frac"] = sroof["achieved"] / HBM_PEAK_GBS
+                # 56 % of k_shade's items are extension rays that escaped: each costs its 32 B of queue stream (hit 16 + throughput /
+                # path id 16) and a 16-B load-add-store of the path's plane entry for the sky term (rt_indirect.hlsl:94-99) without
+                # being a vertex -- compulsory bytes of this design that SURVEY.md 8d's per-vertex figure does not count
+                escapes = max(0, int(tp.rays_extension) - int(shade_vertices))
+                sroof["escapes_per_step"] = escapes
+                sroof["achieved_with_escapes"] = (BYTES_VERTEX * shade_vertices + 64 * escapes) / (shade_ms * 1e-3) / 1e9
+                sroof["frac_with_escapes"] = sroof["achieved_with_escapes"] / HBM_PEAK_GBS
                 tree_variant = {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d %dspp depth=%d, reference shading" %
                                             (bi2.triangle_count, WIDTH, HEIGHT, TREE_SPP, DEPTH),
                                 "value": trays / tdt / 1e6, "unit": "Mrays/s", "ms_per_step": tdt / 2 * 1e3,
@@ -540,6 +547,35 @@ def main():
             except Exception as exc:  # the extra key must never cost the contract line
                 shard_costs = {"error": str(exc)}
 
+        # the stage right after the path: ms per 1080p frame of the reconstruction chain, exact (bit-identical to the
+        # oracle) and with CapPostSettings::fast_weights (stated tolerance); extra key, N = 1 only
+        post_chain = None
+        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant:
+            try:
+                rp = capi.Renderer(device_index, stream.cuda_stream)
+                rp.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
+                rp.upload_bluenoise(capi.load_bluenoise())
+                rp.build_bvh()
+                rp.set_resolution(WIDTH, HEIGHT)
+                camp = capi.cornell_camera(WIDTH, HEIGHT)
+                rp.set_camera(camp)
+                rp.render(0, 1, 2, capi.RENDER_AOV)
+                post_chain = {"what": "Gather -> Accumulate -> BlurDisocclusion -> Blur x4 -> Combine -> TAA, ms per %dx%d frame, static camera, "
+                                      "frames 3..22" % (WIDTH, HEIGHT), "algorithmic_bytes_per_frame": WIDTH * HEIGHT * 16 * 19}
+                for name, fast in (("exact", 0), ("fast_weights", 1)):
+                    ps = capi.PostSettings(fast_weights=fast)
+                    for f in range(3):
+                        rp.post_frame(ps, f, camp)
+                    rp.sync()
+                    t0 = time.perf_counter()
+                    for f in range(3, 23):
+                        rp.post_frame(ps, f, camp)
+                    rp.sync()
+                    post_chain[name + "_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+                rp.close()
+            except Exception as exc:  # the extra key must never cost the contract line
+                post_chain = {"error": str(exc)}
+
         if rank == 0:
             # sanity of the product of the timed region: finite image, every pixel accumulated spp frames
             img = (r.comm_readback() if exchange.startswith("cap_comm") else image.cpu().numpy()).reshape(HEIGHT, WIDTH, 4)
@@ -552,7 +588,7 @@ def main():
                               "triangles": int(bvh.triangle_count), "bvh_depth": int(bvh.max_depth),
                               "rays_per_step": {"primary": rays_p / args.steps, "extension": rays_e / args.steps, "shadow": rays_s / args.steps},
                               "parallelism": "tiles%d" % world, "exchange": exchange},
-                   "roofline": roofline, "ext_variant": ext_variant, "tree_variant": tree_variant, "shard_cost": shard_costs}
+                   "roofline": roofline, "ext_variant": ext_variant, "tree_variant": tree_variant, "shard_cost": shard_costs, "post_chain": post_chain}
             out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()  # rank 0, N = 1 only
             print(json.dumps(out), flush=True)
         r.close()
