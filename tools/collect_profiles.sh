@@ -4,7 +4,7 @@
 #   tools/w8_counts.py on the diagnostic build (make -B EXTRA=-DCAP_W8_COUNT; rebuild without it afterwards).
 # Usage: bash tools/collect_profiles.sh r02
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 python tools/make_traffic.py "$TAG" gpurun_out/w8_counts.json > /dev/null
@@ -24,7 +24,17 @@ cp "$(ls -t gpurun_out/prof_kt/*/*kernel_stats.csv | head -1)" "profiles/${TAG}_
     tail -1 gpurun_out/w8_counts.json
 } > "profiles/${TAG}_tree_path.txt"
 {
-    echo "# tools/post_trace.sh: reconstruction chain at 1920x1080 (kernel trace of tools/time_post.py)"
+    echo "# tools/post_trace.sh: reconstruction chain at 1920x1080 (kernel trace of tools/time_post.py), exact weights"
     cat gpurun_out/post_trace.txt
+    echo
+    echo "# POST_MODE=fast tools/post_trace.sh: CapPostSettings::fast_weights"
+    cat gpurun_out/post_trace_fast.txt
 } > "profiles/${TAG}_post_chain.txt"
+{
+    echo "# tools/shard_trace.sh: per-launch durations of ONE step of shard 0 of N (the compute side of the 1 -> N curve, bench.py shard_cost)"
+    for f in shard1_cornell shard8_cornell shard1_sponza shard8_sponza; do
+        echo "## $f"
+        cat gpurun_out/$f.txt
+    done
+} > "profiles/${TAG}_shard_cost.txt"
 echo "profiles/${TAG}_* written; now: gpurun -- 'python bench.py > gpurun_out/bench_${TAG}.json' and copy it to profiles/${TAG}_bench.json"
