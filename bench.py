@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # debugging only; the contract run uses 64
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-tree-variant", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)  # profiling passes: no shard_cost / post_chain sections
     ap.add_argument("--batch-paths", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--traversal", type=int, default=0, help=argparse.SUPPRESS)  # 0 auto (contract run), 1 stack, 2 exhaustive
     ap.add_argument("--scene", default="cornell", help=argparse.SUPPRESS)  # "sponza": extra line on the procedural 262 k-triangle scene
@@ -522,7 +523,7 @@ def main():
 
         # the compute side of the scaling curve on this one device: extra key, N = 1 only
         shard_costs = None
-        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant:
+        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant and not args.no_extras:
             try:
                 def make_cornell():
                     rc = capi.Renderer(device_index, stream.cuda_stream)
@@ -550,7 +551,7 @@ def main():
         # the stage right after the path: ms per 1080p frame of the reconstruction chain, exact (bit-identical to the
         # oracle) and with CapPostSettings::fast_weights (stated tolerance); extra key, N = 1 only
         post_chain = None
-        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant:
+        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant and not args.no_extras:
             try:
                 rp = capi.Renderer(device_index, stream.cuda_stream)
                 rp.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))

@@ -46,7 +46,7 @@ def total(pass_glob, counter, kernel):
 PASSES = listed_passes()
 out = {"source_sha256": bench.kernel_source_sha(), "kernels": {},
        "method": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ block, each in its own run, no trace options) of `python3 "
-                 "bench.py --steps 2 --warmup 1 --no-cpu-baseline` (tools/prof.sh); counters summed over the kernel's dispatches and "
+                 "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` (tools/prof.sh); counters summed over the kernel's dispatches and "
                  "divided by their number; FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for "
                  "gfx950; per-kernel table in profiles/%s_rocprofv3_summary.txt" % tag}
 for key, name in KERNELS.items():

@@ -5,7 +5,9 @@
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
-ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_EXTRA}"
+# --no-extras: without the shard_cost / post_chain sections, whose launches of the same kernels on other amounts of work would
+# pollute the per-launch averages of the three kernels bench.py prices
+ARGS="$ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_EXTRA}"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_kt $OUT/prof_pmc_* $OUT/prof_manifest.txt
 # the manifest names the passes of THIS run and the sources they were taken on: tools/prof_summary.py and make_traffic.py read
