@@ -1061,8 +1061,8 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     // launches gain nothing measurable (20.45 -> 20.25 ms with the context's own stream, 20.56 -> 20.9 beside a torch stream).
     const bool tree_path = c->traversal_mode == CAP_TRAVERSAL_EXHAUSTIVE ? false
                                                                          : !(c->traversal_mode == CAP_TRAVERSAL_AUTO && c->tri_count <= kExhaustiveMax);
-    bool two_lanes = !no_two_lanes && tree_path && c->bvh_info.stack_entries != 0 && !(flags & CAP_RENDER_STAGE_TIMERS) &&
-                     !(flags & CAP_RENDER_GBUFFER_FEEDBACK) && !(flags & CAP_RENDER_LOWRES_INDIRECT) && !getenv("CAP_TRACE_LAUNCHES") && n_frames >= 2;
+    bool two_lanes = !no_two_lanes && tree_path && c->bvh_info.stack_entries != 0 && !(flags & CAP_RENDER_GBUFFER_FEEDBACK) &&
+                     !(flags & CAP_RENDER_LOWRES_INDIRECT) && n_frames >= 2;
     if (two_lanes && slots >= n_frames)
     {
         static const uint64_t split_min = getenv("CAP_LANE_SPLIT_MIN") ? (uint64_t)atoll(getenv("CAP_LANE_SPLIT_MIN")) : ((uint64_t)4 << 20);  // A/B switch (shard 0 of 8 of the 262 k scene: 4.55 -> 4.35 ms with halves of 4 Mi paths)
@@ -1082,6 +1082,9 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                            !c->accum.p || c->accum.n < c->screen.pixels_padded;
         if (grows) HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    // (per-stage timers and launch tracing need one stream: the batches keep the size the two lanes gave them -- so that a stage-timed
+    // render launches what the plain one does -- and run one after the other on lane 0)
+    if ((flags & CAP_RENDER_STAGE_TIMERS) || getenv("CAP_TRACE_LAUNCHES")) two_lanes = false;
     if (ensure_wavefront(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
     if (two_lanes)
     {
