@@ -1,14 +1,18 @@
 // image_decode.cpp — texture file decoding for the host layer: what TextureSystem gets from stbi_load(file, &w, &h, &n, 4) in the
 // reference (src/core/src/systems/texture_system.cpp:41-45): 8-bit RGBA, rows top to bottom, grey replicated, alpha 255 when
 // the file has none.  Own decoders (the reference vendors stb_image.h, a third-party header that is not carried over):
-//   PNG   colour types 0 / 2 / 3 / 4 / 6, bit depths 1..16, all five filters, zlib inflate (stored / fixed / dynamic blocks);
-//         Adam7-interlaced files are refused
-//   TGA   types 1 / 2 / 3 and their run-length forms 9 / 10 / 11, 8 / 15 / 16 / 24 / 32 bits, either origin
-//   PPM   binary P6, maxval 255 (the container tools/make_sponza_class.py writes)
-// JPEG is not decoded: such a texture is reported missing, which the reference treats as a warning and a black texel
-// (texture_system.cpp:50-56).
+//   PNG   colour types 0 / 2 / 3 / 4 / 6, bit depths 1..16, all five filters, Adam7 interlace, zlib inflate (stored / fixed /
+//         dynamic blocks)
+//   TGA   types 1 / 2 / 3 and their run-length forms 9 / 10 / 11, 8 / 15 / 16 / 24 / 32 bits, either origin (stb's reading of the
+//         format where it departs from Truevision's)
+//   PNM   binary P6 (the container tools/make_sponza_class.py writes) and P5, maxval up to 255
+//   JPEG  baseline and progressive Huffman-coded frames (jpeg_decode.cpp)
+// Anything else (BMP, GIF, PSD, HDR, PIC) is reported missing, which the reference treats as a warning and a
+// black texel (texture_system.cpp:50-56).  tests/test_image_ref.py holds every decoder to stb_image's output bit for bit.
 #include "../../include/capsaicin_scene.h"
+#include "image_decode.h"
 
+#include <algorithm>
 #include <cctype>
 #include <cstdlib>
 #include <cstring>
@@ -214,7 +218,7 @@ bool decode_png(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
     uint32_t W = 0, H = 0;
     int      depth = 0, ctype = 0, interlace = 0;
     Bytes    idat, plte, trns;
-    bool     have_ihdr = false, end = false;
+    bool     have_ihdr = false, have_trns = false, end = false;
     while (!end && pos + 12 <= d.size())
     {
         const uint32_t len = be32(&d[pos]);
@@ -223,22 +227,36 @@ bool decode_png(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
         const uint8_t* body = &d[pos + 8];
         if (!memcmp(tag, "IHDR", 4))
         {
-            if (len != 13) return false;
+            if (len != 13 || have_ihdr) return false;
             W = be32(body), H = be32(body + 4), depth = body[8], ctype = body[9], interlace = body[12];
             if (body[10] != 0 || body[11] != 0) return false;
             have_ihdr = true;
         }
         else if (!memcmp(tag, "PLTE", 4))
+        {
+            if (!have_ihdr || len > 768 || len % 3 != 0) return false;
             plte.assign(body, body + len);
+        }
         else if (!memcmp(tag, "tRNS", 4))
+        {
+            // stb_image.h:4936-4957: a key only for grey / RGB, exactly one 16-bit value per channel; palette alpha after PLTE
+            if (!have_ihdr || !idat.empty()) return false;
+            if (ctype == 3 ? (plte.empty() || len > plte.size() / 3) : ((ctype & 4) || len != (ctype == 2 ? 6u : 2u))) return false;
             trns.assign(body, body + len);
+            have_trns = true;
+        }
         else if (!memcmp(tag, "IDAT", 4))
+        {
+            if (!have_ihdr) return false;
             idat.insert(idat.end(), body, body + len);
+        }
         else if (!memcmp(tag, "IEND", 4))
             end = true;
+        else if (!have_ihdr || !(tag[0] & 0x20))
+            return false;  // something before IHDR, or a critical chunk this decoder does not know (stb refuses both)
         pos += 12 + (size_t)len;
     }
-    if (!have_ihdr || !W || !H || W > 32768 || H > 32768 || (uint64_t)W * H > kMaxPixels || interlace != 0) return false;
+    if (!have_ihdr || !W || !H || W > 32768 || H > 32768 || (uint64_t)W * H > kMaxPixels || interlace > 1) return false;
     int channels;
     switch (ctype)
     {
@@ -251,106 +269,145 @@ bool decode_png(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
     }
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) return false;
     if (ctype == 3 && (depth == 16 || plte.size() < 3)) return false;
-    const size_t bpp_bits = (size_t)channels * depth, stride = (W * bpp_bits + 7) / 8, bpp = (bpp_bits + 7) / 8;
-    Bytes        raw;
-    raw.reserve((stride + 1) * H);
-    if (!zlib_inflate(idat.data(), idat.size(), &raw, (stride + 1) * H) || raw.size() < (stride + 1) * H) return false;
-    // un-filter in place (PNG spec 9.2): a = left, b = up, c = upper left
-    Bytes prev(stride, 0);
-    for (uint32_t y = 0; y < H; ++y)
+    const size_t bpp_bits = (size_t)channels * depth, bpp = (bpp_bits + 7) / 8;
+    // the image as one pass, or as the seven Adam7 passes (PNG spec 8.2): pixel (x0 + i * dx, y0 + j * dy) of the image is pixel
+    // (i, j) of the pass; every pass is a filtered image of its own
+    struct Pass
     {
-        uint8_t*      row = &raw[(stride + 1) * y + 1];
-        const uint8_t f   = row[-1];
-        for (size_t i = 0; i < stride; ++i)
-        {
-            const int a = i >= bpp ? row[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int       pred;
-            switch (f)
-            {
-            case 0: pred = 0; break;
-            case 1: pred = a; break;
-            case 2: pred = b; break;
-            case 3: pred = (a + b) >> 1; break;
-            case 4:
-            {
-                const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-                pred        = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                break;
-            }
-            default: return false;
-            }
-            row[i] = (uint8_t)(row[i] + pred);
-        }
-        memcpy(prev.data(), row, stride);
+        uint32_t x0, y0, dx, dy;
+    };
+    static const Pass whole[1] = {{0, 0, 1, 1}};
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    const Pass*       passes   = interlace ? adam7 : whole;
+    const int         n_passes = interlace ? 7 : 1;
+    size_t            total    = 0;
+    for (int p = 0; p < n_passes; ++p)
+    {
+        const size_t pw = (W - passes[p].x0 + passes[p].dx - 1) / passes[p].dx, ph = (H - passes[p].y0 + passes[p].dy - 1) / passes[p].dy;
+        if (W > passes[p].x0 && H > passes[p].y0) total += ((pw * bpp_bits + 7) / 8 + 1) * ph;
     }
+    Bytes raw;
+    raw.reserve(total);
+    if (!zlib_inflate(idat.data(), idat.size(), &raw, total) || raw.size() < total) return false;
     rgba->assign((size_t)W * H * 4, 255);
-    for (uint32_t y = 0; y < H; ++y)
+    size_t offset = 0;
+    for (int p = 0; p < n_passes; ++p)
     {
-        const uint8_t* row = &raw[(stride + 1) * y + 1];
-        for (uint32_t x = 0; x < W; ++x)
+        const Pass& ps = passes[p];
+        if (W <= ps.x0 || H <= ps.y0) continue;
+        const uint32_t pw = (W - ps.x0 + ps.dx - 1) / ps.dx, ph = (H - ps.y0 + ps.dy - 1) / ps.dy;
+        const size_t   stride = ((size_t)pw * bpp_bits + 7) / 8;
+        // un-filter in place (PNG spec 9.2): a = left, b = up, c = upper left
+        Bytes prev(stride, 0);
+        for (uint32_t y = 0; y < ph; ++y)
         {
-            uint8_t* o = &(*rgba)[4 * ((size_t)y * W + x)];
-            // sample k of the pixel as an 8-bit value (16-bit: the high byte, as stb's 16 -> 8 conversion; < 8 bits: scaled)
-            auto sample = [&](int k) -> int {
-                if (depth == 8) return row[(size_t)x * channels + k];
-                if (depth == 16) return row[2 * ((size_t)x * channels + k)];
-                const size_t bit = (size_t)x * depth;
-                const int    v   = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
-                return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
-            };
-            if (ctype == 3)
+            uint8_t*      row = &raw[offset + (stride + 1) * y + 1];
+            const uint8_t f   = row[-1];
+            for (size_t i = 0; i < stride; ++i)
             {
-                const size_t idx = (size_t)sample(0);
-                if (3 * idx + 2 < plte.size()) o[0] = plte[3 * idx], o[1] = plte[3 * idx + 1], o[2] = plte[3 * idx + 2];
-                else o[0] = o[1] = o[2] = 0;
-                o[3] = idx < trns.size() ? trns[idx] : 255;
+                const int a = i >= bpp ? row[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                int       pred;
+                switch (f)
+                {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4:
+                {
+                    const int q = a + b - c, pa = abs(q - a), pb = abs(q - b), pc = abs(q - c);
+                    pred        = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    break;
+                }
+                default: return false;
+                }
+                row[i] = (uint8_t)(row[i] + pred);
             }
-            else if (ctype == 0 || ctype == 4)
+            memcpy(prev.data(), row, stride);
+            for (uint32_t x = 0; x < pw; ++x)
             {
-                o[0] = o[1] = o[2] = (uint8_t)sample(0);
-                if (ctype == 4) o[3] = (uint8_t)sample(1);
-            }
-            else
-            {
-                o[0] = (uint8_t)sample(0), o[1] = (uint8_t)sample(1), o[2] = (uint8_t)sample(2);
-                if (ctype == 6) o[3] = (uint8_t)sample(3);
+                uint8_t* o = &(*rgba)[4 * ((size_t)(ps.y0 + y * ps.dy) * W + ps.x0 + x * ps.dx)];
+                // sample k of the pixel as an 8-bit value (16-bit: the high byte, as stb's 16 -> 8 conversion; < 8 bits: scaled)
+                auto sample = [&](int k) -> int {
+                    if (depth == 8) return row[(size_t)x * channels + k];
+                    if (depth == 16) return row[2 * ((size_t)x * channels + k)];
+                    const size_t bit = (size_t)x * depth;
+                    const int    v   = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+                    return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
+                };
+                if (ctype == 3)
+                {
+                    const size_t idx = (size_t)sample(0);
+                    if (3 * idx + 2 < plte.size()) o[0] = plte[3 * idx], o[1] = plte[3 * idx + 1], o[2] = plte[3 * idx + 2];
+                    else o[0] = o[1] = o[2] = 0;
+                    o[3] = idx < trns.size() ? trns[idx] : 255;
+                }
+                else if (ctype == 0 || ctype == 4)
+                {
+                    o[0] = o[1] = o[2] = (uint8_t)sample(0);
+                    if (ctype == 4) o[3] = (uint8_t)sample(1);
+                }
+                else
+                {
+                    o[0] = (uint8_t)sample(0), o[1] = (uint8_t)sample(1), o[2] = (uint8_t)sample(2);
+                    if (ctype == 6) o[3] = (uint8_t)sample(3);
+                }
+                // colour key of grey / RGB files (stb_image.h:4952-4956): 16-bit files compare whole samples, the others the low
+                // byte of the key scaled like the samples
+                if (have_trns && ctype != 3)
+                {
+                    bool hit = true;
+                    for (int k = 0; k < channels; ++k)
+                    {
+                        const int key = (trns[2 * k] << 8) | trns[2 * k + 1];
+                        if (depth == 16)
+                        {
+                            const size_t at = 2 * ((size_t)x * channels + k);
+                            hit             = hit && ((row[at] << 8) | row[at + 1]) == key;
+                        }
+                        else
+                            hit = hit && sample(k) == (uint8_t)((key & 255) * (255 / ((1 << depth) - 1)));
+                    }
+                    if (hit) o[3] = 0;
+                }
             }
         }
+        offset += (stride + 1) * ph;
     }
-    // tRNS colour keys of grey / RGB images (rare in textures) are honoured for 8-bit files
-    if (depth == 8 && ((ctype == 0 && trns.size() >= 2) || (ctype == 2 && trns.size() >= 6)))
-        for (size_t i = 0; i < (size_t)W * H; ++i)
-        {
-            uint8_t* o = &(*rgba)[4 * i];
-            if (ctype == 0 ? o[0] == trns[1] : (o[0] == trns[1] && o[1] == trns[3] && o[2] == trns[5])) o[3] = 0;
-        }
     *w = W, *h = H;
     return true;
 }
 
 // ---------------------------------------------------------------- TGA
+// The rules are stb's (stb_image.h:5565-5806), not the Truevision text, wherever the two part: the pixel layout follows the bit
+// count (8 grey, 15 / 16 five-bit RGB -- grey + alpha only for image type 3 --, 24 BGR, 32 BGRA) whatever the image type says;
+// "first colour-map entry" is a count of BYTES skipped in front of the map and indices are not offset by it; an index beyond the
+// map reads entry 0; the right-to-left bit is ignored; only the top-to-bottom bit flips rows.
 bool decode_tga(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
 {
     if (d.size() < 18) return false;
     const int idlen = d[0], cmap_type = d[1], type = d[2];
-    const int cmap_first = d[3] | (d[4] << 8), cmap_len = d[5] | (d[6] << 8), cmap_bits = d[7];
+    const int cmap_skip = d[3] | (d[4] << 8), cmap_len = d[5] | (d[6] << 8), cmap_bits = d[7];
     const uint32_t W = d[12] | (d[13] << 8), H = d[14] | (d[15] << 8);
     const int      bits = d[16], desc = d[17];
-    const bool     rle = type == 9 || type == 10 || type == 11;
+    const bool     rle = type >= 8, indexed = cmap_type == 1;
     const int      base = rle ? type - 8 : type;
-    if (!(base == 1 || base == 2 || base == 3) || !W || !H || (uint64_t)W * H > kMaxPixels) return false;
-    // colour-map entries are expanded like pixels: only the depths expand() knows (anything else was read as 16 bits: wrong
-    // colours and a 1-byte over-read for an 8-bit map)
-    if (cmap_type == 1 && base == 1 && !(cmap_bits == 15 || cmap_bits == 16 || cmap_bits == 24 || cmap_bits == 32)) return false;
-    if (base == 1 && (cmap_type != 1 || bits != 8)) return false;
-    if (base == 2 && !(bits == 15 || bits == 16 || bits == 24 || bits == 32)) return false;
-    if (base == 3 && !(bits == 8 || bits == 16)) return false;
-    if (cmap_type > 1) return false;
-    size_t pos = 18 + (size_t)idlen;
-    const size_t cmap_bytes = cmap_type ? (size_t)cmap_len * ((cmap_bits + 7) / 8) : 0;
-    if (pos + cmap_bytes > d.size()) return false;
-    const uint8_t* cmap = &d[pos];
-    pos += cmap_bytes;
+    auto depth_ok = [](int b) { return b == 8 || b == 15 || b == 16 || b == 24 || b == 32; };
+    if (cmap_type > 1 || !W || !H || (uint64_t)W * H > kMaxPixels || !depth_ok(bits)) return false;
+    if (indexed ? (base != 1 || !depth_ok(cmap_bits) || !(bits == 8 || bits == 16) || cmap_len == 0) : !(base == 2 || base == 3)) return false;
+    const int  value_bits = indexed ? cmap_bits : bits;             // what a colour value looks like
+    const bool grey_alpha = !indexed && base == 3 && bits == 16;
+    size_t     pos        = 18 + (size_t)idlen;
+    const uint8_t* cmap   = nullptr;
+    if (indexed)
+    {
+        pos += (size_t)cmap_skip;
+        const size_t cmap_bytes = (size_t)cmap_len * ((cmap_bits + 7) / 8);
+        if (pos + cmap_bytes > d.size()) return false;
+        cmap = &d[pos];
+        pos += cmap_bytes;
+    }
+    if (pos > d.size()) return false;
     const size_t px = (size_t)(bits + 7) / 8;
     Bytes        raw((size_t)W * H * px);
     if (!rle)
@@ -364,26 +421,30 @@ bool decode_tga(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
         while (o < raw.size())
         {
             if (pos >= d.size()) return false;
-            const int hdr = d[pos++], n = (hdr & 127) + 1;
-            if (o + (size_t)n * px > raw.size()) return false;
+            const int    hdr = d[pos++];
+            const size_t n   = std::min<size_t>((hdr & 127) + 1, (raw.size() - o) / px);  // a last packet may run past the image
             if (hdr & 128)
             {
                 if (pos + px > d.size()) return false;
-                for (int k = 0; k < n; ++k, o += px) memcpy(&raw[o], &d[pos], px);
+                for (size_t k = 0; k < n; ++k, o += px) memcpy(&raw[o], &d[pos], px);
                 pos += px;
             }
             else
             {
-                if (pos + (size_t)n * px > d.size()) return false;
-                memcpy(&raw[o], &d[pos], (size_t)n * px);
-                pos += (size_t)n * px, o += (size_t)n * px;
+                if (pos + n * px > d.size()) return false;
+                memcpy(&raw[o], &d[pos], n * px);
+                pos += n * px, o += n * px;
             }
         }
     }
-    auto expand = [](const uint8_t* p, int b, uint8_t* o) {  // one colour value of b bits -> RGBA
-        if (b == 24 || b == 32)
-            o[0] = p[2], o[1] = p[1], o[2] = p[0], o[3] = b == 32 ? p[3] : 255;
-        else  // 15 / 16: A RRRRR GGGGG BBBBB, little endian
+    auto expand = [&](const uint8_t* p, uint8_t* o) {  // one colour value -> RGBA
+        if (value_bits == 8)
+            o[0] = o[1] = o[2] = p[0], o[3] = 255;
+        else if (grey_alpha)
+            o[0] = o[1] = o[2] = p[0], o[3] = p[1];
+        else if (value_bits == 24 || value_bits == 32)
+            o[0] = p[2], o[1] = p[1], o[2] = p[0], o[3] = value_bits == 32 ? p[3] : 255;
+        else  // 15 / 16: x RRRRR GGGGG BBBBB, little endian; the top bit is not alpha
         {
             const int v = p[0] | (p[1] << 8);
             o[0] = (uint8_t)(((v >> 10) & 31) * 255 / 31), o[1] = (uint8_t)(((v >> 5) & 31) * 255 / 31), o[2] = (uint8_t)((v & 31) * 255 / 31);
@@ -391,34 +452,30 @@ bool decode_tga(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
         }
     };
     rgba->assign((size_t)W * H * 4, 255);
-    const bool top = (desc & 0x20) != 0, right = (desc & 0x10) != 0;
+    const bool top = (desc & 0x20) != 0;
     for (uint32_t y = 0; y < H; ++y)
         for (uint32_t x = 0; x < W; ++x)
         {
             const uint8_t* p = &raw[((size_t)y * W + x) * px];
-            uint8_t*       o = &(*rgba)[4 * ((size_t)(top ? y : H - 1 - y) * W + (right ? W - 1 - x : x))];
-            if (base == 3)
+            uint8_t*       o = &(*rgba)[4 * ((size_t)(top ? y : H - 1 - y) * W + x)];
+            if (indexed)
             {
-                o[0] = o[1] = o[2] = p[0];
-                if (bits == 16) o[3] = p[1];
-            }
-            else if (base == 1)
-            {
-                const int idx = (int)p[0] - cmap_first;
-                if (idx < 0 || idx >= cmap_len) o[0] = o[1] = o[2] = 0;
-                else expand(cmap + (size_t)idx * ((cmap_bits + 7) / 8), cmap_bits, o);
+                int idx = bits == 8 ? p[0] : (p[0] | (p[1] << 8));
+                if (idx >= cmap_len) idx = 0;
+                expand(cmap + (size_t)idx * ((cmap_bits + 7) / 8), o);
             }
             else
-                expand(p, bits, o);
+                expand(p, o);
         }
     *w = W, *h = H;
     return true;
 }
 
-// ---------------------------------------------------------------- PPM (P6, maxval 255)
+// ---------------------------------------------------------------- PNM (P5 / P6, one byte per sample)
 bool decode_ppm(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
 {
-    if (d.size() < 2 || d[0] != 'P' || d[1] != '6') return false;
+    if (d.size() < 2 || d[0] != 'P' || (d[1] != '6' && d[1] != '5')) return false;
+    const size_t ch = d[1] == '6' ? 3 : 1;
     size_t pos = 0;
     auto   token = [&]() {
         std::string t;
@@ -434,17 +491,18 @@ bool decode_ppm(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
         while (pos < d.size() && !std::isspace(d[pos])) t += (char)d[pos++];
         return t;
     };
-    if (token() != "P6") return false;
+    token();
     const long W = std::atol(token().c_str()), H = std::atol(token().c_str()), M = std::atol(token().c_str());
-    if (W <= 0 || H <= 0 || M != 255 || W > 32768 || H > 32768 || (uint64_t)W * (uint64_t)H > kMaxPixels) return false;
+    // (a maximum below 255 is accepted and, as in stb, not rescaled)
+    if (W <= 0 || H <= 0 || M < 1 || M > 255 || W > 32768 || H > 32768 || (uint64_t)W * (uint64_t)H > kMaxPixels) return false;
     ++pos;  // single whitespace after maxval
-    if (d.size() < pos + (size_t)W * H * 3) return false;
+    if (d.size() < pos + (size_t)W * H * ch) return false;
     rgba->resize((size_t)W * H * 4);
     for (size_t i = 0; i < (size_t)W * H; ++i)
     {
-        (*rgba)[4 * i + 0] = d[pos + 3 * i + 0];
-        (*rgba)[4 * i + 1] = d[pos + 3 * i + 1];
-        (*rgba)[4 * i + 2] = d[pos + 3 * i + 2];
+        (*rgba)[4 * i + 0] = d[pos + ch * i];
+        (*rgba)[4 * i + 1] = d[pos + ch * i + (ch == 3 ? 1 : 0)];
+        (*rgba)[4 * i + 2] = d[pos + ch * i + (ch == 3 ? 2 : 0)];
         (*rgba)[4 * i + 3] = 255;
     }
     *w = (uint32_t)W, *h = (uint32_t)H;
@@ -468,15 +526,10 @@ extern "C" int cap_image_decode(const uint8_t* bytes, size_t size, const char* n
     try  // no exception crosses the C ABI: a header that asks for more memory than there is ends as a status, not std::terminate
     {
     const Bytes d(bytes, bytes + size);
-    ok = decode_png(d, &rgba, &w, &h) || decode_ppm(d, &rgba, &w, &h);
-    if (!ok)
-    {
-        // TGA has no signature: only tried for a .tga name, or as a last resort without a name
-        std::string n = name_hint ? name_hint : "";
-        for (auto& c : n) c = (char)std::tolower((unsigned char)c);
-        const bool tga_name = n.size() >= 4 && n.compare(n.size() - 4, 4, ".tga") == 0;
-        if (tga_name || n.empty()) ok = decode_tga(d, &rgba, &w, &h);
-    }
+    ok = cap::decode_jpeg(d.data(), d.size(), &rgba, &w, &h, kMaxPixels) || decode_png(d, &rgba, &w, &h) || decode_ppm(d, &rgba, &w, &h);
+    // TGA has no signature: tried last, on the strength of its header fields alone, as stb does (stb_image.h:1095-1099)
+    if (!ok) ok = decode_tga(d, &rgba, &w, &h);
+    (void)name_hint;
     }
     catch (const std::exception&)
     {
@@ -485,7 +538,7 @@ extern "C" int cap_image_decode(const uint8_t* bytes, size_t size, const char* n
     }
     if (!ok)
     {
-        cap_set_error_("cap_image_decode: not a PNG (non-interlaced), TGA or binary PPM this build decodes");
+        cap_set_error_("cap_image_decode: not a JPEG (Huffman-coded, 8-bit), PNG, TGA or binary PNM this build decodes");
         return CAP_ERR_UNSUPPORTED;
     }
     uint8_t* p = (uint8_t*)std::malloc(rgba.size());

@@ -49,9 +49,11 @@ int cap_geometry_materials(const CapGeometry* g, CapMaterial* out_materials);
 int cap_scene_upload_geometry(CapContext* ctx, const CapGeometry* g);
 
 /* Texture file -> what TextureSystem hands to the GPU (texture_system.cpp:41-45: stbi_load(file, &w, &h, &n, 4)): 8-bit RGBA,
- * rows top to bottom, grey replicated, alpha 255 when the file has none.  Decodes PNG (non-interlaced), TGA and binary PPM
- * (capsaicin_amd/csrc/image_decode.cpp); name_hint (may be NULL) is the file name, consulted for formats without a signature.
- * Anything else returns CAP_ERR_UNSUPPORTED -- the caller then does what the reference does for a missing file: a warning and
+ * rows top to bottom, grey replicated, alpha 255 when the file has none.  Decodes JPEG (Huffman-coded baseline / progressive),
+ * PNG, TGA and binary PNM (capsaicin_amd/csrc/image_decode.cpp, jpeg_decode.cpp), pixel for pixel what stbi_load returns for the
+ * same bytes; the container is recognised from the bytes in stb's order (TGA, which has no signature, last), name_hint (may be
+ * NULL) is not consulted.  Anything else, and any file that is damaged or shorter than its header demands, returns
+ * CAP_ERR_UNSUPPORTED -- the caller then does what the reference does for a missing file: a warning and
  * a 1x1 black texel (texture_system.cpp:50-56).  Release the pixels with cap_image_free. */
 int  cap_image_decode(const uint8_t* bytes, size_t size, const char* name_hint, uint8_t** out_rgba8, uint32_t* out_width,
                       uint32_t* out_height);

@@ -52,8 +52,8 @@ def test_png_large_and_optimised(native_lib):
     assert np.array_equal(capi.image_decode(buf.getvalue()), expected(im))
 
 
-def test_png_interlaced_and_garbage_are_refused(native_lib):
-    # a hand-made IHDR with the interlace flag set
+def test_png_short_interlaced_and_garbage_are_refused(native_lib):
+    # a hand-made interlaced file whose data ends before the seventh pass (55 bytes are due)
     import struct
     import zlib
 
@@ -129,9 +129,12 @@ def test_oversized_truncated_and_bomb_inputs_end_as_errors(native_lib):
     hdr = struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, 65535, 65535, 32, 0)
     with pytest.raises(capi.CapError):
         capi.image_decode(hdr + b"\0" * 64, "big.tga")
-    hdr = struct.pack("<BBBHHBHHHHBB", 0, 1, 1, 0, 4, 8, 0, 0, 2, 2, 8, 0)
+    hdr = struct.pack("<BBBHHBHHHHBB", 0, 1, 1, 0, 4, 12, 0, 0, 2, 2, 8, 0)
     with pytest.raises(capi.CapError):
-        capi.image_decode(hdr + bytes(4) + bytes(4), "cmap8.tga")
+        capi.image_decode(hdr + bytes(8) + bytes(4), "cmap12.tga")
+    # (an 8-bit map is a map of grey values in the reference's decoder: tests/test_image_ref.py)
+    hdr = struct.pack("<BBBHHBHHHHBB", 0, 1, 1, 0, 4, 8, 0, 0, 2, 2, 8, 0)
+    assert np.array_equal(capi.image_decode(hdr + bytes([9, 8, 7, 6]) + bytes([0, 1, 2, 3]), "cmap8.tga")[..., 0], [[7, 6], [9, 8]])
     buf = io.BytesIO()
     image("RGB", 41, 19, seed=3).save(buf, "TGA", compression="tga_rle")
     for cut in range(18, len(buf.getvalue()), 11):

@@ -8,6 +8,7 @@ compared with the oracle's frames pushed through the composite blit (gamma 1 / 2
 The per-pass timing table must carry the reference's timestamp labels (gui_system.cpp:94-104; raytracing_system.cpp:1024, 1099,
 1207 and the reconstruction passes)."""
 import os
+import shutil
 import subprocess
 
 import numpy as np
@@ -111,10 +112,10 @@ def test_realtime_pipeline_with_camera_motion(native_lib, bluenoise, cornell_pat
         assert label + ":" in log
 
 
-def test_png_and_tga_textures_through_the_host_layer(native_lib, bluenoise, tmp_path):
-    """AssetLoadSystem + TextureSystem of the host layer on a textured scene whose textures are PNG and TGA files
+def test_png_tga_and_jpeg_textures_through_the_host_layer(native_lib, bluenoise, tmp_path):
+    """AssetLoadSystem + TextureSystem of the host layer on a textured scene whose textures are PNG, TGA and JPEG files
     (texture_system.cpp:41-45 loads any stb format): decoded by the layer's own decoders and rendered like the oracle renders the
-    same texels."""
+    same texels.  The JPEG is a committed fixture whose texels are what the reference's decoder made of it (tests/golden/images)."""
     PIL = pytest.importorskip("PIL.Image")
     from oracle import cap_oracle as O
     rs = np.random.RandomState(4)
@@ -122,25 +123,28 @@ def test_png_and_tga_textures_through_the_host_layer(native_lib, bluenoise, tmp_
     (tmp_path / "textures").mkdir()
     PIL.fromarray(tex[0], "RGB").save(str(tmp_path / "textures" / "a.png"))
     PIL.fromarray(tex[1], "RGB").save(str(tmp_path / "textures" / "b.tga"), compression="tga_rle")
-    (tmp_path / "s.mtl").write_text("newmtl ma\nmap_Kd a.png\nnewmtl mb\nmap_Kd b.tga\n")
+    golden = os.path.join(ROOT, "tests", "golden", "images")
+    shutil.copy(os.path.join(golden, "rgb420_optimised.jpg"), tmp_path / "textures" / "c.jpg")
+    (tmp_path / "s.mtl").write_text("newmtl ma\nmap_Kd a.png\nnewmtl mb\nmap_Kd b.tga\nnewmtl mc\nmap_Kd c.jpg\n")
     (tmp_path / "s.obj").write_text("\n".join([
         "mtllib s.mtl", "o floor", "v -2 0 -2", "v 2 0 -2", "v 2 0 2", "v -2 0 2", "vn 0 1 0", "vt 0 0", "vt 3 0", "vt 3 3", "vt 0 3",
         "usemtl ma", "f 1/1/1 4/4/1 3/3/1 2/2/1",
-        "o wall", "v -2 0 -2", "v 2 0 -2", "v 2 3 -2", "v -2 3 -2", "vn 0 0 1", "usemtl mb", "f 5/1/2 6/2/2 7/3/2 8/4/2", ""]))
+        "o wall", "v -2 0 -2", "v 2 0 -2", "v 2 3 -2", "v -2 3 -2", "vn 0 0 1", "usemtl mb", "f 5/1/2 6/2/2 7/3/2 8/4/2",
+        "o side", "v -2 0 2", "v -2 0 -2", "v -2 3 -2", "v -2 3 2", "vn 1 0 0", "usemtl mc", "f 9/1/3 10/2/3 11/3/3 12/4/3", ""]))
     w, h, n, D = 128, 72, 3, 2
     view = (0.3, 1.2, 3.5, 0.0, -0.2, -1.0, 0.03)
     out = str(tmp_path / "t.ppm")
     env = dict(os.environ, CAPSAICIN_ASSETS=os.path.join(ROOT, "assets"))
     # CAPSAICIN_ASSETS also names where textures/ is looked up: point it at a directory holding both the blue noise and the textures
-    import shutil
     shutil.copy(os.path.join(ROOT, "assets", "bluenoise256.rgba"), tmp_path / "bluenoise256.rgba")
     env["CAPSAICIN_ASSETS"] = str(tmp_path)
     p = subprocess.run([VIEWER, "--scene", str(tmp_path / "s.obj"), "--out", out, "--width", str(w), "--height", str(h), "--frames", str(n),
                         "--bounces", str(D), "--camera"] + [str(v) for v in view], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "missing" not in p.stderr, p.stderr[-2000:]
     geo = capi.Geometry(str(tmp_path / "s.obj"), str(tmp_path))
-    assert geo.texture_names == ["a.png", "b.tga"]
+    assert geo.texture_names == ["a.png", "b.tga", "c.jpg"]
     rgba = [np.concatenate([t, np.full(t.shape[:2] + (1,), 255, np.uint8)], -1) for t in tex]
+    rgba.append(np.load(os.path.join(golden, "expected.npz"))["rgb420_optimised.jpg"])
     sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes, textures=rgba)
     cam = capi.camera_from_config(dict(position=view[0:3], forward=view[3:6], focal_length=view[6], sensor_x=0.036), w, h)
     acc, _ = sc.render_accumulate(ocam_of(O, cam), bluenoise, w, h, 0, n, D, threads=8)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Host-code sanitizer pass (CPU only; GPU sanitizers are not available on this pool).
-#  1. sah_builder.cpp + obj_loader.cpp + image_decode.cpp under ASan/UBSan with a small driver (random boxes, the Cornell OBJ, a
-#     missing file; good, truncated, oversized-by-header and bomb PNG / TGA / PPM files);
+#  1. sah_builder.cpp + obj_loader.cpp + image_decode.cpp + jpeg_decode.cpp under ASan/UBSan with a small driver (random boxes, the
+#     Cornell OBJ, a missing file; good, truncated, oversized-by-header and bomb PNG / TGA / PPM files; every JPEG of
+#     tests/golden/images whole, cut at every fifth byte and with 400 random byte edits each);
 #  2. the oracle rebuilt with ASan/UBSan and the CPU oracle tests run against it (the regular .so is restored afterwards).
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -45,7 +46,8 @@ int main(int argc, char** argv)
     for (int i = 1; i < argc; ++i)
     {
         const std::string a = argv[i];
-        if (a.size() > 4 && (a.substr(a.size() - 4) == ".png" || a.substr(a.size() - 4) == ".tga" || a.substr(a.size() - 4) == ".ppm"))
+        const std::string ext = a.size() > 4 ? a.substr(a.size() - 4) : "";
+        if (ext == ".png" || ext == ".tga" || ext == ".ppm" || ext == ".jpg")
         {
             FILE* f = fopen(argv[i], "rb");
             if (!f) return 1;
@@ -66,6 +68,20 @@ int main(int argc, char** argv)
                 if (px) cap_image_free(px);
             }
             printf("image %s: %d prefixes decoded, %d refused\n", argv[i], ok, bad);
+            if (ext == ".jpg")
+            {
+                srand(12345);
+                for (int trial = 0; trial < 400; ++trial)
+                {
+                    std::vector<uint8_t> part(d);
+                    for (int e = 1 + rand() % 4; e > 0; --e) part[2 + rand() % (part.size() - 2)] = (uint8_t)rand();
+                    uint8_t* px = nullptr;
+                    uint32_t w = 0, h = 0;
+                    cap_image_decode(part.data(), part.size(), argv[i], &px, &w, &h);
+                    if (px) cap_image_free(px);
+                }
+                printf("image %s: 400 edited copies survived\n", argv[i]);
+            }
             continue;
         }
         void*     g  = nullptr;
@@ -77,7 +93,8 @@ int main(int argc, char** argv)
 }
 EOF
 g++ -std=c++17 $SAN -I"$ROOT/include" -I"$ROOT/capsaicin_amd/csrc" "$W/main.cpp" \
-    "$ROOT/capsaicin_amd/csrc/sah_builder.cpp" "$ROOT/capsaicin_amd/csrc/obj_loader.cpp" "$ROOT/capsaicin_amd/csrc/image_decode.cpp" -o "$W/host"
+    "$ROOT/capsaicin_amd/csrc/sah_builder.cpp" "$ROOT/capsaicin_amd/csrc/obj_loader.cpp" "$ROOT/capsaicin_amd/csrc/image_decode.cpp" \
+    "$ROOT/capsaicin_amd/csrc/jpeg_decode.cpp" -o "$W/host"
 python3 - "$W" <<'EOF'
 import io, struct, sys, zlib
 import numpy as np
@@ -98,7 +115,7 @@ open(w + "/bomb.png", "wb").write(png(4, 4, 8, 2, zlib.compress(b"\0" * (8 << 20
 open(w + "/huge.tga", "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, 65535, 65535, 32, 0) + b"\0" * 64)
 open(w + "/cmap8.tga", "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 1, 1, 0, 4, 8, 0, 0, 2, 2, 8, 0) + bytes(8))
 EOF
-"$W/host" "$ROOT/assets/cornell_box.obj" /nonexistent/none.obj "$W"/*.png "$W"/*.tga "$W"/*.ppm
+"$W/host" "$ROOT/assets/cornell_box.obj" /nonexistent/none.obj "$W"/*.png "$W"/*.tga "$W"/*.ppm "$ROOT"/tests/golden/images/*.jpg
 
 g++ -std=c++17 $SAN -fPIC -ffp-contract=off -mfma -fno-fast-math -pthread -shared -o "$W/libcap_oracle.so" \
     "$ROOT/oracle/cap_oracle.cpp" "$ROOT/oracle/cap_oracle_post.cpp"
