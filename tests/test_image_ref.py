@@ -62,6 +62,20 @@ def test_live_expectations_are_the_reference_decoder_s():
         assert same(ref, expected[name]), name
 
 
+REFERENCE_NOISE = "/root/reference/assets/textures/bluenoise256.png"
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_NOISE), reason="the reference tree is only in the build container")
+def test_reference_blue_noise_texture(native_lib, bluenoise):
+    """The one texture the reference ships is its random-number source (raytracing_system.cpp:642-646): the product's decoder, the
+    reference's decoder and the raw copy under assets/ (what cap_bluenoise_upload gets) agree on all 256 x 256 x 4 bytes."""
+    data = open(REFERENCE_NOISE, "rb").read()
+    got = product(data, "bluenoise256.png")
+    assert same(got, bluenoise)
+    if stb_ref.available():
+        assert same(stb_ref.decode(data), bluenoise)
+
+
 def _picture(mode, w, h, seed):
     from PIL import Image
     rs = np.random.RandomState(seed)
