@@ -62,10 +62,12 @@ struct BvhDev
     uint32_t      wide8_top;  // leading nodes a workgroup may stage in LDS (<= kWideTopNodes)
 };
 
+// One entry per texel, row-major: the RGBA8 words of (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1), indices wrapped -- what one
+// bilinear WRAP sample reads, in one 16-byte load (4 x the memory of the plain image: 16 MB for a 1024 x 1024 texture).
 struct TextureDev
 {
-    const uint8_t* rgba8;
-    uint32_t       width, height;
+    const uint4* quads;
+    uint32_t     width, height;
 };
 
 // Per-frame constants evaluated on the host with cap_math.h (camera.h:41 jitter, lighting.h:20-33 light).

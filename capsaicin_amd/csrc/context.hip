@@ -638,16 +638,38 @@ int cap_texture_upload(CapContext* c, uint32_t index, const uint8_t* rgba8, uint
         for (size_t i = old; i <= index; ++i)
         {
             // holes behave like the missing-texture texel
-            HIP_TRY(c->texture_data[i].ensure(4));
-            HIP_TRY(hipMemcpy(c->texture_data[i].p, zero_texel, 4, hipMemcpyHostToDevice));
-            c->texture_host[i] = TextureDev{c->texture_data[i].p, 1, 1};
+            static const uint8_t zero_quad[16] = {0};
+            HIP_TRY(c->texture_data[i].ensure(16));
+            HIP_TRY(hipMemcpy(c->texture_data[i].p, zero_quad, 16, hipMemcpyHostToDevice));
+            c->texture_host[i] = TextureDev{reinterpret_cast<const uint4*>(c->texture_data[i].p), 1, 1};
         }
     }
-    const size_t bytes = 4 * (size_t)width * height;
+    // stored as the bilinear footprint of every texel: (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1) with WRAP, four RGBA8 words
+    const size_t          bytes = 16 * (size_t)width * height;
+    std::vector<uint32_t> quads(4 * (size_t)width * height);
+    const uint32_t*       src = reinterpret_cast<const uint32_t*>(rgba8);
+    std::vector<uint32_t> aligned;
+    if (reinterpret_cast<uintptr_t>(rgba8) & 3u)
+    {
+        aligned.resize((size_t)width * height);
+        memcpy(aligned.data(), rgba8, 4 * (size_t)width * height);
+        src = aligned.data();
+    }
+    for (uint32_t y = 0; y < height; ++y)
+    {
+        const uint32_t y1 = y + 1 == height ? 0 : y + 1;
+        for (uint32_t x = 0; x < width; ++x)
+        {
+            const uint32_t x1 = x + 1 == width ? 0 : x + 1;
+            uint32_t*      q  = &quads[4 * ((size_t)y * width + x)];
+            q[0] = src[(size_t)y * width + x], q[1] = src[(size_t)y * width + x1];
+            q[2] = src[(size_t)y1 * width + x], q[3] = src[(size_t)y1 * width + x1];
+        }
+    }
     c->texture_data[index].release();
     HIP_TRY(c->texture_data[index].ensure(bytes));
-    HIP_TRY(hipMemcpy(c->texture_data[index].p, rgba8, bytes, hipMemcpyHostToDevice));
-    c->texture_host[index] = TextureDev{c->texture_data[index].p, width, height};
+    HIP_TRY(hipMemcpy(c->texture_data[index].p, quads.data(), bytes, hipMemcpyHostToDevice));
+    c->texture_host[index] = TextureDev{reinterpret_cast<const uint4*>(c->texture_data[index].p), width, height};
     c->textures_dirty = true;
     return CAP_OK;
 }

@@ -1285,11 +1285,22 @@ __device__ __forceinline__ v3 sample_texture(const TextureDev& tex, float u, flo
     const float    x0f = floorf(fx), y0f = floorf(fy);
     const float    wx = fx - x0f, wy = fy - y0f;
     const uint32_t x0 = wrap_texel(x0f, tex.width), y0 = wrap_texel(y0f, tex.height);
-    const uint32_t x1 = (x0 + 1 == tex.width) ? 0 : x0 + 1, y1 = (y0 + 1 == tex.height) ? 0 : y0 + 1;
-    const uchar4*  t   = reinterpret_cast<const uchar4*>(tex.rgba8);
-    const uchar4   c00 = t[y0 * tex.width + x0], c10 = t[y0 * tex.width + x1], c01 = t[y1 * tex.width + x0], c11 = t[y1 * tex.width + x1];
+    // One 16-byte load: a texture is stored as the bilinear footprint of every texel -- (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1)
+    // with WRAP applied, four RGBA8 words (cap_texture_upload).  Four scattered 4-byte loads per vertex were a quarter of the shade
+    // stage's time on the textured scene (the stage is bound by the number of divergent addresses it sends);
+    // the price is 4 x the texture memory.
+    const uint4  fq   = reinterpret_cast<const uint4*>(tex.quads)[y0 * tex.width + x0];
+    auto         rgba = [](uint32_t wd) { return make_uchar4((uint8_t)wd, (uint8_t)(wd >> 8), (uint8_t)(wd >> 16), (uint8_t)(wd >> 24)); };
+    const uchar4 c00 = rgba(fq.x), c10 = rgba(fq.y), c01 = rgba(fq.z), c11 = rgba(fq.w);
+    // byte / 255.0f without the division sequence: q = b * fl(1/255) is off by at most one ulp, and one residual step,
+    // q + fl(b - 255 q) * fl(1/255), lands on the correctly rounded quotient for every one of the 256 bytes (checked exhaustively
+    // in exact arithmetic: tests/test_oracle_kat.py::test_unorm8_is_the_division) -- 3 instructions instead of ~11
+    auto unorm8 = [](uint8_t b) {
+        const float r = 1.0f / 255.0f, fb = (float)b, q = fb * r;
+        return fmaf(fmaf(-q, 255.0f, fb), r, q);
+    };
     auto           lerp2 = [&](uint8_t a00, uint8_t a10, uint8_t a01, uint8_t a11) {
-        const float f00 = (float)a00 / 255.0f, f10 = (float)a10 / 255.0f, f01 = (float)a01 / 255.0f, f11 = (float)a11 / 255.0f;
+        const float f00 = unorm8(a00), f10 = unorm8(a10), f01 = unorm8(a01), f11 = unorm8(a11);
         const float top = fmaf(f10 - f00, wx, f00);
         const float bot = fmaf(f11 - f01, wx, f01);
         return fmaf(bot - top, wy, top);

@@ -225,3 +225,35 @@ def test_texture_sampling():
     np.testing.assert_allclose(O.sample_texture(tex, 0.5, 0.25), (0.5, 0.5, 0), atol=1e-7)
     np.testing.assert_allclose(O.sample_texture(tex, 0.0, 0.25), (0.5, 0.5, 0), atol=1e-7)
     np.testing.assert_allclose(O.sample_texture(tex, 1.25, -0.75), O.sample_texture(tex, 0.25, 0.25), atol=1e-6)
+
+
+def test_unorm8_is_the_division():
+    """kernels.hip sample_texture() turns a texel byte into b / 255.0f with a multiply and one residual step (two fmaf) instead of
+    the division the oracle performs (cap_oracle.cpp sample_texture): equal for all 256 bytes, in exact arithmetic rounded to fp32
+    once per operation (round to nearest even), which is what v_mul_f32 / v_fma_f32 and fmaf do."""
+    from fractions import Fraction
+
+    def rn32(x):  # correctly rounded fp32 value of a rational, as a Fraction
+        if x == 0:
+            return Fraction(0)
+        s, x = (-1 if x < 0 else 1), abs(x)
+        e = 0
+        while x >= 2:
+            x, e = x / 2, e + 1
+        while x < 1:
+            x, e = x * 2, e - 1
+        m = x * (1 << 23)           # 1.xxx * 2^23: 24-bit significand plus a fraction
+        n, frac = int(m), m - int(m)
+        if frac > Fraction(1, 2) or (frac == Fraction(1, 2) and n & 1):
+            n += 1
+        return s * Fraction(n, 1 << 23) * Fraction(2) ** e
+
+    r = rn32(Fraction(1, 255))
+    assert float(r) == float(np.float32(1.0) / np.float32(255.0))
+    for b in range(256):
+        fb = Fraction(b)
+        q = rn32(fb * r)
+        e = rn32(-q * 255 + fb)       # fmaf(-q, 255, b)
+        got = rn32(e * r + q)         # fmaf(e, r, q)
+        assert got == rn32(fb / 255), b
+        assert float(got) == float(np.float32(b) / np.float32(255.0))
