@@ -304,7 +304,10 @@ def test_empty_scene_and_call_order(native_lib, bluenoise):
     r.close()
 
 
-def test_textured_quad_parity(native_lib, bluenoise):
+@pytest.mark.parametrize("shape", [(16, 8), (5, 3), (1, 7), (7, 1), (2, 2)])
+def test_textured_quad_parity(native_lib, bluenoise, shape):
+    """Bilinear WRAP sampling from the footprint layout (cap_device.h TextureDev) against the oracle's four-texel form, on texture
+    extents that are odd, one texel wide or one texel high (every neighbour wraps onto the texel itself), tiled twice across a quad."""
     from oracle import cap_oracle as O
     pos = np.float32([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], [-3, -1, -1], [3, -1, -1], [3, 2, -1], [-3, 2, -1]])
     nrm = np.tile(np.float32([0, 0, 1]), (8, 1))
@@ -312,7 +315,7 @@ def test_textured_quad_parity(native_lib, bluenoise):
     idx = np.uint32([0, 1, 2, 0, 2, 3, 0, 1, 2, 0, 2, 3])
     meshes = np.uint32([[4, 0, 6, 0, 0, 0, 0, 0], [4, 4, 6, 6, 1, 1, 0, 0]])
     rs = np.random.RandomState(5)
-    tex0 = rs.randint(0, 256, (16, 8, 4)).astype(np.uint8)
+    tex0 = rs.randint(0, 256, shape + (4,)).astype(np.uint8)
     tex1 = np.zeros((4, 4, 4), np.uint8)  # black texture: kd == 0 terminates the path (rt_indirect.hlsl:108)
     tex1[::2, ::2] = 255
     w, h, D = 80, 60, 3
