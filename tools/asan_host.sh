@@ -2,7 +2,7 @@
 # Host-code sanitizer pass (CPU only; GPU sanitizers are not available on this pool).
 #  1. sah_builder.cpp + obj_loader.cpp + image_decode.cpp + jpeg_decode.cpp under ASan/UBSan with a small driver (random boxes, the
 #     Cornell OBJ, a missing file; good, truncated, oversized-by-header and bomb PNG / TGA / PPM files; every JPEG of
-#     tests/golden/images whole, cut at every fifth byte and with 400 random byte edits each);
+#     tests/golden/images and every generated file whole, cut at every fifth byte and with 400 random byte edits each);
 #  2. the oracle rebuilt with ASan/UBSan and the CPU oracle tests run against it (the regular .so is restored afterwards).
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -68,7 +68,6 @@ int main(int argc, char** argv)
                 if (px) cap_image_free(px);
             }
             printf("image %s: %d prefixes decoded, %d refused\n", argv[i], ok, bad);
-            if (ext == ".jpg")
             {
                 srand(12345);
                 for (int trial = 0; trial < 400; ++trial)
@@ -115,7 +114,8 @@ open(w + "/bomb.png", "wb").write(png(4, 4, 8, 2, zlib.compress(b"\0" * (8 << 20
 open(w + "/huge.tga", "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, 65535, 65535, 32, 0) + b"\0" * 64)
 open(w + "/cmap8.tga", "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 1, 1, 0, 4, 8, 0, 0, 2, 2, 8, 0) + bytes(8))
 EOF
-"$W/host" "$ROOT/assets/cornell_box.obj" /nonexistent/none.obj "$W"/*.png "$W"/*.tga "$W"/*.ppm "$ROOT"/tests/golden/images/*.jpg
+"$W/host" "$ROOT/assets/cornell_box.obj" /nonexistent/none.obj "$W"/*.png "$W"/*.tga "$W"/*.ppm "$ROOT"/tests/golden/images/*.jpg "$ROOT"/tests/golden/images/*.png \
+    "$ROOT"/tests/golden/images/*.tga "$ROOT"/tests/golden/images/*.ppm
 
 g++ -std=c++17 $SAN -fPIC -ffp-contract=off -mfma -fno-fast-math -pthread -shared -o "$W/libcap_oracle.so" \
     "$ROOT/oracle/cap_oracle.cpp" "$ROOT/oracle/cap_oracle_post.cpp"
