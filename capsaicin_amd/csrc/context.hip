@@ -492,6 +492,16 @@ int ensure_lane1(CapContext* c, uint32_t slots, uint32_t bounces)
 }
 }  // namespace
 
+// (x, y) -> the four RGBA8 words a bilinear WRAP sample at that texel reads (cap_device.h TextureDev)
+__global__ __launch_bounds__(256) void k_texture_footprints(const uint32_t* src, uint4* dst, uint32_t width, uint32_t height)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)width * height) return;
+    const uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i - (size_t)y * width);
+    const uint32_t x1 = x + 1 == width ? 0 : x + 1, y1 = y + 1 == height ? 0 : y + 1;
+    dst[i] = make_uint4(src[(size_t)y * width + x], src[(size_t)y * width + x1], src[(size_t)y1 * width + x], src[(size_t)y1 * width + x1]);
+}
+
 extern "C" {
 
 const char* cap_last_error(void) { return g_error.c_str(); }
@@ -644,31 +654,19 @@ int cap_texture_upload(CapContext* c, uint32_t index, const uint8_t* rgba8, uint
             c->texture_host[i] = TextureDev{reinterpret_cast<const uint4*>(c->texture_data[i].p), 1, 1};
         }
     }
-    // stored as the bilinear footprint of every texel: (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1) with WRAP, four RGBA8 words
-    const size_t          bytes = 16 * (size_t)width * height;
-    std::vector<uint32_t> quads(4 * (size_t)width * height);
-    const uint32_t*       src = reinterpret_cast<const uint32_t*>(rgba8);
-    std::vector<uint32_t> aligned;
-    if (reinterpret_cast<uintptr_t>(rgba8) & 3u)
-    {
-        aligned.resize((size_t)width * height);
-        memcpy(aligned.data(), rgba8, 4 * (size_t)width * height);
-        src = aligned.data();
-    }
-    for (uint32_t y = 0; y < height; ++y)
-    {
-        const uint32_t y1 = y + 1 == height ? 0 : y + 1;
-        for (uint32_t x = 0; x < width; ++x)
-        {
-            const uint32_t x1 = x + 1 == width ? 0 : x + 1;
-            uint32_t*      q  = &quads[4 * ((size_t)y * width + x)];
-            q[0] = src[(size_t)y * width + x], q[1] = src[(size_t)y * width + x1];
-            q[2] = src[(size_t)y1 * width + x], q[3] = src[(size_t)y1 * width + x1];
-        }
-    }
+    // stored as the bilinear footprint of every texel: (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1) with WRAP, four RGBA8 words --
+    // expanded on the device from the plain image (4 bytes per texel cross the bus, not 16)
+    const size_t texels = (size_t)width * height;
     c->texture_data[index].release();
-    HIP_TRY(c->texture_data[index].ensure(bytes));
-    HIP_TRY(hipMemcpy(c->texture_data[index].p, quads.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(c->texture_data[index].ensure(16 * texels));
+    DevBuf<uint8_t> plain;
+    HIP_TRY(plain.ensure(4 * texels));
+    HIP_TRY(hipMemcpy(plain.p, rgba8, 4 * texels, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_texture_footprints, dim3((unsigned)((texels + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(plain.p),
+                       reinterpret_cast<uint4*>(c->texture_data[index].p), width, height);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    plain.release();
     c->texture_host[index] = TextureDev{reinterpret_cast<const uint4*>(c->texture_data[index].p), width, height};
     c->textures_dirty = true;
     return CAP_OK;
