@@ -6,6 +6,8 @@
 // total order in a small fixed-order world (the reference serialises the systems anyway, capsaicin.cpp:38-40 TODO).
 #include "capsaicin.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +16,7 @@
 #include <memory>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "../../include/capsaicin_hip.h"
@@ -55,7 +58,7 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out)
     return true;
 }
 
-// texture_system.cpp:41-45: stbi_load(file, &w, &h, &n, 4) -> own decoders behind the C ABI (PNG, TGA, binary PPM)
+// texture_system.cpp:41-45: stbi_load(file, &w, &h, &n, 4) -> own decoders behind the C ABI (JPEG, PNG, TGA, binary PNM)
 bool decode_image(const std::vector<uint8_t>& d, const std::string& name, std::vector<uint8_t>* rgba, uint32_t* w, uint32_t* h)
 {
     uint8_t* px = nullptr;
@@ -113,15 +116,41 @@ void run_asset_load(World& w)
         CapGeometryView v;
         check(cap_geometry_view(geo, &v), "AssetLoadSystem");
         for (CapContext* c : w.ctxs) check(cap_scene_upload_geometry(c, geo), "AssetLoadSystem");  // the scene is replicated per GPU
-        for (uint32_t t = 0; t < v.texture_count; ++t)
+        // Files are read and decoded on a few host threads, sixteen textures at a time (a scene's worth of 2048 x 2048 JPEGs is
+        // seconds of decoding on one core); the uploads stay in texture order on this thread.
+        struct Decoded
         {
-            const std::string    full = w.assets_dir + "textures/" + cap_geometry_texture_name(geo, t);
-            std::vector<uint8_t> file, rgba;
-            uint32_t             tw = 0, th = 0;
-            const bool           ok = read_file(full, &file) && decode_image(file, full, &rgba, &tw, &th);
-            if (!ok) warn("TextureSystem: texture " + full + " missing or not decodable");  // texture_system.cpp:50-56
-            for (CapContext* c : w.ctxs)
-                check(ok ? cap_texture_upload(c, t, rgba.data(), tw, th) : cap_texture_upload(c, t, nullptr, 0, 0), "TextureSystem");
+            std::string          full;
+            std::vector<uint8_t> rgba;
+            uint32_t             w = 0, h = 0;
+            bool                 ok = false;
+        };
+        constexpr uint32_t kBatch = 16;
+        for (uint32_t first = 0; first < v.texture_count; first += kBatch)
+        {
+            const uint32_t       n = std::min(kBatch, v.texture_count - first);
+            std::vector<Decoded> dec(n);
+            for (uint32_t i = 0; i < n; ++i) dec[i].full = w.assets_dir + "textures/" + cap_geometry_texture_name(geo, first + i);
+            std::atomic<uint32_t> next{0};
+            auto                  work = [&]() {
+                for (uint32_t i; (i = next.fetch_add(1)) < n;)
+                {
+                    std::vector<uint8_t> file;
+                    dec[i].ok = read_file(dec[i].full, &file) && decode_image(file, dec[i].full, &dec[i].rgba, &dec[i].w, &dec[i].h);
+                }
+            };
+            std::vector<std::thread> pool;
+            const uint32_t           threads = std::min<uint32_t>(n, std::max(1u, std::thread::hardware_concurrency()));
+            for (uint32_t k = 1; k < threads; ++k) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                const Decoded& d = dec[i];
+                if (!d.ok) warn("TextureSystem: texture " + d.full + " missing or not decodable");  // texture_system.cpp:50-56
+                for (CapContext* c : w.ctxs)
+                    check(d.ok ? cap_texture_upload(c, first + i, d.rgba.data(), d.w, d.h) : cap_texture_upload(c, first + i, nullptr, 0, 0), "TextureSystem");
+            }
         }
         cap_geometry_free(geo);
         a.loaded = true;
