@@ -286,6 +286,9 @@ bool decode_png(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
         const size_t pw = (W - passes[p].x0 + passes[p].dx - 1) / passes[p].dx, ph = (H - passes[p].y0 + passes[p].dy - 1) / passes[p].dy;
         if (W > passes[p].x0 && H > passes[p].y0) total += ((pw * bpp_bits + 7) / 8 + 1) * ph;
     }
+    // deflate cannot expand by more than 1032 : 1 (258 bytes from two bits of a fixed-code match, RFC 1951): a stream too short for the
+    // header's size is refused before anything of that size is reserved
+    if ((uint64_t)idat.size() * 1032ull + 1032ull < (uint64_t)total) return false;
     Bytes raw;
     raw.reserve(total);
     if (!zlib_inflate(idat.data(), idat.size(), &raw, total) || raw.size() < total) return false;
@@ -409,12 +412,13 @@ bool decode_tga(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
     }
     if (pos > d.size()) return false;
     const size_t px = (size_t)(bits + 7) / 8;
-    Bytes        raw((size_t)W * H * px);
+    // the file must be able to back its header before the image is allocated: all pixels when stored plainly, at least one packet
+    // (a count byte and one pixel) per 128 pixels when run-length coded
+    const uint64_t pixels = (uint64_t)W * H, left = d.size() - pos;
+    if (rle ? ((pixels + 127) / 128) * (1 + px) > left : pixels * px > left) return false;
+    Bytes raw((size_t)pixels * px);
     if (!rle)
-    {
-        if (pos + raw.size() > d.size()) return false;
         memcpy(raw.data(), &d[pos], raw.size());
-    }
     else
     {
         size_t o = 0;

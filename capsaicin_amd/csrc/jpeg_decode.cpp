@@ -221,6 +221,12 @@ struct Decoder
             h_max = c.h > h_max ? c.h : h_max, v_max = c.v > v_max ? c.v : v_max;
         }
         mcus_x = (width + 8 * h_max - 1) / (8 * h_max), mcus_y = (height + 8 * v_max - 1) / (8 * v_max);
+        // Nothing is allocated for a header the file cannot back: every 8 x 8 block of every component is coded at least once, with
+        // a Huffman code of at least one bit, so a file of n bytes holds at most 8 n blocks (a 100-byte file may not ask for 64 Mi pixels)
+        uint64_t blocks = 0;
+        for (int i = 0; i < ncomp; ++i)
+            blocks += (uint64_t)(((width * comp[i].h + h_max - 1) / h_max + 7) / 8) * (uint64_t)(((height * comp[i].v + v_max - 1) / v_max + 7) / 8);
+        if (blocks > 8ull * n) return false;
         for (int i = 0; i < ncomp; ++i)
         {
             Component& c = comp[i];

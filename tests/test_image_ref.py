@@ -256,6 +256,11 @@ def test_corrupt_jpegs_end_as_errors(native_lib):
     sos = base.index(b"\xff\xc4")
     end = base.index(b"\xff\xda")
     assert product(base[:sos] + base[end:], "t.jpg") is None
+    # a header the file cannot back (8000 x 8000 in a 1.4 KB file: a block needs at least one coded bit) is refused before allocation
+    big = bytearray(base)
+    sof = base.index(b"\xff\xc0")
+    big[sof + 5:sof + 9] = (8000).to_bytes(2, "big") * 2
+    assert product(bytes(big), "t.jpg") is None
     # sampling factors that do not divide the largest one: no defined upsampling
     bad = bytearray(base)
     sof = base.index(b"\xff\xc0")
