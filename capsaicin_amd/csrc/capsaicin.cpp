@@ -135,8 +135,15 @@ void run_asset_load(World& w)
             auto                  work = [&]() {
                 for (uint32_t i; (i = next.fetch_add(1)) < n;)
                 {
-                    std::vector<uint8_t> file;
-                    dec[i].ok = read_file(dec[i].full, &file) && decode_image(file, dec[i].full, &dec[i].rgba, &dec[i].w, &dec[i].h);
+                    try  // an exception must not leave a worker thread: the texture then counts as missing
+                    {
+                        std::vector<uint8_t> file;
+                        dec[i].ok = read_file(dec[i].full, &file) && decode_image(file, dec[i].full, &dec[i].rgba, &dec[i].w, &dec[i].h);
+                    }
+                    catch (const std::exception&)
+                    {
+                        dec[i].ok = false;
+                    }
                 }
             };
             std::vector<std::thread> pool;
