@@ -58,7 +58,7 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out)
     return true;
 }
 
-// texture_system.cpp:41-45: stbi_load(file, &w, &h, &n, 4) -> own decoders behind the C ABI (JPEG, PNG, TGA, binary PNM)
+// texture_system.cpp:41-45: stbi_load(file, &w, &h, &n, 4) -> own decoders behind the C ABI (JPEG, PNG, BMP, TGA, binary PNM)
 bool decode_image(const std::vector<uint8_t>& d, const std::string& name, std::vector<uint8_t>* rgba, uint32_t* w, uint32_t* h)
 {
     uint8_t* px = nullptr;

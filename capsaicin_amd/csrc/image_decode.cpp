@@ -7,7 +7,8 @@
 //         format where it departs from Truevision's)
 //   PNM   binary P6 (the container tools/make_sponza_class.py writes) and P5, maxval up to 255
 //   JPEG  baseline and progressive Huffman-coded frames (jpeg_decode.cpp)
-// Anything else (BMP, GIF, PSD, HDR, PIC) is reported missing, which the reference treats as a warning and a
+//   BMP   1 / 4 / 8 bits with a palette, 16 / 24 / 32 bits (channel masks), every header size stb reads, not run-length coded
+// Anything else (GIF, PSD, HDR, PIC) is reported missing, which the reference treats as a warning and a
 // black texel (texture_system.cpp:50-56).  tests/test_image_ref.py holds every decoder to stb_image's output bit for bit.
 #include "../../include/capsaicin_scene.h"
 #include "image_decode.h"
@@ -475,6 +476,141 @@ bool decode_tga(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
     return true;
 }
 
+// ---------------------------------------------------------------- BMP
+// stb's reading again (stb_image.h:5131-5474): headers of 12 / 40 / 56 / 108 / 124 bytes; 1 / 4 / 8 bits through a BGRx palette whose
+// length follows from the data offset, 24 bits BGR, 16 / 32 bits through channel masks (defaults 5-5-5 and 8-8-8-8; the V4 / V5
+// headers' own masks; BI_BITFIELDS behind a 40-byte header), each channel widened to eight bits by bit replication; run-length
+// compression is refused; a 32-bit file whose alpha bytes are all zero is opaque; rows bottom-up unless the height is negative.
+bool decode_bmp(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
+{
+    if (d.size() < 26 || d[0] != 'B' || d[1] != 'M') return false;
+    auto u16 = [&](size_t at) -> uint32_t { return at + 2 <= d.size() ? (uint32_t)(d[at] | (d[at + 1] << 8)) : 0u; };
+    auto u32 = [&](size_t at) -> uint32_t { return at + 4 <= d.size() ? (uint32_t)d[at] | ((uint32_t)d[at + 1] << 8) | ((uint32_t)d[at + 2] << 16) | ((uint32_t)d[at + 3] << 24) : 0u; };
+    const uint32_t offset = u32(10), hsz = u32(14);
+    if (hsz != 12 && hsz != 40 && hsz != 56 && hsz != 108 && hsz != 124) return false;
+    if (d.size() < 14 + (size_t)hsz) return false;
+    int32_t  W, H;
+    uint32_t planes, bpp, compress = 0;
+    if (hsz == 12)
+        W = (int32_t)u16(18), H = (int32_t)u16(20), planes = u16(22), bpp = u16(24);
+    else
+        W = (int32_t)u32(18), H = (int32_t)u32(22), planes = u16(26), bpp = u16(28), compress = u32(30);
+    if (planes != 1 || compress == 1 || compress == 2) return false;
+    uint32_t mr = 0, mg = 0, mb = 0, ma = 0, extra = 14;
+    bool     alpha_may_be_unused = false;  // default 32-bit masks: all-zero alpha means "no alpha"
+    if (hsz == 40 || hsz == 56)
+    {
+        if (bpp == 16 || bpp == 32)
+        {
+            if (compress == 0)
+            {
+                if (bpp == 32) mr = 0xffu << 16, mg = 0xffu << 8, mb = 0xffu, ma = 0xffu << 24, alpha_may_be_unused = true;
+                else mr = 31u << 10, mg = 31u << 5, mb = 31u;
+            }
+            else if (compress == 3)
+            {
+                const size_t at = 14 + (size_t)hsz;
+                mr = u32(at), mg = u32(at + 4), mb = u32(at + 8), extra += 12;
+                if (mr == mg && mg == mb) return false;
+            }
+            else
+                return false;
+        }
+    }
+    else if (hsz == 108 || hsz == 124)
+        mr = u32(54), mg = u32(58), mb = u32(62), ma = u32(66);
+    const bool flip = H > 0;
+    if (H < 0) H = -H;
+    if (W <= 0 || H <= 0 || (uint64_t)W * (uint64_t)H > kMaxPixels) return false;
+    int64_t psize = 0;
+    if (hsz == 12)
+    {
+        if (bpp < 24) psize = ((int64_t)offset - extra - 24) / 3;
+    }
+    else if (bpp < 16)
+        psize = ((int64_t)offset - extra - hsz) >> 2;
+    uint32_t all_a = alpha_may_be_unused ? 0u : 255u;
+    rgba->assign((size_t)W * H * 4, 255);
+    size_t pos = (size_t)extra + hsz;
+    if (bpp < 16)
+    {
+        if (psize <= 0 || psize > 256 || !(bpp == 1 || bpp == 4 || bpp == 8)) return false;
+        const size_t entry = hsz == 12 ? 3 : 4;
+        if (pos + (size_t)psize * entry > d.size()) return false;
+        uint8_t pal[256][3];
+        memset(pal, 0, sizeof(pal));
+        for (int64_t i = 0; i < psize; ++i) pal[i][2] = d[pos + i * entry], pal[i][1] = d[pos + i * entry + 1], pal[i][0] = d[pos + i * entry + 2];
+        const int64_t skip = (int64_t)offset - extra - hsz - psize * (int64_t)entry;
+        if (skip < 0) return false;
+        pos += (size_t)psize * entry + (size_t)skip;
+        const size_t row = bpp == 1 ? ((size_t)W + 7) >> 3 : (bpp == 4 ? ((size_t)W + 1) >> 1 : (size_t)W), stride = (row + 3) & ~(size_t)3;
+        if (pos > d.size() || (uint64_t)stride * (H - 1) + row > d.size() - pos) return false;
+        for (int32_t y = 0; y < H; ++y)
+        {
+            const uint8_t* src = &d[pos + stride * (size_t)y];
+            uint8_t*       o   = &(*rgba)[4 * (size_t)(flip ? H - 1 - y : y) * W];
+            for (int32_t x = 0; x < W; ++x, o += 4)
+            {
+                const int v = bpp == 8 ? src[x] : (bpp == 4 ? (src[x >> 1] >> ((x & 1) ? 0 : 4)) & 15 : (src[x >> 3] >> (7 - (x & 7))) & 1);
+                o[0] = pal[v][0], o[1] = pal[v][1], o[2] = pal[v][2];
+            }
+        }
+    }
+    else
+    {
+        if (!(bpp == 16 || bpp == 24 || bpp == 32)) return false;
+        const int64_t skip = (int64_t)offset - extra - hsz;
+        if (skip < 0) return false;
+        pos += (size_t)skip;
+        const int  easy = bpp == 24 ? 1 : ((bpp == 32 && mb == 0xffu && mg == 0xff00u && mr == 0x00ff0000u && ma == 0xff000000u) ? 2 : 0);
+        auto high_bit = [](uint32_t z) { int n = -1; while (z) ++n, z >>= 1; return n; };
+        auto bit_count = [](uint32_t z) { int n = 0; while (z) n += (int)(z & 1u), z >>= 1; return n; };
+        int rs = 0, gs = 0, bs = 0, as = 0, rc = 0, gc = 0, bc = 0, ac = 0;
+        if (!easy)
+        {
+            if (!mr || !mg || !mb) return false;
+            rs = high_bit(mr) - 7, gs = high_bit(mg) - 7, bs = high_bit(mb) - 7, as = high_bit(ma) - 7;
+            rc = bit_count(mr), gc = bit_count(mg), bc = bit_count(mb), ac = bit_count(ma);
+            if (rc > 8 || gc > 8 || bc > 8 || ac > 8) return false;  // (stb's widening is undefined beyond eight bits)
+        }
+        // a channel of `bits` bits with its top bit moved to bit 7, widened to eight by replication (stb_image.h:5176-5195)
+        auto widen = [](uint32_t v, int shift, int bits) -> uint32_t {
+            static const uint32_t mul[9] = {0, 0xff, 0x55, 0x49, 0x11, 0x21, 0x41, 0x81, 0x01}, sh[9] = {0, 0, 0, 1, 0, 2, 4, 6, 0};
+            v = shift < 0 ? v << -shift : v >> shift;
+            v >>= (8 - bits);
+            return (v * mul[bits]) >> sh[bits];
+        };
+        const size_t px = bpp / 8, row = (size_t)W * px, stride = bpp == 32 ? row : (row + 3) & ~(size_t)3;
+        if (pos > d.size() || (uint64_t)stride * (H - 1) + row > d.size() - pos) return false;
+        for (int32_t y = 0; y < H; ++y)
+        {
+            const uint8_t* src = &d[pos + stride * (size_t)y];
+            uint8_t*       o   = &(*rgba)[4 * (size_t)(flip ? H - 1 - y : y) * W];
+            for (int32_t x = 0; x < W; ++x, o += 4, src += px)
+            {
+                uint32_t a = 255;
+                if (easy)
+                {
+                    o[0] = src[2], o[1] = src[1], o[2] = src[0];
+                    if (easy == 2) a = src[3];
+                }
+                else
+                {
+                    const uint32_t v = bpp == 16 ? (uint32_t)(src[0] | (src[1] << 8)) : ((uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24));
+                    o[0] = (uint8_t)widen(v & mr, rs, rc), o[1] = (uint8_t)widen(v & mg, gs, gc), o[2] = (uint8_t)widen(v & mb, bs, bc);
+                    if (ma) a = widen(v & ma, as, ac);
+                }
+                all_a |= a;
+                o[3] = (uint8_t)a;
+            }
+        }
+    }
+    if (all_a == 0)
+        for (size_t i = 3; i < rgba->size(); i += 4) (*rgba)[i] = 255;
+    *w = (uint32_t)W, *h = (uint32_t)H;
+    return true;
+}
+
 // ---------------------------------------------------------------- PNM (P5 / P6, one byte per sample)
 bool decode_ppm(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
 {
@@ -530,7 +666,7 @@ extern "C" int cap_image_decode(const uint8_t* bytes, size_t size, const char* n
     try  // no exception crosses the C ABI: a header that asks for more memory than there is ends as a status, not std::terminate
     {
     const Bytes d(bytes, bytes + size);
-    ok = cap::decode_jpeg(d.data(), d.size(), &rgba, &w, &h, kMaxPixels) || decode_png(d, &rgba, &w, &h) || decode_ppm(d, &rgba, &w, &h);
+    ok = cap::decode_jpeg(d.data(), d.size(), &rgba, &w, &h, kMaxPixels) || decode_png(d, &rgba, &w, &h) || decode_bmp(d, &rgba, &w, &h) || decode_ppm(d, &rgba, &w, &h);
     // TGA has no signature: tried last, on the strength of its header fields alone, as stb does (stb_image.h:1095-1099)
     if (!ok) ok = decode_tga(d, &rgba, &w, &h);
     (void)name_hint;
@@ -542,7 +678,7 @@ extern "C" int cap_image_decode(const uint8_t* bytes, size_t size, const char* n
     }
     if (!ok)
     {
-        cap_set_error_("cap_image_decode: not a JPEG (Huffman-coded, 8-bit), PNG, TGA or binary PNM this build decodes");
+        cap_set_error_("cap_image_decode: not a JPEG (Huffman-coded, 8-bit), PNG, BMP (not run-length coded), TGA or binary PNM this build decodes");
         return CAP_ERR_UNSUPPORTED;
     }
     uint8_t* p = (uint8_t*)std::malloc(rgba.size());

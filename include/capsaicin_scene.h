@@ -50,7 +50,7 @@ int cap_scene_upload_geometry(CapContext* ctx, const CapGeometry* g);
 
 /* Texture file -> what TextureSystem hands to the GPU (texture_system.cpp:41-45: stbi_load(file, &w, &h, &n, 4)): 8-bit RGBA,
  * rows top to bottom, grey replicated, alpha 255 when the file has none.  Decodes JPEG (Huffman-coded baseline / progressive),
- * PNG, TGA and binary PNM (capsaicin_amd/csrc/image_decode.cpp, jpeg_decode.cpp), pixel for pixel what stbi_load returns for the
+ * PNG, BMP, TGA and binary PNM (capsaicin_amd/csrc/image_decode.cpp, jpeg_decode.cpp), pixel for pixel what stbi_load returns for the
  * same bytes; the container is recognised from the bytes in stb's order (TGA, which has no signature, last), name_hint (may be
  * NULL) is not consulted.  Anything else, and any file that is damaged or shorter than its header demands, returns
  * CAP_ERR_UNSUPPORTED -- the caller then does what the reference does for a missing file: a warning and

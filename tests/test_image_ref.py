@@ -7,7 +7,7 @@ reference itself, tolerance 0:
   * test_golden_*: tests/golden/images/ (inputs) against expected.npz (stb's outputs, written by tools/make_image_fixtures.py) --
     runs wherever the product library loads;
   * test_live_*: only where oracle/_ref exists -- a few hundred more files made on the spot (PIL/libjpeg writes the common JPEG
-    layouts, tests/jpeg_craft.py the rest), each decoded by both, and the committed expectations re-derived.
+    layouts, tests/*_craft.py the rest), each decoded by both, and the committed expectations re-derived.
 """
 import io
 import itertools
@@ -16,6 +16,7 @@ import os
 import numpy as np
 import pytest
 
+import bmp_craft
 import jpeg_craft
 import png_craft
 import tga_craft
@@ -40,7 +41,7 @@ def same(got, ref):
 
 def test_golden_set_covers_every_container():
     ext = {os.path.splitext(n)[1] for n in NAMES}
-    assert ext == {".jpg", ".png", ".tga", ".ppm", ".pgm"} and len(NAMES) >= 49
+    assert ext == {".jpg", ".png", ".tga", ".bmp", ".ppm", ".pgm"} and len(NAMES) >= 57
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -235,6 +236,59 @@ def test_live_tga_layouts(native_lib):
     # the one deliberate difference: a file shorter than its header demands is an error here; stb pads it with zero bytes
     data = tga_craft.random_file(rs, 7, 5, 2, 24)[:-10]
     assert stb_ref.decode(data) is not None and product(data, "t.tga") is None
+
+
+@needs_ref
+def test_live_bmp_layouts(native_lib):
+    """BMP as stb reads it: header sizes 12 / 40 / 56 / 108 / 124, palettes of 1 / 4 / 8 bits (any length), 24 bits, 16 / 32 bits with
+    the default masks, BI_BITFIELDS behind a 40-byte header and the V4 / V5 headers' own masks (5-6-5, 4-4-4-4, 6-6-6, swapped
+    8-8-8-8), bottom-up and top-down, the all-zero alpha channel that means "opaque".  Not compared, because stb's own output is
+    undefined there (uninitialised palette entries / masks read from pixel data): OS/2 headers with a palette, BI_BITFIELDS behind a
+    56-byte header."""
+    pytest.importorskip("PIL.Image")
+    rs = np.random.RandomState(3)
+    count = 0
+
+    def both(data, what):
+        nonlocal count
+        ref = stb_ref.decode(data)
+        assert ref is not None and same(product(data, "x.bmp"), ref), what
+        count += 1
+    for (w, h), hdr, td in itertools.product([(13, 7), (1, 1), (8, 3), (5, 2)], (12, 40, 56, 108, 124), (False, True)):
+        if hdr == 12:
+            if not td:
+                both(bmp_craft.write(rs, w, h, 24, 12), (w, h, hdr))
+            continue
+        for bpp in (1, 4, 8, 24):
+            both(bmp_craft.write(rs, w, h, bpp, hdr, top_down=td), (w, h, hdr, bpp, td))
+        for bpp in (16, 32):
+            default = None if hdr in (40, 56) else ((0x7c00, 0x3e0, 0x1f, 0) if bpp == 16 else (0xff0000, 0xff00, 0xff, 0xff000000))
+            both(bmp_craft.write(rs, w, h, bpp, hdr, top_down=td, masks=default), (w, h, hdr, bpp, td))
+            if hdr == 56:
+                continue
+            sets = ((0xf800, 0x7e0, 0x1f, 0), (0x0f00, 0x00f0, 0x000f, 0xf000)) if bpp == 16 else \
+                ((0xff, 0xff00, 0xff0000, 0xff000000), (0x3f000000, 0x00fc0000, 0x0003f000, 0), (0xff0000, 0xff00, 0xff, 0))
+            for masks in sets:
+                both(bmp_craft.write(rs, w, h, bpp, hdr, masks=masks, top_down=td), (w, h, hdr, bpp, td, masks))
+    both(bmp_craft.write(rs, 9, 4, 8, 40, palette_entries=17), "17 entries")
+    both(bmp_craft.write(rs, 9, 4, 4, 40, palette_entries=5), "5 entries")
+    zero_alpha = bytearray(bmp_craft.write(rs, 6, 3, 32, 40))
+    for i in range(18):
+        zero_alpha[54 + 4 * i + 3] = 0
+    both(bytes(zero_alpha), "alpha all zero")
+    assert (product(bytes(zero_alpha), "x.bmp")[..., 3] == 255).all()
+    assert count > 250
+    # refused by both: run-length coding, a header size nobody defines, two planes
+    rle = bmp_craft.write(rs, 9, 4, 8, 40, compression=1)
+    odd = bytearray(bmp_craft.write(rs, 9, 4, 24, 40))
+    odd[14:18] = (52).to_bytes(4, "little")
+    planes = bytearray(bmp_craft.write(rs, 9, 4, 24, 40))
+    planes[26:28] = (2).to_bytes(2, "little")
+    for data in (rle, bytes(odd), bytes(planes)):
+        assert stb_ref.decode(data) is None and product(data, "x.bmp") is None
+    # the deliberate difference again: a file that ends before its last row is an error here (stb pads with zero bytes)
+    short = bmp_craft.write(rs, 9, 4, 24, 40)[:-5]
+    assert stb_ref.decode(short) is not None and product(short, "x.bmp") is None
 
 
 def test_corrupt_jpegs_end_as_errors(native_lib):

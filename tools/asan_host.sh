@@ -47,7 +47,7 @@ int main(int argc, char** argv)
     {
         const std::string a = argv[i];
         const std::string ext = a.size() > 4 ? a.substr(a.size() - 4) : "";
-        if (ext == ".png" || ext == ".tga" || ext == ".ppm" || ext == ".jpg")
+        if (ext == ".png" || ext == ".tga" || ext == ".ppm" || ext == ".jpg" || ext == ".bmp")
         {
             FILE* f = fopen(argv[i], "rb");
             if (!f) return 1;
@@ -115,7 +115,7 @@ open(w + "/huge.tga", "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0,
 open(w + "/cmap8.tga", "wb").write(struct.pack("<BBBHHBHHHHBB", 0, 1, 1, 0, 4, 8, 0, 0, 2, 2, 8, 0) + bytes(8))
 EOF
 "$W/host" "$ROOT/assets/cornell_box.obj" /nonexistent/none.obj "$W"/*.png "$W"/*.tga "$W"/*.ppm "$ROOT"/tests/golden/images/*.jpg "$ROOT"/tests/golden/images/*.png \
-    "$ROOT"/tests/golden/images/*.tga "$ROOT"/tests/golden/images/*.ppm
+    "$ROOT"/tests/golden/images/*.tga "$ROOT"/tests/golden/images/*.ppm "$ROOT"/tests/golden/images/*.bmp
 
 g++ -std=c++17 $SAN -fPIC -ffp-contract=off -mfma -fno-fast-math -pthread -shared -o "$W/libcap_oracle.so" \
     "$ROOT/oracle/cap_oracle.cpp" "$ROOT/oracle/cap_oracle_post.cpp"

@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import jpeg_craft  # noqa: E402
+import bmp_craft  # noqa: E402
 import png_craft  # noqa: E402
 import tga_craft  # noqa: E402
 from oracle import stb_ref  # noqa: E402
@@ -123,6 +124,15 @@ def corpus():
     f["craft_type2_bpp8.tga"] = tga_craft.random_file(rs, 9, 5, 2, 8)
     f["craft_type3_bpp24_rle.tga"] = tga_craft.random_file(rs, 9, 5, 3, 24, rle=True)
     f["craft_right_to_left.tga"] = tga_craft.random_file(rs, 9, 5, 2, 15, descriptor=0x10)
+    # BMP: what PIL writes, and what it does not (tests/bmp_craft.py)
+    f["rgb24.bmp"] = saved(picture("RGB", 13, 7, 50), "BMP")
+    f["palette8.bmp"] = saved(pal, "BMP")
+    f["craft_rgb565_top_down.bmp"] = bmp_craft.write(rs, 9, 5, 16, 40, masks=(0xf800, 0x7e0, 0x1f), top_down=True)
+    f["craft_rgb555.bmp"] = bmp_craft.write(rs, 9, 5, 16, 40)
+    f["craft_bgra32_v5.bmp"] = bmp_craft.write(rs, 9, 5, 32, 124, masks=(0xff0000, 0xff00, 0xff, 0xff000000))
+    f["craft_palette4.bmp"] = bmp_craft.write(rs, 9, 5, 4, 40, palette_entries=11)
+    f["craft_palette1_v4.bmp"] = bmp_craft.write(rs, 9, 5, 1, 108)
+    f["craft_os2_rgb24.bmp"] = bmp_craft.write(rs, 9, 5, 24, 12)
     # PNM
     f["rgb.ppm"] = saved(picture("RGB", 13, 5, 40), "PPM")
     f["grey.pgm"] = saved(picture("L", 13, 5, 41), "PPM")
