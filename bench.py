@@ -22,7 +22,10 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 64, 8
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.3 TB/s is the measured achievable stream rate
-TREE_SPP = 32  # frames per step of the tree-path variant = one batch (tools/tree_trace.sh and tree_pmc.sh profile the same)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming kernel reaches on this chip (MI355X_MICROARCH.md, measured: `empirical_stream_peak`)
+TREE_SPP = 32  # one batch of the tree-path variant (tools/tree_trace.sh and tree_pmc.sh profile the same)
+TREE_FULL_SPP = 128  # BASELINE configs[3]'s own sample count: four such batches
+BIG_SCALE, BIG_SPP = 8.0, 8  # big_variant: the hall at 16.8 M triangles, 8 spp
 BYTES_CLOSEST, BYTES_ANY, BYTES_VERTEX = 48, 36, 144  # SURVEY.md 8d algorithmic queue-stream bytes per ray / shaded vertex
 # vector-instruction issue peak: one wave64 instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz (MI355X_MICROARCH.md)
 VALU_PEAK_WAVE_INSTS_PER_S = 1024 * 2.4e9 / 2.0
@@ -91,14 +94,24 @@ def cpu_baseline(budget_s=12.0):
     ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0],
                          cam.sensor_size[1], cam.focal_length)
     cores = os.cpu_count() or 1
+    # All cores: frames side by side, each on its own band of threads (the oracle threads a frame over interleaved rows; one
+    # frame at a time on 256 threads spent most of its time starting and joining them: 9x over one thread in round 3).
+    import concurrent.futures as cf
+    side = max(1, min(16, cores // 16))
+    per = max(1, cores // side)
+
+    def one(frame):
+        return sum(sc.render_frame(ocam, bn, WIDTH, HEIGHT, frame, DEPTH, flags=O.FLAG_USE_BVH, threads=per)["rays"])
+
     rays, frames, t0 = 0, 0, time.time()
-    while True:
-        r = sc.render_frame(ocam, bn, WIDTH, HEIGHT, frames, DEPTH, flags=O.FLAG_USE_BVH, threads=cores)
-        rays += sum(r["rays"])
-        frames += 1
-        el = time.time() - t0
-        if el > budget_s or frames >= 16:
-            break
+    with cf.ThreadPoolExecutor(max_workers=side) as pool:
+        while True:
+            got = list(pool.map(one, range(frames, frames + side)))  # ctypes releases the GIL for the call
+            rays += sum(got)
+            frames += side
+            el = time.time() - t0
+            if el > budget_s or frames >= 64:
+                break
     # the same tracer on ONE host thread, one frame at half the resolution per axis
     w1, h1 = WIDTH // 2, HEIGHT // 2
     cam1 = capi.cornell_camera(w1, h1)
@@ -107,42 +120,28 @@ def cpu_baseline(budget_s=12.0):
     t1 = time.time()
     r1 = sc.render_frame(ocam1, bn, w1, h1, 0, DEPTH, flags=O.FLAG_USE_BVH, threads=1)
     el1 = time.time() - t1
-    return {"value": rays / el / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d frame(s) of %dx%d depth %d (of the %d spp workload), oracle BVH mode, %d threads, %.1f s" %
-                      (frames, WIDTH, HEIGHT, DEPTH, SPP, cores, el),
-            "single_thread": {"value": sum(r1["rays"]) / el1 / 1e6, "unit": "Mrays/s", "cores": 1,
+    v, v1 = rays / el / 1e6, sum(r1["rays"]) / el1 / 1e6
+    return {"value": v, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d frame(s) of %dx%d depth %d (of the %d spp workload), oracle BVH mode, %d frames side by side x %d threads, %.1f s" %
+                      (frames, WIDTH, HEIGHT, DEPTH, SPP, side, per, el),
+            "scaling_over_single_thread": v / v1,
+            "single_thread": {"value": v1, "unit": "Mrays/s", "cores": 1,
                               "sample": "1 frame of %dx%d depth %d, %.1f s" % (w1, h1, DEPTH, el1)}}
 
 
-def load_sponza_class(r, rank=0):
-    """Generates and uploads the procedural 262 k-triangle textured scene (tools/make_sponza_class.py); returns its camera."""
-    import tempfile
+def load_sponza_class(r, rank=0, scale=1.0, tex_size=256):
+    """Generates and uploads the procedural textured hall (tools/make_sponza_class.py: 262 k triangles at scale 1, 4.2 M at 4,
+    16.8 M at 8) as GeometryStorage arrays -- bit for bit what the native OBJ loader makes of the OBJ the same tool writes
+    (tests/test_obj_loader.py) -- and returns its camera."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_sponza_class as gen
     from capsaicin_amd import capi
-    tmp = tempfile.mkdtemp(prefix="sponza_class_r%d_" % rank)
-    gen.write(tmp, 1.0, 256)
-    geo = capi.Geometry(os.path.join(tmp, "sponza_class.obj"))
-    r.upload_geometry(geo)
-    for i, name in enumerate(geo.texture_names):
-        raw = open(os.path.join(tmp, "textures", name), "rb").read().split(b"\n", 3)
-        tw, th = (int(x) for x in raw[1].split())
-        rgb = np.frombuffer(raw[3], np.uint8).reshape(th, tw, 3)
-        r.upload_texture(i, np.concatenate([rgb, np.full((th, tw, 1), 255, np.uint8)], -1))
-    c = gen.camera()
-    f = np.float64(c["forward"]) / np.linalg.norm(c["forward"])
-    right = -np.cross(f, (0, 1, 0))
-    right /= np.linalg.norm(right)
-    camera = capi.CameraData()
-    camera.position[:] = c["position"]
-    camera.forward[:] = f
-    camera.right[:] = right
-    camera.up[:] = np.cross(f, right)
-    camera.focal_length = c["focal_length"]
-    camera.sensor_size[0] = 0.036
-    camera.sensor_size[1] = np.float32(0.036) * (np.float32(HEIGHT) / np.float32(WIDTH))
-    return camera
+    pos, nrm, uv, idx, meshes, texs = gen.arrays(scale, tex_size)
+    r.upload_scene(pos, nrm, uv, idx, meshes)
+    for i, t in enumerate(texs):
+        r.upload_texture(i, t)
+    return capi.camera_from_config(dict(gen.camera(), sensor_x=0.036), WIDTH, HEIGHT)
 
 
 def shard_cost(make_renderer, spp, depth, reps=3):
@@ -166,20 +165,289 @@ def shard_cost(make_renderer, spp, depth, reps=3):
     return {"ms_shard0_of_N": {str(n): out[n] for n in out},
             "predicted_parallel_efficiency": {str(n): out[1] / (n * out[n]) for n in out}}
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Extra lines (N = 1): the other BASELINE configs and the frames the north star's roofline target is about.  Each is a function
+# of (device index, torch stream handle) that builds its own context, so that `--only NAME` can run one of them alone -- which
+# is how tools/prof.sh takes per-workload kernel traces and counter passes (one workload per rocprofv3 run).
+# ---------------------------------------------------------------------------------------------------------------------------
+def timed(r, frame_begin, spp, depth, flags, reps):
+    """reps renders of spp frames each, accumulation reset in between; (seconds per render, stats summed over the reps)."""
+    r.sync()
+    r.stats_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r.accum_reset()
+        r.render(frame_begin, spp, depth, flags)
+    r.sync()
+    return (time.perf_counter() - t0) / reps, r.stats()
+
+
+def check_guards(st, what):
+    if st.guard_shade or st.guard_trace_any or st.guard_append:
+        raise SystemExit("%s: kernel bounds guards fired: shade=%d trace_any=%d append=%d last=0x%x" %
+                         (what, st.guard_shade, st.guard_trace_any, st.guard_append, st.guard_last))
+
+
+def stage_ms(sp):
+    return {"primary": sp.ms_primary, "trace_closest": sp.ms_trace_closest, "trace_any": sp.ms_trace_any, "shade": sp.ms_shade,
+            "resolve": sp.ms_resolve, "total": sp.ms_total}
+
+
+def cornell_ext_materials():
+    """cornell_box.mtl's Kd / Ke + the GGX lobes of assets/scene_config.json: the literal "Lambert+GGX ... emissive" scene."""
+    import shutil
+    import tempfile
+    from capsaicin_amd import capi
+    tmp = tempfile.mkdtemp(prefix="cornell_mtl_")
+    txt = open(os.path.join(ROOT, "assets", "cornell_box.obj")).read().replace("mtllib cornellbox.mtl", "mtllib cornell_box.mtl")
+    open(os.path.join(tmp, "c.obj"), "w").write(txt)
+    shutil.copy(os.path.join(ROOT, "assets", "cornell_box.mtl"), os.path.join(tmp, "cornell_box.mtl"))
+    mats = capi.Geometry(os.path.join(tmp, "c.obj")).materials()
+    for m, (rough, ks) in capi.scene_config()["cornell_ggx"].items():
+        mats[int(m), 3], mats[int(m), 4:7] = rough, ks
+    return mats
+
+
+def make_cornell(device_index, stream, width=WIDTH, height=HEIGHT, ext=False, shard=(0, 1)):
+    from capsaicin_amd import capi
+    r = capi.Renderer(device_index, stream)
+    r.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
+    r.upload_bluenoise(capi.load_bluenoise())
+    r.build_bvh()
+    r.set_resolution(width, height)
+    r.set_shard(*shard)
+    r.set_camera(capi.cornell_camera(width, height))
+    if ext:
+        r.upload_materials(cornell_ext_materials())
+    return r
+
+
+def make_hall(device_index, stream, scale=1.0):
+    from capsaicin_amd import capi
+    r = capi.Renderer(device_index, stream)
+    cam = load_sponza_class(r, scale=scale)
+    r.upload_bluenoise(capi.load_bluenoise())
+    bi = r.build_bvh()
+    r.set_resolution(WIDTH, HEIGHT)
+    r.set_camera(cam)
+    return r, bi
+
+
+def fused_roofline(sp, name, key, ext, quote):
+    """k_trace_shade of bounces >= 1.  Reference model: reads one 48-B queue entry (ray 32 + throughput / path id 16) per extension
+    ray, writes one 48-B entry per ray it emits and 32 B per shadow ray its own probe does not answer (CapStats::shadow_entries).
+    EXT model: 64-B entries (+ the 16 B of radiance the path has gathered), no shadow entries (the next-event ray is traced where
+    it is generated)."""
+    ext_out = sp.rays_extension - sp.rays_extension_bounce0
+    if ext:
+        kb = 64 * sp.rays_extension + 64 * ext_out + 48 * (sp.shadow_entries - sp.shadow_entries_bounce0)
+    else:
+        kb = 48 * sp.rays_extension + 48 * ext_out + 32 * (sp.shadow_entries - sp.shadow_entries_bounce0)
+    return roofline_object(name, key, kb, sp.launches_trace_closest, sp.ms_trace_closest, sp.rays_extension, quote_counters=quote), kb
+
+
+def ext_variant(dev, stream, steps, spp=SPP):
+    from capsaicin_amd import capi
+    r = make_cornell(dev, stream, ext=True)
+    r.render(0, spp, DEPTH, capi.RENDER_EXT_MATERIALS)
+    dt, es = timed(r, 0, spp, DEPTH, capi.RENDER_EXT_MATERIALS, steps)
+    check_guards(es, "ext_variant")
+    _, ep = timed(r, 0, spp, DEPTH, capi.RENDER_EXT_MATERIALS | capi.RENDER_STAGE_TIMERS, 1)
+    roof, _ = fused_roofline(ep, "k_trace_shade<bounce>=1, EXT> (exhaustive closest hit + GGX/NEE shading, fused)", "ext", True, spp == SPP)
+    r.close()
+    erays = es.rays_primary + es.rays_extension + es.rays_shadow
+    return {"workload": "cornell_box.obj + cornell_box.mtl %dx%d %dspp depth=%d, Lambert+GGX, emissive lamp + NEE (EXT model)" %
+                        (WIDTH, HEIGHT, spp, DEPTH),
+            "value": erays / steps / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
+            "rays_per_step": {"primary": es.rays_primary / steps, "extension": es.rays_extension / steps, "shadow": es.rays_shadow / steps},
+            "roofline": roof, "stage_ms": stage_ms(ep)}
+
+
+def tree_rooflines(tp, key, scene_note):
+    """The tree path's two priced kernels from one stage-timed render: k_trace_closest8 -- (A) queue bytes, 32-B ray read + 16-B hit
+    written, and (A + B) with the nodes and triangle records a ray requests (instrumented build, tools/w8_counts.py,
+    committed with the counter passes) -- and k_shade (144 B per shaded vertex; escapes priced separately)."""
+    pmc, _ = committed_counters(key)
+    trav = pmc.get("traversal_bytes_per_ray") if pmc else None
+    troof = roofline_object("k_trace_closest8 (extension rays, compressed 8-wide tree)", key, BYTES_CLOSEST * tp.rays_extension,
+                            tp.launches_trace_closest, tp.ms_trace_closest, tp.rays_extension)
+    troof["bound_note"] = scene_note
+    if trav:
+        ab = (BYTES_CLOSEST + trav) * tp.rays_extension / (tp.ms_trace_closest * 1e-3) / 1e9
+        troof.update({"traversal_bytes_per_ray": trav, "node_steps_per_ray": pmc.get("node_steps_per_ray"),
+                      "triangle_tests_per_ray": pmc.get("triangle_tests_per_ray"), "achieved_with_traversal_bytes": ab,
+                      "frac_with_traversal_bytes": ab / HBM_PEAK_GBS, "frac_with_traversal_bytes_of_achievable": ab / HBM_ACHIEVABLE_GBS})
+    if troof.get("traffic"):
+        troof["traffic_frac"] = troof["traffic"] / HBM_PEAK_GBS
+        troof["traffic_frac_of_achievable"] = troof["traffic"] / HBM_ACHIEVABLE_GBS
+    spmc, ssrc = committed_counters(key + "_shade")
+    shade_ms, shade_launches = tp.ms_shade, max(1, tp.launches_shade)
+    # bounce 0 is shaded by the camera-ray kernel (k_primary_shade): k_shade sees the vertices of bounces >= 1 -- at least
+    # shaded_vertices - rays_primary of them (not every camera ray finds a vertex: a lower bound, on purpose)
+    shade_vertices = max(0, tp.shaded_vertices - tp.rays_primary)
+    sroof = {"bound": "hbm", "kernel": "k_shade, bounces >= 1 (attributes, material, direct light, BSDF sample, queue compaction)",
+             "achieved": BYTES_VERTEX * shade_vertices / (shade_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "traffic": (spmc["hbm_bytes_per_launch"] / (shade_ms / shade_launches * 1e-3) / 1e9) if spmc else None,
+             "traffic_source": ssrc, "avg_launch_ms": shade_ms / shade_launches, "launches": int(shade_launches),
+             "bytes_per_vertex": BYTES_VERTEX, "vertices_per_step": int(shade_vertices)}
+    sroof["frac"] = sroof["achieved"] / HBM_PEAK_GBS
+    # the escaped extension rays among k_shade's items: 32 B of queue stream (hit 16 + throughput / path id 16) and a 16-B
+    # load-add-store of the path's plane entry for the sky term (rt_indirect.hlsl:94-99) each, without being a vertex
+    escapes = max(0, int(tp.rays_extension) - int(shade_vertices))
+    sroof["escapes_per_step"] = escapes
+    sroof["achieved_with_escapes"] = (BYTES_VERTEX * shade_vertices + 64 * escapes) / (shade_ms * 1e-3) / 1e9
+    sroof["frac_with_escapes"] = sroof["achieved_with_escapes"] / HBM_PEAK_GBS
+    return troof, sroof
+
+
+def tree_variant(dev, stream):
+    """BASELINE configs[3] at its own sample count: the 262 k-triangle textured hall, 1920x1080, 128 spp (four batches of 32),
+    depth 8; the stage split and the rooflines come from one stage-timed 32-spp batch (sub-key batch_32spp)."""
+    from capsaicin_amd import capi
+    r2, bi2 = make_hall(dev, stream)
+    r2.render(0, TREE_SPP, DEPTH, 0)
+    dt, ts = timed(r2, 0, TREE_FULL_SPP, DEPTH, 0, 1)
+    check_guards(ts, "tree_variant")
+    dt32, ts32 = timed(r2, 0, TREE_SPP, DEPTH, 0, 2)
+    _, tp = timed(r2, 0, TREE_SPP, DEPTH, capi.RENDER_STAGE_TIMERS, 1)
+    troof, sroof = tree_rooflines(tp, "tree", "texture-address path + vector-instruction issue + exposed latency (DESIGN.md 5): on this "
+                                  "scene the nodes and triangles a ray touches come from L2 / Infinity Cache, not HBM; achieved / frac = "
+                                  "queue-stream bytes (A), achieved_with_traversal_bytes = (A + B) requested bytes, traffic = measured HBM bytes")
+    r2.close()
+    rays = lambda s: s.rays_primary + s.rays_extension + s.rays_shadow
+    return {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d %dspp depth=%d, reference shading" %
+                        (bi2.triangle_count, WIDTH, HEIGHT, TREE_FULL_SPP, DEPTH),
+            "value": rays(ts) / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
+            "bvh": {"build": "device PLOC + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
+            "batch_32spp": {"value": rays(ts32) / 2 / dt32 / 1e6, "ms_per_step": dt32 * 1e3, "stage_ms": stage_ms(tp)},
+            "roofline": troof, "shade_roofline": sroof}
+
+
+def big_variant(dev, stream):
+    """The frames the north star's roofline target is about: a scene past every cache.  The hall at scale 8 (16.8 M triangles:
+    1.07 GB of intersection records, ~0.25 GB of wide nodes, 2.15 GB of shading records against 256 MiB of Infinity Cache), 1920x1080,
+    8 spp, depth 8, tree built by cap_bvh_build AUTO on the device."""
+    from capsaicin_amd import capi
+    t0 = time.perf_counter()
+    r, bi = make_hall(dev, stream, scale=BIG_SCALE)
+    setup_s = time.perf_counter() - t0
+    winfo = r.bvh_wide_info()
+    r.render(0, BIG_SPP, DEPTH, 0)
+    dt, bs = timed(r, 0, BIG_SPP, DEPTH, 0, 2)
+    check_guards(bs, "big_variant")
+    _, bp = timed(r, 0, BIG_SPP, DEPTH, capi.RENDER_STAGE_TIMERS, 1)
+    troof, sroof = tree_rooflines(bp, "big", "16.8 M triangles: the wide nodes and intersection records no longer fit the Infinity Cache, so "
+                                  "`traffic` (measured HBM bytes) approaches the (A + B) bytes a ray requests; frac = (A) alone, "
+                                  "frac_with_traversal_bytes = (A + B) against the 8 TB/s peak, traffic_frac = measured bytes against it")
+    r.close()
+    rays = bs.rays_primary + bs.rays_extension + bs.rays_shadow
+    n = int(bi.triangle_count)
+    return {"workload": "sponza_class hall at scale %g (procedural, %d triangles, textured) %dx%d %dspp depth=%d, reference shading" %
+                        (BIG_SCALE, n, WIDTH, HEIGHT, BIG_SPP, DEPTH),
+            "value": rays / 2 / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
+            "bvh": {"build": "device PLOC + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi.max_depth), "build_ms": float(bi.build_ms),
+                    "wide_nodes": winfo[0], "wide_depth": winfo[1], "triangles_per_s_build": n / (bi.build_ms * 1e-3),
+                    "resident_bytes": {"wide_nodes": 80 * winfo[0], "intersection_records": 64 * n, "shading_records": 128 * n}},
+            "scene_setup_s": setup_s, "roofline": troof, "shade_roofline": sroof, "stage_ms": stage_ms(bp)}
+
+
+def config3_variant(dev, stream):
+    """BASELINE configs[2], "the HBM-roofline run": cornell_box 3840x2160, 512 spp, depth 8, EXT model (next-event estimation of
+    the emissive lamp), ONE step; the roofline object comes from a stage-timed 64-spp slice of it (eight batches)."""
+    from capsaicin_amd import capi
+    w, h, spp = 3840, 2160, 512
+    r = make_cornell(dev, stream, w, h, ext=True)
+    fl = capi.RENDER_EXT_MATERIALS
+    r.render(0, 16, DEPTH, fl)
+    dt, st = timed(r, 0, spp, DEPTH, fl, 1)
+    check_guards(st, "config3_variant")
+    img = r.readback(capi.BUF_ACCUM_SUM)
+    import numpy as np
+    assert np.isfinite(img).all() and (img[..., 3] == spp).all(), "config3 image is incomplete"
+    _, sp = timed(r, 0, 64, DEPTH, fl | capi.RENDER_STAGE_TIMERS, 1)
+    roof, _ = fused_roofline(sp, "k_trace_shade<bounce>=1, EXT> at 3840x2160", "ext", True, False)
+    r.close()
+    rays = st.rays_primary + st.rays_extension + st.rays_shadow
+    return {"workload": "cornell_box.obj + cornell_box.mtl %dx%d %dspp depth=%d + next-event estimation (EXT model), 1 step" % (w, h, spp, DEPTH),
+            "value": rays / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
+            "rays_per_step": {"primary": st.rays_primary, "extension": st.rays_extension, "shadow": st.rays_shadow},
+            "roofline": roof, "stage_ms_64spp_slice": stage_ms(sp)}
+
+
+def config5_share(dev, stream):
+    """BASELINE configs[4], one rank's share: shard 0 of 8 (tiles t = 0 mod 8) of 4096x4096, 1024 spp, depth 16, mixed Lambert / GGX
+    / emissive materials (EXT model), ONE step.  Every rank's share is the same to within a tile row, so 8 x this value is the
+    8-GPU number before the frame-end gather (33.5 MB per rank)."""
+    from capsaicin_amd import capi
+    w = h = 4096
+    spp, depth = 1024, 16
+    r = make_cornell(dev, stream, w, h, ext=True, shard=(0, 8))
+    fl = capi.RENDER_EXT_MATERIALS
+    r.render(0, 16, depth, fl)
+    dt, st = timed(r, 0, spp, depth, fl, 1)
+    check_guards(st, "config5_share")
+    r.close()
+    rays = st.rays_primary + st.rays_extension + st.rays_shadow
+    return {"workload": "cornell_box.obj + cornell_box.mtl %dx%d %dspp depth=%d, Lambert/GGX/emissive (EXT model), shard 0 of 8, 1 step" %
+                        (w, h, spp, depth),
+            "value": rays / dt / 1e6, "unit": "Mrays/s (this rank)", "ms_per_step": dt * 1e3,
+            "rays_per_step": {"primary": st.rays_primary, "extension": st.rays_extension, "shadow": st.rays_shadow},
+            "predicted_8gpu_value_before_gather": 8 * rays / dt / 1e6}
+
+
+def post_chain_variant(dev, stream):
+    from capsaicin_amd import capi
+    rp = make_cornell(dev, stream)
+    camp = capi.cornell_camera(WIDTH, HEIGHT)
+    rp.render(0, 1, 2, capi.RENDER_AOV)
+    out = {"what": "Gather -> Accumulate -> BlurDisocclusion -> Blur x4 -> Combine -> TAA, ms per %dx%d frame, static camera, "
+                   "frames 3..22" % (WIDTH, HEIGHT), "algorithmic_bytes_per_frame": WIDTH * HEIGHT * 16 * 19}
+    for name, fast in (("exact", 0), ("fast_weights", 1)):
+        ps = capi.PostSettings(fast_weights=fast)
+        for f in range(3):
+            rp.post_frame(ps, f, camp)
+        rp.sync()
+        t0 = time.perf_counter()
+        for f in range(3, 23):
+            rp.post_frame(ps, f, camp)
+        rp.sync()
+        out[name + "_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    rp.close()
+    return out
+
+
+def guarded(fn, *a):
+    """An extra line must never cost the contract line."""
+    try:
+        return fn(*a)
+    except SystemExit:
+        raise
+    except Exception as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help=argparse.SUPPRESS)  # debugging only; the contract run uses 64
+    ap.add_argument("--workload", choices=("cornell", "sponza"), default="cornell",
+                    help="cornell: BASELINE configs[1], the contract line (default).  sponza: BASELINE configs[3] -- the 262 k-triangle "
+                         "textured hall, 1920x1080, 128 spp -- as the sharded workload of --gpus N (second scaling curve)")
+    ap.add_argument("--spp", type=int, default=0, help=argparse.SUPPRESS)  # debugging only; the contract run uses 64 (sponza: 128)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-tree-variant", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)  # profiling passes: no shard_cost / post_chain sections
+    ap.add_argument("--no-extras", action="store_true", help=argparse.SUPPRESS)  # profiling passes: the contract workload only
+    ap.add_argument("--only", default="", help=argparse.SUPPRESS)  # one extra workload alone (tools/prof.sh): ext, tree, big, config3, config5
     ap.add_argument("--batch-paths", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--traversal", type=int, default=0, help=argparse.SUPPRESS)  # 0 auto (contract run), 1 stack, 2 exhaustive
-    ap.add_argument("--scene", default="cornell", help=argparse.SUPPRESS)  # "sponza": extra line on the procedural 262 k-triangle scene
+    ap.add_argument("--scene", default="", help=argparse.SUPPRESS)  # old name of --workload
     args = ap.parse_args()
+    if args.scene:
+        args.workload = args.scene
+    sponza = args.workload == "sponza"
+    spp = args.spp or (TREE_FULL_SPP if sponza else SPP)
+    contract = not sponza and spp == SPP
 
     import numpy as np
     import torch
@@ -199,6 +467,17 @@ def main():
     backend = os.environ.get("CAP_BENCH_BACKEND", "nccl")
     device_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(device_index)
+
+    if args.only:
+        if world != 1:
+            raise SystemExit("--only runs on one GPU")
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            fn = {"ext": lambda d, s: ext_variant(d, s, max(1, args.steps), spp), "tree": tree_variant, "big": big_variant, "config3": config3_variant,
+                  "config5": config5_share, "post": post_chain_variant}[args.only]
+            print(json.dumps({"only": args.only, "result": fn(device_index, stream.cuda_stream)}), flush=True)
+        return
+
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -212,8 +491,8 @@ def main():
         r = capi.Renderer(device_index, stream.cuda_stream)
         scene_name = "cornell_box.obj"
         camera = capi.cornell_camera(WIDTH, HEIGHT)
-        if args.scene == "sponza":
-            # not the contract workload: BASELINE configs[3] stand-in (tools/make_sponza_class.py), tree traversal kernels
+        if sponza:
+            # BASELINE configs[3] (tools/make_sponza_class.py), tree traversal kernels
             camera = load_sponza_class(r, rank)
             scene_name = "sponza_class.obj (procedural, textured)"
         else:
@@ -304,7 +583,7 @@ def main():
 
         def step(flags=0):
             r.accum_reset()
-            r.render(0, args.spp, DEPTH, flags)
+            r.render(0, spp, DEPTH, flags)
             if exchange.startswith("cap_comm"):
                 r.comm_gather_frame()
                 return
@@ -339,8 +618,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         st = r.stats()
-        if st.guard_shade or st.guard_trace_any:
-            raise SystemExit("kernel bounds guards fired: shade=%d trace_any=%d last=0x%x" % (st.guard_shade, st.guard_trace_any, st.guard_last))
+        check_guards(st, "rank %d" % rank)
 
         # whole-job numbers: MAX time over ranks, SUM of rays over ranks
         red = torch.tensor([dt], dtype=torch.float64, device=comm_device)
@@ -357,25 +635,29 @@ def main():
         step(capi.RENDER_STAGE_TIMERS)
         fence()
         sp = r.stats()
+        # per-rank stage split of that step (a future SCALE run shows where a rank's time goes as N grows)
+        mine = [sp.ms_primary, sp.ms_trace_closest, sp.ms_trace_any, sp.ms_shade, sp.ms_resolve, sp.ms_total]
+        per_rank = [None] * world
+        if world > 1:
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
+        stage_ms_per_rank = [dict(zip(("primary", "trace_closest", "trace_any", "shade", "resolve", "total"), m)) for m in per_rank]
         roofline = None
         if rank == 0 and sp.launches_trace_closest:
             fused = sp.launches_shade == 0
             SH_ENTRY = 32  # reference-model shadow entry: (origin, path id) + (contribution, -); see DESIGN.md "Data layout"
+            quote = contract and world == 1
             if fused:
-                # k_trace_shade (bounce >= 1): reads one 48-B queue entry (ray 32 + throughput/path id 16) per extension ray,
-                # writes one 48-B extension entry per ray it emits and one 32-B shadow entry per shadow ray its own probe does not
-                # answer (CapStats::shadow_entries; DESIGN.md "algorithmic bytes")
-                ext_out = sp.rays_extension - sp.rays_extension_bounce0
-                sh_out = sp.shadow_entries - sp.shadow_entries_bounce0
-                kernel_bytes = 48 * sp.rays_extension + 48 * ext_out + SH_ENTRY * sh_out
-                kernel_name, key = "k_trace_shade<bounce>=1> (exhaustive closest hit + shading, fused)", "headline"
+                roofline, kernel_bytes = fused_roofline(sp, "k_trace_shade<bounce>=1> (exhaustive closest hit + shading, fused)", "headline",
+                                                        False, quote)
                 # + bounce-0 kernel (3 planes + its queue writes), any-hit (16-B origin read per ray, 16-B contribution read and 12 B
                 # added per unoccluded ray: counted as 16 + 12 per ray, an upper bound), resolve (48 B per path)
                 all_bytes = kernel_bytes + 48 * sp.rays_extension_bounce0 + SH_ENTRY * sp.shadow_entries_bounce0 + 48 * sp.rays_primary + \
                     (16 + 12) * sp.shadow_entries + 48 * sp.rays_primary
             else:
-                kernel_bytes = BYTES_CLOSEST * sp.rays_extension
-                kernel_name, key = "k_trace_closest8", "tree"
+                roofline = roofline_object("k_trace_closest8", "tree", BYTES_CLOSEST * sp.rays_extension, sp.launches_trace_closest,
+                                           sp.ms_trace_closest, sp.rays_extension, quote_counters=False)
                 all_bytes = BYTES_CLOSEST * sp.rays_extension + 16 * sp.rays_primary + BYTES_ANY * sp.rays_shadow + BYTES_VERTEX * sp.shaded_vertices
             # the empirical stream peak of this box, measured in the same run (1 GiB float copy, read + write)
             empirical = None
@@ -395,201 +677,47 @@ def main():
                     del src_t, dst_t
                 except Exception:
                     empirical = None
-            quote = args.spp == SPP and world == 1 and (args.scene == "cornell") == fused
-            roofline = roofline_object(kernel_name, key, kernel_bytes, sp.launches_trace_closest, sp.ms_trace_closest, sp.rays_extension,
-                                       quote_counters=quote)
             roofline.update({"empirical_stream_peak": empirical,
                              "frac_of_empirical": (roofline["achieved"] / empirical) if empirical else None,
                              "whole_step_queue_stream_gbs": all_bytes / (sp.ms_total * 1e-3) / 1e9,
-                             "stage_ms": {"primary": sp.ms_primary, "trace_closest": sp.ms_trace_closest, "trace_any": sp.ms_trace_any,
-                                          "shade": sp.ms_shade, "resolve": sp.ms_resolve, "total": sp.ms_total}})
+                             "stage_ms": stage_ms(sp)})
 
-        # Second line of the same workload with the EXT shading model (no reference counterpart) -- the literal "Lambert+GGX" of
-        # BASELINE configs[1]: the Cornell box with its MTL colours, GGX on the two boxes and the back wall
-        # (assets/scene_config.json), the emissive lamp sampled by next-event estimation.
-        ext_variant = None
-        if args.scene == "cornell" and world == 1:
-            import shutil
-            import tempfile
-            tmp = tempfile.mkdtemp(prefix="cornell_mtl_")
-            txt = open(os.path.join(ROOT, "assets", "cornell_box.obj")).read().replace("mtllib cornellbox.mtl", "mtllib cornell_box.mtl")
-            open(os.path.join(tmp, "c.obj"), "w").write(txt)
-            shutil.copy(os.path.join(ROOT, "assets", "cornell_box.mtl"), os.path.join(tmp, "cornell_box.mtl"))
-            mats = capi.Geometry(os.path.join(tmp, "c.obj")).materials()
-            for m, (rough, ks) in capi.scene_config()["cornell_ggx"].items():
-                mats[int(m), 3], mats[int(m), 4:7] = rough, ks
-            r.upload_materials(mats)
-            step(capi.RENDER_EXT_MATERIALS)
-            fence()
-            r.stats_reset()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step(capi.RENDER_EXT_MATERIALS)
-            fence()
-            edt = time.perf_counter() - t0
-            es = r.stats()
-            erays = es.rays_primary + es.rays_extension + es.rays_shadow
-            r.stats_reset()
-            step(capi.RENDER_EXT_MATERIALS | capi.RENDER_STAGE_TIMERS)
-            fence()
-            ep = r.stats()
-            # EXT entries: extension 48 B + the 16 B of radiance the path has gathered (the next-event shadow ray is traced where it is
-            # generated: no shadow entries, CapStats::shadow_entries == 0), read once and written once per ray that continues
-            ebytes = 64 * ep.rays_extension + 64 * (ep.rays_extension - ep.rays_extension_bounce0) + 48 * (ep.shadow_entries - ep.shadow_entries_bounce0)
-            ext_variant = {"workload": "cornell_box.obj + cornell_box.mtl %dx%d %dspp depth=%d, Lambert+GGX, emissive lamp + NEE (EXT model)" %
-                                       (WIDTH, HEIGHT, args.spp, DEPTH),
-                           "value": erays / edt / 1e6, "unit": "Mrays/s", "ms_per_step": edt / args.steps * 1e3,
-                           "rays_per_step": {"primary": es.rays_primary / args.steps, "extension": es.rays_extension / args.steps,
-                                             "shadow": es.rays_shadow / args.steps},
-                           "roofline": roofline_object("k_trace_shade<bounce>=1, EXT> (exhaustive closest hit + GGX/NEE shading, fused)", "ext",
-                                                       ebytes, ep.launches_trace_closest, ep.ms_trace_closest, ep.rays_extension,
-                                                       quote_counters=args.spp == SPP),
-                           "stage_ms": {"primary": ep.ms_primary, "trace_closest": ep.ms_trace_closest, "trace_any": ep.ms_trace_any,
-                                        "resolve": ep.ms_resolve, "total": ep.ms_total}}
-
-        # the general path (tree traversal, textures) on the BASELINE configs[3] stand-in, TREE_SPP spp per step (one batch of the
-        # default size: configs[3]'s 128 spp are four of them): extra line, N = 1 only.
-        # These are the BVH-traversal-bound frames of the north star: its roofline object is for the closest-hit kernel.
-        tree_variant = None
-        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant:
-            try:
-                r2 = capi.Renderer(device_index, stream.cuda_stream)
-                cam2 = load_sponza_class(r2)
-                r2.upload_bluenoise(capi.load_bluenoise())
-                bi2 = r2.build_bvh()
-                r2.set_resolution(WIDTH, HEIGHT)
-                r2.set_camera(cam2)
-                r2.render(0, TREE_SPP, DEPTH, 0)
-                r2.sync()
-                r2.stats_reset()
-                t0 = time.perf_counter()
-                for _ in range(2):
-                    r2.accum_reset()
-                    r2.render(0, TREE_SPP, DEPTH, 0)
-                r2.sync()
-                tdt = time.perf_counter() - t0
-                ts = r2.stats()
-                trays = ts.rays_primary + ts.rays_extension + ts.rays_shadow
-                r2.stats_reset()
-                r2.accum_reset()
-                r2.render(0, TREE_SPP, DEPTH, capi.RENDER_STAGE_TIMERS)
-                r2.sync()
-                tp = r2.stats()
-                # (A) queue stream: 32-B ray read + 16-B hit written per ray; (B) traversal bytes per ray = nodes
-                # visited x 80 B + triangles tested x 64 B from the instrumented build (tools/w8_counts.py), committed with the
-                # counter passes
-                pmc, _ = committed_counters("tree")
-                trav = pmc.get("traversal_bytes_per_ray") if pmc else None
-                troof = roofline_object("k_trace_closest8 (extension rays, compressed 8-wide tree)", "tree", BYTES_CLOSEST * tp.rays_extension,
-                                        tp.launches_trace_closest, tp.ms_trace_closest, tp.rays_extension)
-                troof["bound_note"] = ("texture-address path + vector-instruction issue + exposed latency (DESIGN.md 5): the nodes and "
-                                       "triangles a ray touches come from L2 / Infinity Cache, not HBM; achieved / frac = queue-stream bytes "
-                                       "(A), achieved_with_traversal_bytes = (A + B) requested bytes, traffic = measured HBM bytes")
-                if trav:
-                    ab = (BYTES_CLOSEST + trav) * tp.rays_extension / (tp.ms_trace_closest * 1e-3) / 1e9
-                    troof.update({"traversal_bytes_per_ray": trav, "achieved_with_traversal_bytes": ab,
-                                  "frac_with_traversal_bytes": ab / HBM_PEAK_GBS})
-                # the stand-alone shade stage of this path IS bound by HBM: SURVEY.md 8d's 144 B per shaded vertex (hit 16 + path state
-                # 32 read, path state 32 + extension ray 32 + shadow ray 32 written) -- the shading record of the hit triangle (96 B,
-                # random) and the texels come on top and show in `traffic` when the counters are quoted
-                spmc, ssrc = committed_counters("tree_shade")
-                shade_ms, shade_launches = tp.ms_shade, max(1, tp.launches_shade)
-                # bounce 0 is shaded by the camera-ray kernel (k_primary_shade): k_shade sees the vertices of bounces >= 1 -- at
-                # least shaded_vertices - rays_primary of them (not every camera ray finds a vertex: a lower bound, on purpose)
-                shade_vertices = max(0, tp.shaded_vertices - tp.rays_primary)
-                sroof = {"bound": "hbm", "kernel": "k_shade, bounces >= 1 (attributes, material, direct light, BSDF sample, queue compaction)",
-                         "achieved": BYTES_VERTEX * shade_vertices / (shade_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "traffic": (spmc["hbm_bytes_per_launch"] / (shade_ms / shade_launches * 1e-3) / 1e9) if spmc else None,
-                         "traffic_source": ssrc, "avg_launch_ms": shade_ms / shade_launches, "launches": int(shade_launches),
-                         "bytes_per_vertex": BYTES_VERTEX, "vertices_per_step": int(shade_vertices)}
-                sroof["frac"] = sroof["achieved"] / HBM_PEAK_GBS
-                # 56 % of k_shade's items are extension rays that escaped: each costs its 32 B of queue stream (hit 16 + throughput /
-                # path id 16) and a 16-B load-add-store of the path's plane entry for the sky term (rt_indirect.hlsl:94-99) without
-                # being a vertex -- compulsory bytes of this design that SURVEY.md 8d's per-vertex figure does not count
-                escapes = max(0, int(tp.rays_extension) - int(shade_vertices))
-                sroof["escapes_per_step"] = escapes
-                sroof["achieved_with_escapes"] = (BYTES_VERTEX * shade_vertices + 64 * escapes) / (shade_ms * 1e-3) / 1e9
-                sroof["frac_with_escapes"] = sroof["achieved_with_escapes"] / HBM_PEAK_GBS
-                tree_variant = {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d %dspp depth=%d, reference shading" %
-                                            (bi2.triangle_count, WIDTH, HEIGHT, TREE_SPP, DEPTH),
-                                "value": trays / tdt / 1e6, "unit": "Mrays/s", "ms_per_step": tdt / 2 * 1e3,
-                                "bvh": {"build": "device PLOC + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
-                                "roofline": troof, "shade_roofline": sroof,
-                                "stage_ms": {"primary": tp.ms_primary, "trace_closest": tp.ms_trace_closest, "trace_any": tp.ms_trace_any,
-                                             "shade": tp.ms_shade, "resolve": tp.ms_resolve, "total": tp.ms_total}}
-                r2.close()
-            except Exception as exc:  # the extra line must never cost the contract line
-                tree_variant = {"error": str(exc)}
-
-        # the compute side of the scaling curve on this one device (VERDICT r2 item 3): extra key, N = 1 only
+        extras = world == 1 and contract and not args.no_extras
+        s_h = stream.cuda_stream
+        # the literal "Lambert+GGX" of BASELINE configs[1] (EXT model: no reference counterpart)
+        ext = guarded(ext_variant, device_index, s_h, args.steps, spp) if (world == 1 and not sponza and not args.no_extras) else None
+        tree = guarded(tree_variant, device_index, s_h) if (extras and not args.no_tree_variant) else None
+        big = guarded(big_variant, device_index, s_h) if (extras and not args.no_tree_variant) else None
+        c3 = guarded(config3_variant, device_index, s_h) if extras else None
+        c5 = guarded(config5_share, device_index, s_h) if extras else None
+        # the compute side of the scaling curve on this one device: extra key, N = 1 only
         shard_costs = None
-        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant and not args.no_extras:
-            try:
-                def make_cornell():
-                    rc = capi.Renderer(device_index, stream.cuda_stream)
-                    rc.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
-                    rc.upload_bluenoise(capi.load_bluenoise())
-                    rc.build_bvh()
-                    rc.set_resolution(WIDTH, HEIGHT)
-                    rc.set_camera(capi.cornell_camera(WIDTH, HEIGHT))
-                    return rc
-
-                def make_tree():
-                    rt = capi.Renderer(device_index, stream.cuda_stream)
-                    camt = load_sponza_class(rt)
-                    rt.upload_bluenoise(capi.load_bluenoise())
-                    rt.build_bvh()
-                    rt.set_resolution(WIDTH, HEIGHT)
-                    rt.set_camera(camt)
-                    return rt
-                shard_costs = {"what": "ms per step of shard 0 of N on ONE MI355X (no exchange): the compute side of the 1 -> N curve",
-                               "cornell_64spp": shard_cost(make_cornell, SPP, DEPTH),
-                               "sponza_class_32spp": shard_cost(make_tree, TREE_SPP, DEPTH, reps=2)}
-            except Exception as exc:  # the extra key must never cost the contract line
-                shard_costs = {"error": str(exc)}
-
-        # the stage right after the path: ms per 1080p frame of the reconstruction chain, exact (bit-identical to the
-        # oracle) and with CapPostSettings::fast_weights (stated tolerance); extra key, N = 1 only
-        post_chain = None
-        if world == 1 and args.scene == "cornell" and args.spp == SPP and not args.no_tree_variant and not args.no_extras:
-            try:
-                rp = capi.Renderer(device_index, stream.cuda_stream)
-                rp.upload_geometry(capi.Geometry(os.path.join(ROOT, "assets", "cornell_box.obj")))
-                rp.upload_bluenoise(capi.load_bluenoise())
-                rp.build_bvh()
-                rp.set_resolution(WIDTH, HEIGHT)
-                camp = capi.cornell_camera(WIDTH, HEIGHT)
-                rp.set_camera(camp)
-                rp.render(0, 1, 2, capi.RENDER_AOV)
-                post_chain = {"what": "Gather -> Accumulate -> BlurDisocclusion -> Blur x4 -> Combine -> TAA, ms per %dx%d frame, static camera, "
-                                      "frames 3..22" % (WIDTH, HEIGHT), "algorithmic_bytes_per_frame": WIDTH * HEIGHT * 16 * 19}
-                for name, fast in (("exact", 0), ("fast_weights", 1)):
-                    ps = capi.PostSettings(fast_weights=fast)
-                    for f in range(3):
-                        rp.post_frame(ps, f, camp)
-                    rp.sync()
-                    t0 = time.perf_counter()
-                    for f in range(3, 23):
-                        rp.post_frame(ps, f, camp)
-                    rp.sync()
-                    post_chain[name + "_ms"] = (time.perf_counter() - t0) / 20 * 1e3
-                rp.close()
-            except Exception as exc:  # the extra key must never cost the contract line
-                post_chain = {"error": str(exc)}
+        if extras and not args.no_tree_variant:
+            shard_costs = guarded(lambda: {"what": "ms per step of shard 0 of N on ONE MI355X (no exchange): the compute side of the 1 -> N curve",
+                                           "cornell_64spp": shard_cost(lambda: make_cornell(device_index, s_h), SPP, DEPTH),
+                                           "sponza_class_32spp": shard_cost(lambda: make_hall(device_index, s_h)[0], TREE_SPP, DEPTH, reps=2)})
+        post_chain = guarded(post_chain_variant, device_index, s_h) if extras else None
 
         if rank == 0:
             # sanity of the product of the timed region: finite image, every pixel accumulated spp frames
             img = (r.comm_readback() if exchange.startswith("cap_comm") else image.cpu().numpy()).reshape(HEIGHT, WIDTH, 4)
-            assert np.isfinite(img).all() and (img[..., 3] == args.spp).all(), "bench image is incomplete"
-            out = {"metric": "Mrays/sec (primary+secondary), cornell_box 1080p 64spp", "value": rays / dt / 1e6, "unit": "Mrays/s",
+            assert np.isfinite(img).all() and (img[..., 3] == spp).all(), "bench image is incomplete"
+            metric = "Mrays/sec (primary+secondary), cornell_box 1080p 64spp" if not sponza else \
+                "Mrays/sec (primary+secondary), sponza_class 1080p %dspp (BASELINE configs[3]; not the contract metric)" % spp
+            out = {"metric": metric, "value": rays / dt / 1e6, "unit": "Mrays/s",
                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                    "config": {"workload": scene_name + " %dx%d %dspp depth=%d (reference shading: Lambert + directional light + sky), "
-                                          "tile-sharded over %d GPU(s)" % (WIDTH, HEIGHT, args.spp, DEPTH, world),
+                                          "tile-sharded over %d GPU(s)" % (WIDTH, HEIGHT, spp, DEPTH, world),
                               "triangles": int(bvh.triangle_count), "bvh_depth": int(bvh.max_depth),
                               "rays_per_step": {"primary": rays_p / args.steps, "extension": rays_e / args.steps, "shadow": rays_s / args.steps},
                               "parallelism": "tiles%d" % world, "exchange": exchange},
-                   "roofline": roofline, "ext_variant": ext_variant, "tree_variant": tree_variant, "shard_cost": shard_costs, "post_chain": post_chain}
+                   # BASELINE configs[1] reads "Lambert+GGX": that literal configuration is the EXT model's line below (ext_variant);
+                   # `value` is the reference's own shading model on the same scene, camera, resolution, spp and depth
+                   "value_literal_config": ext.get("value") if isinstance(ext, dict) else None,
+                   "exchange": exchange, "stage_ms_per_rank": stage_ms_per_rank,
+                   "roofline": roofline, "ext_variant": ext, "tree_variant": tree, "big_variant": big, "config3_variant": c3,
+                   "config5_share": c5, "shard_cost": shard_costs, "post_chain": post_chain}
             out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()  # rank 0, N = 1 only
             print(json.dumps(out), flush=True)
         r.close()

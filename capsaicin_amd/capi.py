@@ -41,7 +41,7 @@ class Stats(C.Structure):
                 ("launches_shade", C.c_uint64), ("rays_extension_bounce0", C.c_uint64), ("rays_shadow_bounce0", C.c_uint64),
                 ("guard_shade", C.c_uint64), ("guard_trace_any", C.c_uint64), ("guard_last", C.c_uint64), ("ms_post", C.c_double),
                 ("post_frames", C.c_uint64), ("ms_direct", C.c_double), ("ms_post_pass", C.c_double * 5), ("shadow_entries", C.c_uint64),
-                ("shadow_entries_bounce0", C.c_uint64)]
+                ("shadow_entries_bounce0", C.c_uint64), ("guard_append", C.c_uint64)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n == "ms_post_pass" else getattr(self, n)) for n, _ in self._fields_}
@@ -95,6 +95,7 @@ SYMBOLS = {
     "cap_set_shard": (_i, [_vp, _u32, _u32]),
     "cap_set_batch_paths": (_i, [_vp, _u64]),
     "cap_set_traversal": (_i, [_vp, _u32]),
+    "cap_debug_set": (_i, [_vp, _u32, _u64]),
     "cap_render": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "cap_accum_reset": (_i, [_vp]),
     "cap_sync": (_i, [_vp]),
@@ -382,6 +383,12 @@ class Renderer:
         _check(lib().cap_bvh_wide_readback(self.ctx, _p(nodes), _p(src), _p(info)), "cap_bvh_wide_readback")
         return nodes, src[:self.bvh_info().triangle_count], int(info[1]), int(info[2])
 
+    def bvh_wide_info(self):
+        """(wide nodes, depth, leading top-level nodes) of the compressed 8-wide view, without reading it back."""
+        info = np.zeros(3, np.uint32)
+        _check(lib().cap_bvh_wide_readback(self.ctx, None, None, _p(info)), "cap_bvh_wide_readback")
+        return int(info[0]), int(info[1]), int(info[2])
+
     def set_camera(self, cam):
         _check(lib().cap_camera_set(self.ctx, C.byref(cam)), "cap_camera_set")
 
@@ -398,6 +405,11 @@ class Renderer:
     def set_traversal(self, mode):
         """0 auto, 1 LBVH + LDS stack, 2 exhaustive (small scenes)."""
         _check(lib().cap_set_traversal(self.ctx, mode), "cap_set_traversal")
+
+    DEBUG_QUEUE_CAPACITY_DIV = 1
+
+    def debug_set(self, key, value):
+        _check(lib().cap_debug_set(self.ctx, key, value), "cap_debug_set")
 
     def set_batch_paths(self, n):
         _check(lib().cap_set_batch_paths(self.ctx, n), "cap_set_batch_paths")

@@ -26,7 +26,7 @@ void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueu
 // The same on the compressed 8-wide view of the tree (trace8.hip; needs bvh.wide8_ok).  work: kQueueClasses zeroed chunk-grab counters.
 void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work);
 // Any hit for the shadow-ray queue (lighting.h:48-61); unoccluded rays add contrib to target[plane index].
-// guard: 4 x uint64 {shaded vertices, malformed path ids seen by shade, by trace_any, last offender}
+// guard: 8 x uint64 {-, malformed path ids seen by shade, by trace_any, last offender, appends beyond a class's capacity, -, -, -}
 // work: kQueueClasses zeroed chunk-grab counters for this launch (exhaustive path; may be NULL for the LBVH kernels)
 void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target,
                       uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard, uint32_t* work, bool mostly_unoccluded,

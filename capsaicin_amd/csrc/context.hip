@@ -83,6 +83,10 @@ struct DevBuf
     }
 };
 
+// guard block of a context (ShadeArgs::shaded_counter): {-, malformed path ids seen by shade, by trace_any, last offender, appends
+// beyond a class's capacity, -, -, -}
+constexpr size_t kGuardWords = 8;
+
 enum StageId
 {
     ST_PRIMARY,
@@ -161,6 +165,7 @@ struct CapContext
     bool          camera_ready = false, prev_camera_ready = false;
     ScreenDev     screen{};
     uint64_t      max_batch_paths = 0;
+    uint32_t      debug_capacity_div = 1;  // cap_debug_set(CAP_DEBUG_QUEUE_CAPACITY_DIV): tests of the append guard only
     uint32_t      traversal_mode  = CAP_TRAVERSAL_AUTO;
     uint32_t      bvh_build_mode  = CAP_BVH_BUILD_AUTO;
 
@@ -289,10 +294,11 @@ int sync_and_collect(CapContext* c)
     c->pending.clear();
     if (c->pinned_shaded && c->shaded_counter.p)
     {
-        HIP_TRY(hipMemcpy(c->pinned_shaded, c->shaded_counter.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c->pinned_shaded, c->shaded_counter.p, kGuardWords * sizeof(uint64_t), hipMemcpyDeviceToHost));
         c->stats.guard_shade     = c->pinned_shaded[1];
         c->stats.guard_trace_any = c->pinned_shaded[2];
         c->stats.guard_last      = c->pinned_shaded[3];
+        c->stats.guard_append    = c->pinned_shaded[4];
     }
     return CAP_OK;
 }
@@ -444,8 +450,8 @@ int ensure_wavefront(CapContext* c, uint32_t slots, uint32_t bounces)
     HIP_TRY(c->counters.ensure(3 * (size_t)(bounces + 1) * kQueueClasses * kCounterStride));
     if (!c->shaded_counter.p)
     {
-        HIP_TRY(c->shaded_counter.ensure(4));
-        HIP_TRY(hipMemsetAsync(c->shaded_counter.p, 0, 4 * sizeof(uint64_t), c->stream));
+        HIP_TRY(c->shaded_counter.ensure(kGuardWords));
+        HIP_TRY(hipMemsetAsync(c->shaded_counter.p, 0, kGuardWords * sizeof(uint64_t), c->stream));
     }
     if (!c->accum.p || c->accum.n < c->screen.pixels_padded)
     {
@@ -539,7 +545,7 @@ int cap_ctx_create(int device_id, void* hip_stream, CapContext** out_ctx)
         }
         c->own_stream = true;
     }
-    (void)hipHostMalloc((void**)&c->pinned_shaded, 4 * sizeof(uint64_t), hipHostMallocDefault);
+    (void)hipHostMalloc((void**)&c->pinned_shaded, kGuardWords * sizeof(uint64_t), hipHostMallocDefault);
     update_screen(c, 0, 0, 0, 1);
     *out_ctx = c;
     return CAP_OK;
@@ -999,6 +1005,19 @@ int cap_set_batch_paths(CapContext* c, uint64_t max_paths)
     return CAP_OK;
 }
 
+int cap_debug_set(CapContext* c, uint32_t key, uint64_t value)
+{
+    if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_debug_set: ctx is NULL");
+    switch (key)
+    {
+    case CAP_DEBUG_QUEUE_CAPACITY_DIV:
+        if (value < 1 || value > 1024) return fail(CAP_ERR_INVALID_ARG, "cap_debug_set: capacity divisor %llu not in 1..1024", (unsigned long long)value);
+        c->debug_capacity_div = (uint32_t)value;
+        return CAP_OK;
+    default: return fail(CAP_ERR_INVALID_ARG, "cap_debug_set: unknown key %u", key);
+    }
+}
+
 int cap_set_bvh_build(CapContext* c, uint32_t mode)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_bvh_build: ctx is NULL");
@@ -1205,7 +1224,9 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         uint32_t*      work_shade = L.counters + counter_words;      // + b * per_queue: grab counters of bounce b's fused launch
         uint32_t*      work_any   = L.counters + 2 * counter_words;  // ... and of its any-hit launch
         const uint32_t total_chunks   = ns * (Ppad >> 6);
-        const uint32_t class_capacity = ((total_chunks + kQueueClasses - 1) / kQueueClasses) * 64u;
+        uint32_t       class_capacity = ((total_chunks + kQueueClasses - 1) / kQueueClasses) * 64u;
+        // (tests of the append guard: sub-queues deliberately too small -- the appends beyond them must be dropped and counted)
+        if (c->debug_capacity_div > 1) class_capacity = std::max(64u, (class_capacity / c->debug_capacity_div) & ~63u);
         const bool     last_batch = done + ns >= n_frames;
         const uint32_t aov_slot   = ((flags & CAP_RENDER_AOV) && last_batch) ? ns - 1 : ~0u;
         const uint32_t max_count  = ns * Ppad;
@@ -1429,7 +1450,7 @@ int cap_stats_reset(CapContext* c)
     HIP_TRY(hipSetDevice(c->device));
     if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
     c->stats = CapStats{};
-    if (c->shaded_counter.p) HIP_TRY(hipMemsetAsync(c->shaded_counter.p, 0, 4 * sizeof(uint64_t), c->stream));  // ordered on the context's stream
+    if (c->shaded_counter.p) HIP_TRY(hipMemsetAsync(c->shaded_counter.p, 0, kGuardWords * sizeof(uint64_t), c->stream));  // ordered on the context's stream
     return CAP_OK;
 }
 

@@ -1388,8 +1388,15 @@ __device__ __forceinline__ ShadePre shade_prefetch(const ShadeArgs& a, const Fra
 
 // Both queue appends of a wave with ONE device atomic: the extension and the shadow counter of a class sit in one 64-bit word
 // (low half = extension entries, high half = shadow entries).
-__device__ __forceinline__ void wave_append2(bool emit_ext, bool emit_shadow, uint32_t* counter_pair, uint32_t& ext_slot,
-                                             uint32_t& shadow_slot)
+//
+// Overflow guard (round 4).  A sub-queue's capacity is static because a path keeps the class it got at bounce 0 (cap_device.h); the
+// appends used to rest on that argument alone, and anything that re-classifies paths -- the XCD-band experiment of round 3, any
+// future sort -- would have written past the class's region, into its neighbour's entries or, for class 63, past the allocation.
+// Now a lane whose slot lies beyond `capacity` does not store (emit_* comes back false for it), the wave that saw it bumps word 4
+// of the guard block (CapStats::guard_append) and the consumers, which already clamp a class's count to its capacity, never read
+// what was not written.  A run in which the guard fired has lost paths: bench.py and the tests treat it as a failure.
+__device__ __forceinline__ void wave_append2(bool& emit_ext, bool& emit_shadow, uint32_t* counter_pair, uint32_t& ext_slot,
+                                             uint32_t& shadow_slot, uint32_t capacity, uint64_t* guard)
 {
     const unsigned long long me = __ballot(emit_ext), ms = __ballot(emit_shadow);
     ext_slot = shadow_slot = 0;
@@ -1407,6 +1414,16 @@ __device__ __forceinline__ void wave_append2(bool emit_ext, bool emit_shadow, ui
     const unsigned long long below = (1ull << lane) - 1ull;
     ext_slot    = lo + (uint32_t)__popcll(me & below);
     shadow_slot = hi + (uint32_t)__popcll(ms & below);
+    if (lo + (uint32_t)__popcll(me) > capacity || hi + (uint32_t)__popcll(ms) > capacity)  // wave-uniform, never true in a correct run
+    {
+        if (lane == leader)
+        {
+            atomicAdd((unsigned long long*)guard + 4, 1ull);
+            guard[3] = ((uint64_t)lo << 32) | hi;
+        }
+        emit_ext    = emit_ext && ext_slot < capacity;
+        emit_shadow = emit_shadow && shadow_slot < capacity;
+    }
 }
 
 // Diagnostic build only (-DCAP_STAMPS): per-phase shader-clock sums of the fused kernel, see tools/stamps.py.
@@ -1635,7 +1652,7 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
         // a.shadow.count == a.out.count + 1: both counters of a class share one 64-bit word (one atomic per wave for both queues)
         uint32_t ei, si;
         STAMP(st, 2, true);  // shading inputs arrived + shading ALU
-        wave_append2(emit_ext, emit_shadow, a.out.count + klass * kCounterStride, ei, si);
+        wave_append2(emit_ext, emit_shadow, a.out.count + klass * kCounterStride, ei, si, a.out.class_capacity, a.shaded_counter);
         STAMP(st, 3, true);  // append atomic returned
         ei += klass * a.out.class_capacity;
         si += klass * a.shadow.class_capacity;
@@ -1847,7 +1864,7 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
         }
     }
     uint32_t ei, si;
-    wave_append2(emit_ext, emit_shadow, a.out.count + klass * kCounterStride, ei, si);  // (INLINE: the shadow counter still counts the rays)
+    wave_append2(emit_ext, emit_shadow, a.out.count + klass * kCounterStride, ei, si, a.out.class_capacity, a.shaded_counter);  // (INLINE: the shadow counter still counts the rays)
     ei += klass * a.out.class_capacity;
     si += klass * a.shadow.class_capacity;
     if (INLINE)

@@ -136,6 +136,11 @@ typedef struct CapStats
      * rest become entries. */
     uint64_t shadow_entries;
     uint64_t shadow_entries_bounce0;
+    /* Waves whose queue append ran past the capacity of their class's sub-queue: always 0 in a correct run (a path keeps the class
+     * it got at bounce 0, so a sub-queue cannot receive more entries than the class has paths).  The entries beyond the capacity are
+     * NOT stored -- nothing is written out of bounds -- and their paths are lost; guard_last then holds the two counter values the
+     * offending wave saw (extension << 32 | shadow).  cap_debug_set(CAP_DEBUG_QUEUE_CAPACITY_DIV) provokes it for the tests. */
+    uint64_t guard_append;
 } CapStats;
 
 typedef struct CapBvhInfo
@@ -209,6 +214,14 @@ int cap_set_resolution(CapContext* ctx, uint32_t width, uint32_t height);
 int cap_set_shard(CapContext* ctx, uint32_t shard_index, uint32_t shard_count);
 /* Upper bound of (frame, pixel) paths kept in flight per batch (0 = default). */
 int cap_set_batch_paths(CapContext* ctx, uint64_t max_paths);
+/* Test hooks (no reference counterpart; never needed by a host program).  CAP_DEBUG_QUEUE_CAPACITY_DIV: the sub-queues of the next
+ * renders get 1 / value of the capacity they need (value 1 = normal), so that the kernels' append guard (CapStats::guard_append) can
+ * be seen to fire -- entries beyond a sub-queue are dropped and counted, never written. */
+enum
+{
+    CAP_DEBUG_QUEUE_CAPACITY_DIV = 1
+};
+int cap_debug_set(CapContext* ctx, uint32_t key, uint64_t value);
 /* Traversal strategy of the trace kernels (same hits either way): AUTO picks EXHAUSTIVE for scenes of at most 64
  * triangles (wave-uniform test of every triangle, no stack) and STACK (LBVH + per-lane LDS stack) otherwise. */
 typedef enum CapTraversal

@@ -1,0 +1,132 @@
+"""Scenes past the caches.  The reference's pools admit 60 M vertices and 60 M indices
+(asset_load_system.h:43-45, blas_system.cpp:27-65 builds over whatever they hold); until round 4 nothing above 262 k triangles
+had been built, traced or checked here.  The procedural hall of tools/make_sponza_class.py at scale 4 is 4.2 M triangles
+(0.27 GB of intersection records + 0.06 GB of wide nodes + 0.54 GB of shading records: past the 256-MiB Infinity Cache); at
+scale 8 -- bench.py's `big_variant` -- 16.8 M.
+
+* 4.2 M triangles, 1920x1080, depth 8, the three builders (device clustering = AUTO, device Morton hierarchy, host SAH): one
+  WHOLE frame against the oracle for the AUTO tree (six planes and the three ray counters, tolerance 0), three 8-row crops
+  (top, middle, bottom: `rows=`) for the other two with counters equal to the AUTO render's, structural invariants of every
+  tree (each triangle in exactly one leaf, depth within the kernels' stacks, the 8-wide view in use), guards silent.
+* 16.8 M triangles, AUTO build: oracle crops bit-exact, an accumulated 2-spp render finite with .w == spp.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from capsaicin_amd import capi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+PLANES = (("gbuffer_geo", capi.BUF_GBUFFER_GEO), ("albedo", capi.BUF_ALBEDO), ("direct", capi.BUF_DIRECT),
+          ("normal_depth", capi.BUF_NORMAL_DEPTH), ("indirect", capi.BUF_INDIRECT), ("combined", capi.BUF_COMBINED))
+W, H, D = 1920, 1080, 8
+CROPS = ((0, 8), (536, 544), (1072, 1080))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _camera():
+    import make_sponza_class as gen
+    c = dict(gen.camera(), sensor_x=0.036)
+    return capi.camera_from_config(c, W, H)
+
+
+def _renderer(arrays, bluenoise, build):
+    pos, nrm, uv, idx, meshes, texs = arrays
+    r = capi.Renderer(0)
+    r.set_bvh_build(build)
+    r.upload_scene(pos, nrm, uv, idx, meshes)
+    for i, t in enumerate(texs):
+        r.upload_texture(i, t)
+    r.upload_bluenoise(bluenoise)
+    info = r.build_bvh()
+    r.set_resolution(W, H)
+    r.set_camera(_camera())
+    return r, info
+
+
+def _oracle(arrays):
+    from oracle import cap_oracle as O
+    pos, nrm, uv, idx, meshes, texs = arrays
+    cam = _camera()
+    sc = O.Scene(pos, nrm, uv, idx, meshes, textures=texs)
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1],
+                         cam.focal_length)
+    return O, sc, ocam
+
+
+def _check_tree(r, info, ntri):
+    assert info.triangle_count == ntri and info.node_count == ntri - 1 and 16 < info.max_depth <= 64
+    _, leaves = r.bvh_readback()
+    assert np.array_equal(np.sort(leaves), np.arange(ntri, dtype=np.uint32))  # every triangle in exactly one leaf
+    winfo = np.zeros(3, np.uint32)
+    capi._check(capi.lib().cap_bvh_wide_readback(r.ctx, None, None, capi._p(winfo)), "cap_bvh_wide_readback")
+    assert 0 < winfo[0] <= ntri // 2 + 16 and 0 < winfo[1] <= 21  # the 8-wide view exists and fits the kernels' pair stacks
+
+
+def _compare_crops(r, sc, O, ocam, bluenoise, frame, threads):
+    for y0, y1 in CROPS:
+        ref = sc.render_frame(ocam, bluenoise, W, H, frame, D, flags=O.FLAG_USE_BVH, threads=threads, rows=(y0, y1))
+        for name, kind in PLANES:
+            got = r.readback(kind)[y0:y1]
+            nbad = int((bits(got) != bits(ref[name][y0:y1])).any(-1).sum())
+            assert nbad == 0, "rows %d..%d, %s: %d pixels differ" % (y0, y1, name, nbad)
+
+
+def test_4m_triangles_three_builders(native_lib, bluenoise):
+    import make_sponza_class as gen
+    arrays = gen.arrays(4.0, 256)
+    ntri = arrays[3].size // 3
+    assert 4_000_000 < ntri < 4_400_000
+    O, sc, ocam = _oracle(arrays)
+    threads = min(64, os.cpu_count() or 8)
+    frame = 3
+    auto_rays = None
+    for build in (capi.Renderer.BVH_BUILD_AUTO, capi.Renderer.BVH_BUILD_LBVH, capi.Renderer.BVH_BUILD_SAH):
+        r, info = _renderer(arrays, bluenoise, build)
+        _check_tree(r, info, ntri)
+        r.render(frame, 1, D, capi.RENDER_AOV)
+        s = r.stats()
+        assert s.guard_shade == 0 and s.guard_trace_any == 0 and s.guard_append == 0
+        assert s.launches_shade > 0 and s.rays_primary == W * H
+        if build == capi.Renderer.BVH_BUILD_AUTO:
+            ref = sc.render_frame(ocam, bluenoise, W, H, frame, D, flags=O.FLAG_USE_BVH, threads=threads)
+            for name, kind in PLANES:
+                nbad = int((bits(r.readback(kind)) != bits(ref[name])).any(-1).sum())
+                assert nbad == 0, "%s: %d pixels differ" % (name, nbad)
+            assert (s.rays_primary, s.rays_extension, s.rays_shadow) == ref["rays"]
+            auto_rays = ref["rays"]
+        else:
+            _compare_crops(r, sc, O, ocam, bluenoise, frame, threads)
+            assert (s.rays_primary, s.rays_extension, s.rays_shadow) == auto_rays  # same hits whatever the tree
+        r.close()
+
+
+def test_16m_triangles(native_lib, bluenoise):
+    import make_sponza_class as gen
+    arrays = gen.arrays(8.0, 256)
+    ntri = arrays[3].size // 3
+    assert 16_000_000 < ntri < 17_500_000
+    r, info = _renderer(arrays, bluenoise, capi.Renderer.BVH_BUILD_AUTO)
+    _check_tree(r, info, ntri)
+    frame = 11
+    r.render(frame, 1, D, capi.RENDER_AOV)
+    s = r.stats()
+    assert s.guard_shade == 0 and s.guard_trace_any == 0 and s.guard_append == 0 and s.rays_primary == W * H
+    O, sc, ocam = _oracle(arrays)
+    _compare_crops(r, sc, O, ocam, bluenoise, frame, min(64, os.cpu_count() or 8))
+    spp = 2
+    r.accum_reset()
+    r.stats_reset()
+    r.render(0, spp, D, 0)
+    a, s = r.readback(capi.BUF_ACCUM_SUM), r.stats()
+    assert np.isfinite(a).all() and (a[..., 3] == spp).all() and (a[..., :3] >= 0).all()
+    assert s.rays_primary == spp * W * H and s.guard_shade == 0 and s.guard_trace_any == 0 and s.guard_append == 0
+    r.close()

@@ -102,3 +102,20 @@ def test_empty_file(native_lib, tmp_path):
     (tmp_path / "e.obj").write_text("# nothing\n")
     g = capi.Geometry(str(tmp_path / "e.obj"))
     assert g.meshes.shape[0] == 0 and g.indices.size == 0
+
+
+def test_scene_arrays_equal_the_obj_round_trip(native_lib, tmp_path):
+    """tools/make_sponza_class.py arrays(): the in-memory form the multi-million-triangle scenes use (no OBJ text in between) is
+    the GeometryStorage the native loader makes of the OBJ the same tool writes, bit for bit, textures included."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_sponza_class as gen
+    gen.write(str(tmp_path), 0.1, 64)
+    geo = capi.Geometry(os.path.join(str(tmp_path), "sponza_class.obj"))
+    pos, nrm, uv, idx, meshes, texs = gen.arrays(0.1, 64)
+    assert np.array_equal(geo.positions.view(np.uint32), pos.reshape(-1).view(np.uint32))
+    assert np.array_equal(geo.normals.view(np.uint32), nrm.reshape(-1).view(np.uint32))
+    assert np.array_equal(geo.texcoords.view(np.uint32), uv.reshape(-1).view(np.uint32))
+    assert np.array_equal(geo.indices, idx) and np.array_equal(geo.meshes, meshes)
+    for name, t in zip(geo.texture_names, texs):
+        assert np.array_equal(capi.image_decode(open(os.path.join(str(tmp_path), "textures", name), "rb").read(), name), t)

@@ -7,9 +7,14 @@ set -e
 TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
-python tools/make_traffic.py "$TAG" gpurun_out/w8_counts.json > /dev/null
+python tools/make_traffic.py "$TAG" gpurun_out/w8_counts.json gpurun_out/w8_counts_big.json > /dev/null
 python tools/prof_summary.py > "profiles/${TAG}_rocprofv3_summary.txt" 2>&1
-cp "$(ls -t gpurun_out/prof_kt/*/*kernel_stats.csv | head -1)" "profiles/${TAG}_kernel_stats.csv"
+# one table per workload (cornell / ext / tree on one lane / big on one lane): every avg_launch_ms of the bench line can be
+# recomputed from one file
+for wl in cornell ext tree big; do
+    f=$(ls -t gpurun_out/prof_${wl}_kt/*/*kernel_stats.csv 2>/dev/null | head -1)
+    [ -n "$f" ] && cp "$f" "profiles/${TAG}_kernel_stats_${wl}.csv"
+done
 {
     echo "# tools/tree_trace.sh: per-launch durations, one batch (32 spp) of the 262 k-triangle scene"
     cat gpurun_out/tree_trace.txt
@@ -22,6 +27,8 @@ cp "$(ls -t gpurun_out/prof_kt/*/*kernel_stats.csv | head -1)" "profiles/${TAG}_
     echo
     echo "# tools/w8_counts.py (diagnostic build): traversal steps of k_trace_closest8 per ray"
     tail -1 gpurun_out/w8_counts.json
+    echo "# the same on the 16.8 M-triangle hall (bench.py big_variant)"
+    tail -1 gpurun_out/w8_counts_big.json
 } > "profiles/${TAG}_tree_path.txt"
 {
     echo "# tools/post_trace.sh: reconstruction chain at 1920x1080 (kernel trace of tools/time_post.py), exact weights"

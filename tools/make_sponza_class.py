@@ -198,6 +198,34 @@ def write(out_dir, scale=1.0, tex_size=1024):
     return ntri
 
 
+def arrays(scale=1.0, tex_size=1024):
+    """The same scene as GeometryStorage-layout arrays, without the OBJ text in between (what `write` + the OBJ loader produce for
+    it, vertex for vertex: every `f` line of `write` uses one index for position / uv / normal, so the loader's pools are the
+    meshes' own vertex arrays): (positions [V,3], normals [V,3], texcoords [V,2] float32, mesh-local indices [I] uint32,
+    mesh descriptors [12,8] uint32 in MeshComponent layout, textures: 12 x [tex_size, tex_size, 4] uint8).  For scenes the OBJ
+    round trip would make gigabytes of text of: scale 4 is 4.2 M triangles, scale 8 is 16.8 M."""
+    meshes = build(scale)
+    rng = PCG32(0x5EED, 7)
+    P, N, T, I, D, texs = [], [], [], [], [], []
+    voff = ioff = 0
+    for m, (name, mat, kind, (p, n, t, tris)) in enumerate(meshes):
+        img = texture(kind, rng, tex_size)
+        texs.append(np.concatenate([img, np.full(img.shape[:2] + (1,), 255, np.uint8)], -1))
+        # the loader numbers a mesh's vertices in the order the faces first use them (asset_load_system.cpp:97-141)
+        flat = tris.reshape(-1)
+        uniq, first = np.unique(flat, return_index=True)
+        order = uniq[np.argsort(first, kind="stable")]
+        remap = np.zeros(len(p), np.int64)
+        remap[order] = np.arange(len(order))
+        p, n, t, tris = p[order], n[order], t[order], remap[flat].reshape(-1, 3)
+        P.append(p.astype(np.float32)), N.append(n.astype(np.float32)), T.append(t.astype(np.float32))
+        I.append(tris.astype(np.uint32).reshape(-1))
+        D.append([len(p), voff, 3 * len(tris), ioff, m, m, 0, 0])
+        voff += len(p)
+        ioff += 3 * len(tris)
+    return (np.concatenate(P), np.concatenate(N), np.concatenate(T), np.concatenate(I), np.uint32(D), texs)
+
+
 def camera():
     """Viewpoint used by tests and the extra bench line: inside the hall, looking down its length."""
     import json

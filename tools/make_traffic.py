@@ -2,7 +2,9 @@
 """profiles/rNN_traffic.json from the PMC passes of tools/prof.sh (gpurun_out/prof_pmc_*): per-launch HBM bytes (FETCH_SIZE doubled
 as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE) and vector instructions of the three kernels bench.py prices, plus
 the hash of the kernel sources the passes were taken on (bench.py quotes the numbers only while it matches).
-Usage: python tools/make_traffic.py r02 [w8_counts.json]   -- the optional file is the output line of tools/w8_counts.py."""
+Usage: python tools/make_traffic.py r04 [w8_counts.json [w8_counts_big.json]]   -- the optional files are the output lines of
+tools/w8_counts.py on the 262 k-triangle and on the 16.8 M-triangle hall.  Every workload has its own passes (tools/prof.sh), so
+a kernel that several workloads launch (k_trace_closest8: tree and big) is priced per workload."""
 import csv
 import glob
 import json
@@ -14,8 +16,10 @@ sys.path.insert(0, root)
 import bench  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-KERNELS = {"headline": "k_trace_shade<false, false, false, true>", "ext": "k_trace_shade<false, true, false, true>",
-           "tree": "k_trace_closest8", "tree_shade": "k_shade<"}
+# key -> (workload whose passes are read, kernel name)
+KERNELS = {"headline": ("cornell", "k_trace_shade<false, false, false, true>"), "ext": ("ext", "k_trace_shade<false, true, false, true>"),
+           "tree": ("tree", "k_trace_closest8"), "tree_shade": ("tree", "k_shade<"), "tree_any": ("tree", "k_trace_any<"),
+           "big": ("big", "k_trace_closest8"), "big_shade": ("big", "k_shade<"), "big_any": ("big", "k_trace_any<")}
 
 
 def listed_passes():
@@ -45,26 +49,29 @@ def total(pass_glob, counter, kernel):
 
 PASSES = listed_passes()
 out = {"source_sha256": bench.kernel_source_sha(), "kernels": {},
-       "method": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ block, each in its own run, no trace options) of `python3 "
-                 "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` (tools/prof.sh); counters summed over the kernel's dispatches and "
+       "method": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ block, each in its own run, no trace options), one workload per "
+                 "run: `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` (headline), `bench.py --only ext`, and with "
+                 "CAP_NO_TWO_LANES=1 `bench.py --only tree` / `--only big` (tools/prof.sh); counters summed over the kernel's dispatches and "
                  "divided by their number; FETCH_SIZE / WRITE_SIZE are KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for "
                  "gfx950; per-kernel table in profiles/%s_rocprofv3_summary.txt" % tag}
-for key, name in KERNELS.items():
-    fetch, n = total("prof_pmc_FETCH_SIZE", "FETCH_SIZE", name)
-    write, n2 = total("prof_pmc_WRITE_SIZE", "WRITE_SIZE", name)
-    valu, n3 = total("prof_pmc_SQ_WAVES*", "SQ_INSTS_VALU", name)
+for key, (wl, name) in KERNELS.items():
+    fetch, n = total("prof_%s_pmc_FETCH_SIZE" % wl, "FETCH_SIZE", name)
+    write, n2 = total("prof_%s_pmc_WRITE_SIZE" % wl, "WRITE_SIZE", name)
+    valu, n3 = total("prof_%s_pmc_SQ_WAVES*" % wl, "SQ_INSTS_VALU", name)
     if not n:
         continue
     assert n == n2, (key, n, n2)
-    k = {"kernel": "cap::" + name, "dispatches": n, "FETCH_SIZE_KB_sum": fetch, "WRITE_SIZE_KB_sum": write,
+    k = {"kernel": "cap::" + name, "workload": wl, "dispatches": n, "FETCH_SIZE_KB_sum": fetch, "WRITE_SIZE_KB_sum": write,
          "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / n}
     if n3:
         k["valu_insts_per_launch"] = valu / n3
     out["kernels"][key] = k
-if len(sys.argv) > 2 and "tree" in out["kernels"]:
-    c = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-    out["kernels"]["tree"].update({"traversal_bytes_per_ray": c["traversal_bytes_per_ray"], "node_steps_per_ray": c["node_steps_per_ray"],
-                                   "triangle_tests_per_ray": c["triangle_tests_per_ray"],
+for key, arg in (("tree", 2), ("big", 3)):
+    if len(sys.argv) <= arg or key not in out["kernels"] or not os.path.exists(sys.argv[arg]):
+        continue
+    c = json.loads(open(sys.argv[arg]).read().strip().splitlines()[-1])
+    out["kernels"][key].update({"traversal_bytes_per_ray": c["traversal_bytes_per_ray"], "node_steps_per_ray": c["node_steps_per_ray"],
+                                   "triangle_tests_per_ray": c["triangle_tests_per_ray"], "lanes_per_load_sequence": c["lanes_per_load_sequence"],
                                    "traversal_bytes_source": "tools/w8_counts.py on the diagnostic build (EXTRA=-DCAP_W8_COUNT)"})
 json.dump(out, open(os.path.join(root, "profiles", tag + "_traffic.json"), "w"), indent=1)
 if "tree" in out["kernels"]:  # the file VERDICT round 1 asked for by name: the tree path's two priced kernels on their own

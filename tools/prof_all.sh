@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything tools/collect_profiles.sh condenses into profiles/<tag>_*, in one gpurun call (~5 GPU-minutes):
-#   gpurun --timeout 1100 -- 'bash tools/prof_all.sh'      then here:  bash tools/collect_profiles.sh r03
+#   gpurun --timeout 1190 -- 'bash tools/prof_all.sh'      then here:  bash tools/collect_profiles.sh r04
 # The per-launch listings and counter passes of the tree path run with CAP_NO_TWO_LANES=1: with the two batch lanes (context.hip)
 # kernels of two streams overlap and a launch's duration is no longer its own.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -26,7 +26,8 @@ for n in 1 8; do
     CAP_NO_TWO_LANES=1 bash tools/shard_trace.sh $n sponza > $OUT/shard${n}_sponza.txt 2>&1
 done
 echo "w8_counts (diagnostic build)" >> $OUT/prof_all_progress.log
-(cd capsaicin_amd/csrc && make -B trace8.o kernels.o context.o EXTRA=-DCAP_W8_COUNT > /dev/null 2>&1 && make > /dev/null 2>&1)
+(cd capsaicin_amd/csrc && make -B trace8.o kernels.o context.o EXTRA=-DCAP_W8_COUNT > /dev/null 2>&1 && make EXTRA=-DCAP_W8_COUNT > /dev/null 2>&1)
 timeout -k 5 200 python tools/w8_counts.py > $OUT/w8_counts.json 2> $OUT/w8_counts.err
+timeout -k 5 300 python tools/w8_counts.py 8 > $OUT/w8_counts_big.json 2> $OUT/w8_counts_big.err
 echo "done" >> $OUT/prof_all_progress.log
 tail -3 $OUT/prof_sh.log; tail -2 $OUT/tree_trace.txt; tail -1 $OUT/w8_counts.json | cut -c1-200

@@ -32,7 +32,7 @@ def newest_per_dir(pattern):
     return sorted(by_dir.values())
 
 
-for f in newest_per_dir(os.path.join(root, "prof_kt", "**", "*kernel_trace.csv")):
+for f in newest_per_dir(os.path.join(root, "prof_*_kt", "**", "*kernel_trace.csv")):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         d[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -42,7 +42,7 @@ for f in newest_per_dir(os.path.join(root, "prof_kt", "**", "*kernel_trace.csv")
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
         print("%-62s %8d %12.1f %10.1f %6.1f" % (k, len(v), sum(v), sum(v) / len(v), 100 * sum(v) / tot))
 # counters
-for f in newest_per_dir(os.path.join(root, "prof_pmc_*", "**", "*counter_collection.csv")):
+for f in newest_per_dir(os.path.join(root, "prof_*_pmc_*", "**", "*counter_collection.csv")):
     d = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):

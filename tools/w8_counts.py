@@ -1,6 +1,6 @@
-"""Step counts of the wide closest-hit kernel on the 262 k-triangle scene (diagnostic build: make -C capsaicin_amd/csrc -B
-EXTRA=-DCAP_W8_COUNT).  python tools/w8_counts.py  -> per-ray node steps / triangle tests, lane utilisation of the two phases,
-and the traversal bytes (B) of SURVEY.md 8d per ray."""
+"""Step counts of the wide closest-hit kernel on the procedural hall (diagnostic build: make -C capsaicin_amd/csrc -B
+EXTRA=-DCAP_W8_COUNT).  python tools/w8_counts.py [scale [spp]]  -> per-ray node steps / triangle tests, lane utilisation of the two
+phases, and the traversal bytes (B) of SURVEY.md 8d per ray.  scale 1 (default): 262 k triangles, 16 spp; scale 8: 16.8 M, 8 spp."""
 import ctypes
 import json
 import os
@@ -16,24 +16,26 @@ def main():
     lib = capi.lib()
     if not hasattr(lib, "cap_debug_w8_counts"):
         raise SystemExit("needs the diagnostic build: make -C capsaicin_amd/csrc -B EXTRA=-DCAP_W8_COUNT")
+    scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    spp = int(sys.argv[2]) if len(sys.argv) > 2 else (16 if scale <= 1.0 else bench.BIG_SPP)
     r = capi.Renderer(0)
-    cam = bench.load_sponza_class(r)
+    cam = bench.load_sponza_class(r, scale=scale)
     r.upload_bluenoise(capi.load_bluenoise())
     r.build_bvh()
     r.set_resolution(bench.WIDTH, bench.HEIGHT)
     r.set_camera(cam)
     out = (ctypes.c_ulonglong * 8)()
-    r.render(0, 16, bench.DEPTH, 0)
+    r.render(0, spp, bench.DEPTH, 0)
     r.sync()
     lib.cap_debug_w8_counts(out, 1)
     r.stats_reset()
     r.accum_reset()
-    r.render(0, 16, bench.DEPTH, 0)
+    r.render(0, spp, bench.DEPTH, 0)
     r.sync()
     s = r.stats()
     lib.cap_debug_w8_counts(out, 1)
     nodes, tris, seqs, top, rays, iters, pushes, spills = (int(x) for x in out)
-    res = {"rays": rays, "rays_extension": int(s.rays_extension), "node_steps_per_ray": nodes / rays, "triangle_tests_per_ray": tris / rays,
+    res = {"scale": scale, "spp": spp, "triangles": int(r.bvh_info().triangle_count), "rays": rays, "rays_extension": int(s.rays_extension), "node_steps_per_ray": nodes / rays, "triangle_tests_per_ray": tris / rays,
            "lanes_per_load_sequence": (nodes + tris) / max(1, seqs), "load_sequences": seqs, "loop_iterations": iters,
            "node_steps_on_top_levels": top / max(1, nodes), "pushes_per_ray": pushes / rays,
            "spilled_push_fraction": spills / max(1, pushes),
