@@ -177,6 +177,7 @@ struct SceneDev
     // EXT shading model (no reference counterpart; DESIGN.md "EXT shading model")
     const float2*      bluenoise_ba;  // 256*256 (B,A)/255
     const MaterialDev* materials;     // one per mesh
+    uint32_t           material_count;
     const uint32_t*    light_tris;    // emissive triangles (global ids) in triangle order
     const float*       light_cdf;     // float prefix sums of their areas
     uint32_t           light_count;

@@ -417,6 +417,7 @@ SceneDev scene_dev(const CapContext* c)
     s.kd_untextured = pow22_c(0.75f);
     s.bluenoise_ba  = c->bluenoise_ba.p;
     s.materials     = reinterpret_cast<const MaterialDev*>(c->materials.p);
+    s.material_count = c->materials_ready ? c->mesh_count : 0u;
     s.light_tris    = c->light_tris.p;
     s.light_cdf     = c->light_cdf.p;
     s.light_count   = c->light_count;

@@ -1702,16 +1702,33 @@ struct ExtBsdf
 
 __device__ __forceinline__ float lum3(v3 c) { return fmaf(c.z, 0.114f, fmaf(c.y, 0.587f, c.x * 0.299f)); }
 
-__device__ __forceinline__ ExtBsdf ext_bsdf(v3 kd, v3 ks, float a2, v3 nf, v3 wo, v3 wi)
+// What the BSDF needs of the vertex and the outgoing direction alone: both evaluations of a vertex (towards the light sample and
+// along the sampled direction) share them, so they are computed once -- the same expressions on the same operands as before.
+struct ExtView
 {
-    const float cos_o = dot3(nf, wo), cos_i = dot3(nf, wi);
+    float cos_o, g_o;
+};
+__device__ __forceinline__ ExtView ext_view(float a2, v3 nf, v3 wo)
+{
+    ExtView w;
+    w.cos_o = dot3(nf, wo);
+    w.g_o   = (2.0f * w.cos_o) / (w.cos_o + sqrtf(fmaf(1.0f - a2, w.cos_o * w.cos_o, a2)));
+    return w;
+}
+__device__ __forceinline__ ExtBsdf ext_bsdf(v3 kd, v3 ks, float a2, v3 nf, v3 wo, v3 wi, const ExtView& vw)
+{
+    const float cos_o = vw.cos_o, cos_i = dot3(nf, wi);
     const v3    h     = normalize3(wo + wi);
     const float cos_h = dot3(nf, h), woh = dot3(wo, h);
     const float dd    = fmaf(cos_h * cos_h, a2 - 1.0f, 1.0f);
     const float D     = a2 / (kPi * dd * dd);
-    const float g_o   = (2.0f * cos_o) / (cos_o + sqrtf(fmaf(1.0f - a2, cos_o * cos_o, a2)));
+    const float g_o   = vw.g_o;
     const float g_i   = (2.0f * cos_i) / (cos_i + sqrtf(fmaf(1.0f - a2, cos_i * cos_i, a2)));
+#if defined(CAP_EXT_DIAG) && CAP_EXT_DIAG == 3  // diagnostic build: no microfacet term (D, G and their divisions fall away)
+    const float spec  = 0.0f * (cos_o + woh);
+#else
     const float spec  = (D * (g_o * g_i)) / (4.0f * cos_o * cos_i);
+#endif
     ExtBsdf     r;
     r.f        = mk3(kd.x * kInvPi + ks.x * spec, kd.y * kInvPi + ks.y * spec, kd.z * kInvPi + ks.z * spec);
     r.pdf_spec = (D * cos_h) / (4.0f * woh);
@@ -1719,12 +1736,25 @@ __device__ __forceinline__ ExtBsdf ext_bsdf(v3 kd, v3 ks, float a2, v3 nf, v3 wo
     return r;
 }
 
+// Tables of the EXT model in LDS (fused small-scene kernels, scenes of at most kExhaustiveMax triangles): the per-mesh materials,
+// the light table and, per emissive triangle, its three vertices, unit normal and emission -- what shade_vertex_ext otherwise
+// fetches through four dependent global loads and recomputes per vertex (the normal: a cross product and a normalisation that
+// depend on the light triangle alone).  Same operations on the same operands, done once per workgroup.
+struct ExtTables
+{
+    const MaterialDev* materials  = nullptr;  // [mesh]
+    const float*       light_cdf  = nullptr;
+    const float4*      light_rec  = nullptr;  // 4 per light: (q0, ke.x) (q1, ke.y) (q2, ke.z) (nl, -)
+};
+constexpr uint32_t kExtLightsMax = 32;  // lights the LDS table holds (more: the global path)
+
 // INLINE (ShadeArgs::inline_nee, fused small-scene kernels only): bvh is traced for the shadow ray here; acc = what the path has
 // gathered so far
 template <bool FIRST, bool INLINE = false>
 __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float4* shade_tab, const ShadePre& pre, uint32_t klass,
                                                  uint32_t pid, float4 hit, v3 thr,
-                                                 v3 d, uint32_t& n_shaded, const BvhDev* bvh = nullptr, v3 acc = mk3(0.f, 0.f, 0.f))
+                                                 v3 d, uint32_t& n_shaded, const BvhDev* bvh = nullptr, v3 acc = mk3(0.f, 0.f, 0.f),
+                                                 const ExtTables tabs = ExtTables())
 {
     const uint32_t Ppad = a.screen.pixels_padded;
     const uint32_t slot = pid >> kPidShift, pl = pid & kPidMask;
@@ -1768,11 +1798,12 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
         const v3      n = normalize3(mk3(mix(s3.x, s4.x, s5.x), mix(s3.y, s4.y, s5.y), mix(s3.z, s4.z, s5.z)));
         p = mk3(mix(s0.x, s1.x, s2.x), mix(s0.y, s1.y, s2.y), mix(s0.z, s1.z, s2.z));
         const uint32_t    inst = f2u(st[6].x);
-        const MaterialDev m    = a.scene.materials[inst];
+        const MaterialDev m    = tabs.materials ? tabs.materials[inst] : a.scene.materials[inst];
         const v3    kd = mk3(m.kd[0], m.kd[1], m.kd[2]), ks = mk3(m.ks[0], m.ks[1], m.ks[2]), ke = mk3(m.ke[0], m.ke[1], m.ke[2]);
         const float alpha = fmaxf(m.roughness * m.roughness, 1e-3f), a2 = alpha * alpha;
         const v3    wo = mk3(-d.x, -d.y, -d.z);
         const v3    nf = dot3(n, wo) < 0.0f ? mk3(-n.x, -n.y, -n.z) : n;
+        const ExtView vw = ext_view(a2, nf, wo);
         if (FIRST)
         {
             first_ke = ke;
@@ -1792,33 +1823,49 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
             }
         }
         // ---- next-event estimation: one point on the emissive triangles, uniform by area ----
+#if defined(CAP_EXT_DIAG) && CAP_EXT_DIAG == 2  // diagnostic build: no next-event estimation at all
+        if (false)
+#else
         if (a.scene.light_count != 0)
+#endif
         {
             const float target = pre.r4 * a.scene.light_area;
+            const float* cdf   = tabs.light_cdf ? tabs.light_cdf : a.scene.light_cdf;
             uint32_t    lo = 0, hi = a.scene.light_count - 1;
             while (lo < hi)  // first entry whose prefix sum exceeds target, else the last
             {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (a.scene.light_cdf[mid] > target) hi = mid; else lo = mid + 1;
+                if (cdf[mid] > target) hi = mid; else lo = mid + 1;
             }
-            const uint32_t lg = a.scene.light_tris[lo];
-            const float4*  lt = shade_tab + kShadeRec * (size_t)lg;
-            const float4   l0 = lt[0], l1 = lt[1], l2 = lt[2];
-            const v3       q0 = mk3(l0.x, l0.y, l0.z), q1 = mk3(l1.x, l1.y, l1.z), q2 = mk3(l2.x, l2.y, l2.z);
+            v3 q0, q1, q2, nl, lke;
+            if (tabs.light_rec)  // wave-uniform
+            {
+                const float4 r0 = tabs.light_rec[4 * lo], r1 = tabs.light_rec[4 * lo + 1], r2 = tabs.light_rec[4 * lo + 2], r3 = tabs.light_rec[4 * lo + 3];
+                q0 = mk3(r0.x, r0.y, r0.z), q1 = mk3(r1.x, r1.y, r1.z), q2 = mk3(r2.x, r2.y, r2.z), nl = mk3(r3.x, r3.y, r3.z);
+                lke = mk3(r0.w, r1.w, r2.w);
+            }
+            else
+            {
+                const uint32_t lg = a.scene.light_tris[lo];
+                const float4*  lt = shade_tab + kShadeRec * (size_t)lg;
+                const float4   l0 = lt[0], l1 = lt[1], l2 = lt[2];
+                q0 = mk3(l0.x, l0.y, l0.z), q1 = mk3(l1.x, l1.y, l1.z), q2 = mk3(l2.x, l2.y, l2.z);
+                nl = normalize3(cross3(q1 - q0, q2 - q0));
+                const MaterialDev lm = a.scene.materials[f2u(lt[6].x)];
+                lke = mk3(lm.ke[0], lm.ke[1], lm.ke[2]);
+            }
             const float    su = sqrtf(pre.r5), b0 = 1.0f - su, b1 = su * (1.0f - pre.r6), b2 = su * pre.r6;
             const v3 lp = mk3(fmaf(q2.x, b2, fmaf(q1.x, b1, q0.x * b0)), fmaf(q2.y, b2, fmaf(q1.y, b1, q0.y * b0)),
                               fmaf(q2.z, b2, fmaf(q1.z, b1, q0.z * b0)));
-            const v3    nl = normalize3(cross3(q1 - q0, q2 - q0));
             const v3    Lv = lp - p;
             const float d2 = dot3(Lv, Lv), dist = sqrtf(d2);
             const v3    wi = Lv * (1.0f / dist);
             const float cos_s = dot3(nf, wi), cos_l = fabsf(dot3(nl, wi));
             if (cos_s > 0.0f && cos_l > 0.0f && d2 > 0.0f)
             {
-                const MaterialDev lm  = a.scene.materials[f2u(lt[6].x)];
-                const ExtBsdf     bs  = ext_bsdf(kd, ks, a2, nf, wo, wi);
+                const ExtBsdf     bs  = ext_bsdf(kd, ks, a2, nf, wo, wi, vw);
                 const float       wgt = ((cos_s * cos_l) * a.scene.light_area) / d2;
-                const v3 c = mk3((thr.x * bs.f.x) * (lm.ke[0] * wgt), (thr.y * bs.f.y) * (lm.ke[1] * wgt), (thr.z * bs.f.z) * (lm.ke[2] * wgt));
+                const v3 c = mk3((thr.x * bs.f.x) * (lke.x * wgt), (thr.y * bs.f.y) * (lke.y * wgt), (thr.z * bs.f.z) * (lke.z * wgt));
                 if (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f)
                 {
                     emit_shadow = true, contrib = c, sdir = wi, stmax = dist * 0.999f;
@@ -1830,28 +1877,30 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
         if (sum > 0.0f)
         {
             const float ps = ls / sum;
-            v3          wi;
-            if (pre.r3 < ps)
-            {
-                const float c2 = (1.0f - pre.r2) / fmaf(a2 - 1.0f, pre.r2, 1.0f);
-                const float ct = sqrtf(c2), stt = sqrtf(fmaxf(0.0f, 1.0f - c2));
-                float       sp, cp;
-                sincos_c((2.0f * kPi) * pre.r1, sp, cp);
-                v3       uu = ortho_vector(nf);
-                const v3 vv = cross3(uu, nf);
-                uu          = cross3(nf, vv);
-                const float ca = stt * cp, cb = stt * sp;
-                const v3    hh = normalize3(mk3(fmaf(nf.x, ct, fmaf(vv.x, cb, uu.x * ca)), fmaf(nf.y, ct, fmaf(vv.y, cb, uu.y * ca)),
-                                                fmaf(nf.z, ct, fmaf(vv.z, cb, uu.z * ca))));
-                const float k2 = 2.0f * dot3(wo, hh);
-                wi = mk3(fmaf(hh.x, k2, -wo.x), fmaf(hh.y, k2, -wo.y), fmaf(hh.z, k2, -wo.z));
-            }
-            else
-                wi = map_to_hemisphere(pre.r1, pre.r2, nf);
+            // The two lobes sample a polar angle -- GGX: cos^2 = (1 - r2) / (1 + (a2 - 1) r2) for the half vector, Lambert:
+            // cos = sqrt(1 - r2) for the direction (MapToHemisphere, sampling.h:113-132, e = 1) -- around the SAME frame with
+            // the SAME azimuth; a wave whose lanes chose different lobes (any wave: the choice is a random number per lane) used
+            // to run the frame, the sincos and the normalisation twice.  One copy now, the polar angle selected per lane: the
+            // same operations on the same operands for either lobe, so the same bits.
+            const bool  lobe_spec = pre.r3 < ps;
+            const float c2  = (1.0f - pre.r2) / fmaf(a2 - 1.0f, pre.r2, 1.0f);
+            const float ctd = sqrtf(1.0f - pre.r2);
+            const float ct  = lobe_spec ? sqrtf(c2) : ctd;
+            const float stt = lobe_spec ? sqrtf(fmaxf(0.0f, 1.0f - c2)) : sqrtf(1.0f - ctd * ctd);
+            float       sp, cp;
+            sincos_c((2.0f * kPi) * pre.r1, sp, cp);
+            v3       uu = ortho_vector(nf);
+            const v3 vv = cross3(uu, nf);
+            uu          = cross3(nf, vv);
+            const float ca = stt * cp, cb = stt * sp;
+            const v3    hh = normalize3(mk3(fmaf(nf.x, ct, fmaf(vv.x, cb, uu.x * ca)), fmaf(nf.y, ct, fmaf(vv.y, cb, uu.y * ca)),
+                                            fmaf(nf.z, ct, fmaf(vv.z, cb, uu.z * ca))));
+            const float k2 = 2.0f * dot3(wo, hh);
+            const v3    wi = lobe_spec ? mk3(fmaf(hh.x, k2, -wo.x), fmaf(hh.y, k2, -wo.y), fmaf(hh.z, k2, -wo.z)) : hh;
             const float cos_i = dot3(nf, wi);
             if (cos_i > 0.0f)
             {
-                const ExtBsdf bs  = ext_bsdf(kd, ks, a2, nf, wo, wi);
+                const ExtBsdf bs  = ext_bsdf(kd, ks, a2, nf, wo, wi, vw);
                 const float   pdf = ps * bs.pdf_spec + (1.0f - ps) * bs.pdf_diff;
                 if (pdf > 1e-8f)
                 {
@@ -1871,7 +1920,12 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
     {
         // the any-hit kernel's test and its addition, here: lanes without a shadow ray trace an empty interval
         const Ray  sr      = make_ray(p, sdir, kRayEps, emit_shadow ? stmax : kRayEps);
-        const bool visible = emit_shadow && !exhaustive_any<false>(*bvh, sr);
+        bool       visible = false;
+#if defined(CAP_EXT_DIAG) && CAP_EXT_DIAG == 1  // diagnostic build (wrong images, right timing): what the inline any-test costs
+        visible = emit_shadow;
+#else
+        if (__ballot(emit_shadow) != 0ull) visible = emit_shadow && !exhaustive_any<false>(*bvh, sr);  // (a wave without a shadow ray: no test)
+#endif
         const bool on_surface = valid && gid != kInvalidId;
         if (FIRST)
         {
@@ -2115,11 +2169,35 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
     // screen.  A tile of camera rays only tests the pairs whose bounds overlap it: a ray can only hit a quad through a sample
     // point inside the quad's projection, so the pairs left out are missed by all 64 rays -- same hits, same bits.
     __shared__ float4     lds_bounds[ORG ? kExhaustiveMax / 2 : 1];
+    // EXT model: materials, light table and per-light records (ExtTables) -- staged when they fit
+    constexpr bool        XT = EXT && LDS;
+    __shared__ float      lds_mat[XT ? 12 * kExhaustiveMax : 1];
+    __shared__ float      lds_lcdf[XT ? kExtLightsMax : 1];
+    __shared__ float4     lds_lrec[XT ? 4 * kExtLightsMax : 1];
+    const bool            ext_tabs = XT && a.scene.material_count <= kExhaustiveMax && a.scene.light_count <= kExtLightsMax;  // wave-uniform
     if (LDS)
     {
         const uint32_t n = bvh.tri_count <= kExhaustiveMax ? bvh.tri_count : kExhaustiveMax;
         for (uint32_t k = threadIdx.x; k < kShadeRec * n; k += kBlock) lds_shade[k] = a.scene.shade_tris[k];
         for (uint32_t k = threadIdx.x; k < 4 * n; k += kBlock) lds_rec[k] = bvh.tris_by_id[k];
+        if (XT && ext_tabs)
+        {
+            const float* ms = reinterpret_cast<const float*>(a.scene.materials);
+            for (uint32_t k = threadIdx.x; k < 12u * a.scene.material_count; k += kBlock) lds_mat[k] = ms[k];
+            for (uint32_t k = threadIdx.x; k < a.scene.light_count; k += kBlock)
+            {
+                lds_lcdf[k] = a.scene.light_cdf[k];
+                const float4* lt = a.scene.shade_tris + kShadeRec * (size_t)a.scene.light_tris[k];
+                const float4  l0 = lt[0], l1 = lt[1], l2 = lt[2];
+                const v3      q0 = mk3(l0.x, l0.y, l0.z), q1 = mk3(l1.x, l1.y, l1.z), q2 = mk3(l2.x, l2.y, l2.z);
+                const v3      nl = normalize3(cross3(q1 - q0, q2 - q0));  // as shade_vertex_ext computes it per vertex without the table
+                const MaterialDev lm = a.scene.materials[f2u(lt[6].x)];
+                lds_lrec[4 * k]     = make_float4(q0.x, q0.y, q0.z, lm.ke[0]);
+                lds_lrec[4 * k + 1] = make_float4(q1.x, q1.y, q1.z, lm.ke[1]);
+                lds_lrec[4 * k + 2] = make_float4(q2.x, q2.y, q2.z, lm.ke[2]);
+                lds_lrec[4 * k + 3] = make_float4(nl.x, nl.y, nl.z, 0.f);
+            }
+        }
         if (ORG)
         {
             const v3     o  = mk3(a.cam.position[0], a.cam.position[1], a.cam.position[2]);
@@ -2226,6 +2304,8 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
     };
     const float4* shade_tab = LDS ? lds_shade : a.scene.shade_tris;
     const float4* rec_tab   = LDS ? lds_rec : bvh.tris_by_id;
+    ExtTables     xtabs;
+    if (XT && ext_tabs) xtabs.materials = reinterpret_cast<const MaterialDev*>(lds_mat), xtabs.light_cdf = lds_lcdf, xtabs.light_rec = lds_lrec;
     Stamps st;
     st.start();
     // Chunk slots from the class's work counter, like the any-hit kernel (with the priorities below: bounce 0 4.6 -> 4.1 ms,
@@ -2322,10 +2402,10 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
                     const float4 q = a.in.acc[i];
                     acc            = mk3(q.x, q.y, q.z);
                 }
-                shade_vertex_ext<FIRST, true>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded, &bvh, acc);
+                shade_vertex_ext<FIRST, true>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded, &bvh, acc, xtabs);
             }
             else
-                shade_vertex_ext<FIRST>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded);
+                shade_vertex_ext<FIRST>(a, shade_tab, pre, klass, pid, make_float4(u, v, u2f(gid), t), thr, r.d, n_shaded, nullptr, mk3(0.f, 0.f, 0.f), xtabs);
         }
         else
         {
