@@ -53,17 +53,31 @@ class BvhInfo(C.Structure):
                 ("build_ms", C.c_double)]
 
 
+OUTPUT_COMBINED, OUTPUT_DIRECT, OUTPUT_INDIRECT, OUTPUT_VARIANCE = range(4)  # SettingsComponent::output, gui_system.h:11-17
+
+
 class PostSettings(C.Structure):
-    """SettingsComponent fields read by the reconstruction chain, reference src/systems/gui_system.h:20-37 (defaults below)."""
+    """SettingsComponent fields read by the reconstruction chain, reference src/systems/gui_system.h:20-37.  Every field behind
+    lowres_indirect reads 0 as the reference default (so `use_variance`, default true, travels as disable_variance)."""
     _fields_ = [("gather", C.c_int32), ("denoise", C.c_int32), ("eaw5", C.c_int32), ("eaw_normal_sigma", C.c_float),
                 ("eaw_depth_sigma", C.c_float), ("eaw_luma_sigma", C.c_float), ("gather_normal_sigma", C.c_float),
                 ("gather_depth_sigma", C.c_float), ("gather_luma_sigma", C.c_float), ("temporal_upscale_feedback", C.c_float),
-                ("taa_feedback", C.c_float), ("lowres_indirect", C.c_int32), ("use_variance", C.c_int32), ("fast_weights", C.c_int32)]
+                ("taa_feedback", C.c_float), ("lowres_indirect", C.c_int32), ("disable_variance", C.c_int32), ("fast_weights", C.c_int32),
+                ("output", C.c_int32)]
 
     def __init__(self, **kw):
-        super().__init__(1, 1, 1, 128.0, 3.0, 3.0, 64.0, 2.0, 3.0, 0.975, 0.9, 0, 1, 0)
+        super().__init__()
+        lib().cap_post_settings_default(C.byref(self))  # the reference's defaults, from the library itself
         for k, v in kw.items():
             setattr(self, k, v)
+
+    @property
+    def use_variance(self):  # RaytracingOptions::use_variance, raytracing_system.h:25
+        return 0 if self.disable_variance else 1
+
+    @use_variance.setter
+    def use_variance(self, v):
+        self.disable_variance = 0 if v else 1
 
 
 class GeometryView(C.Structure):
@@ -96,6 +110,7 @@ SYMBOLS = {
     "cap_set_batch_paths": (_i, [_vp, _u64]),
     "cap_set_traversal": (_i, [_vp, _u32]),
     "cap_debug_set": (_i, [_vp, _u32, _u64]),
+    "cap_debug_get": (_i, [_vp, _u32, C.POINTER(_u64)]),
     "cap_render": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "cap_accum_reset": (_i, [_vp]),
     "cap_sync": (_i, [_vp]),
@@ -105,6 +120,7 @@ SYMBOLS = {
     "cap_tile_buffer_floats": (_i, [_vp, C.POINTER(C.c_size_t)]),
     "cap_resolve_tiles": (_i, [_vp, _vp]),
     "cap_assemble_tiles": (_i, [_vp, _vp, _u32, _vp]),
+    "cap_post_settings_default": (None, [C.POINTER(PostSettings)]),
     "cap_post_frame": (_i, [_vp, C.POINTER(PostSettings), _u32, C.POINTER(CameraData)]),
     "cap_aov_tile_buffer_floats": (_i, [_vp, C.POINTER(C.c_size_t)]),
     "cap_resolve_aov_tiles": (_i, [_vp, _vp]),
@@ -406,10 +422,15 @@ class Renderer:
         """0 auto, 1 LBVH + LDS stack, 2 exhaustive (small scenes)."""
         _check(lib().cap_set_traversal(self.ctx, mode), "cap_set_traversal")
 
-    DEBUG_QUEUE_CAPACITY_DIV = 1
+    DEBUG_QUEUE_CAPACITY_DIV, DEBUG_WIDE_DEPTH_LIMIT, DEBUG_WIDE_IN_USE = 1, 2, 3
 
     def debug_set(self, key, value):
         _check(lib().cap_debug_set(self.ctx, key, value), "cap_debug_set")
+
+    def debug_get(self, key):
+        v = _u64()
+        _check(lib().cap_debug_get(self.ctx, key, C.byref(v)), "cap_debug_get")
+        return int(v.value)
 
     def set_batch_paths(self, n):
         _check(lib().cap_set_batch_paths(self.ctx, n), "cap_set_batch_paths")

@@ -165,6 +165,7 @@ struct PostSettingsDev  // SettingsComponent subset, gui_system.h:20-37
     int   lowres_indirect;  // UPSCALE2X: `indirect` is the (W/2, H/2) image of this frame's interleave offset
     int   use_variance;     // USE_VARIANCE of eaw_blur.hlsl
     int   fast_weights;     // hardware exp / log / rcp in the edge-stopping weights (toleranced mode)
+    int   output;           // SettingsComponent::output = CombineIllumination's `type` (combine_illumination.hlsl:26-40): 0..3
 };
 struct PostChainArgs
 {

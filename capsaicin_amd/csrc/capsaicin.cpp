@@ -84,6 +84,10 @@ struct World
     bool                     exchange = false;  // a gather + assembly ends every Render()
     CapContext* ctx        = nullptr;
     bool        tlas_built = false;  // tlas_system.cpp:111-121 `built` flag: the structure is built once
+    // InputSystem state (input_system.h): the pending scripted input and the accumulated mouse angles, in degrees
+    ScriptedInput input;
+    bool          input_pending = false, angles_valid = false;
+    float         yaw = 0.f, pitch = 0.f;
     std::string assets_dir;
 };
 
@@ -211,7 +215,7 @@ void run_raytracing(World& w)
         check(cap_render(w.ctx, w.frame_count, 1, (uint32_t)std::max(0, s.num_diffuse_bounces), flags), "RaytracingSystem");
         CapPostSettings ps{s.gather, s.denoise, s.eaw5, s.eaw_normal_sigma, s.eaw_depth_sigma, s.eaw_luma_sigma, s.gather_normal_sigma,
                            s.gather_depth_sigma, s.gather_luma_sigma, s.temporal_upscale_feedback, s.taa_feedback, s.lowres_indirect,
-                           s.use_variance, s.fast_weights};
+                           s.use_variance ? 0 : 1, s.fast_weights, s.output};
         CapCameraData   prev;
         std::memcpy(&prev, &w.prev_camera, sizeof(prev));
         check(cap_post_frame(w.ctx, &ps, w.frame_count, &prev), "RaytracingSystem");
@@ -286,14 +290,70 @@ void LoadSceneFromOBJ(const std::string& file_name)
     world().assets.push_back(AssetComponent{file_name, false});  // lazily loaded by the next Render(), capsaicin.cpp:65-71
 }
 
-void ProcessInput(void*) {}
+void ProcessInput(void* input)
+{
+    World& w        = world();
+    w.input_pending = input != nullptr;
+    if (input) w.input = *static_cast<const ScriptedInput*>(input);
+}
 void Update(float) {}
+
+namespace
+{
+// InputSystem::Run (input_system.cpp:13-34): HandleMouse, then HandleKeyboard, on the one camera.
+void run_input(World& w)
+{
+    if (!w.input_pending) return;
+    w.input_pending        = false;
+    const ScriptedInput in = w.input;
+    CameraData&         cd = w.camera;
+    if (in.rotate)
+    {
+        // The reference's yaw_ / pitch_ start at 0 with the camera looking down +z (camera_system.cpp:25-33).  A session whose
+        // camera was placed through GetCamera() continues from THAT view [not-ref]: the angles whose rotation gives its forward
+        // vector, forward = (sin yaw cos pitch, -sin pitch, cos yaw cos pitch) -- see below.
+        if (!w.angles_valid)
+        {
+            const float fy = std::fmin(1.f, std::fmax(-1.f, cd.forward[1]));
+            w.pitch        = -std::asin(fy) * (180.f / 3.14159265358979323846f);
+            w.yaw          = std::atan2(cd.forward[0], cd.forward[2]) * (180.f / 3.14159265358979323846f);
+            w.angles_valid = true;
+        }
+        w.yaw += in.dyaw_deg, w.pitch += in.dpitch_deg;   // input_system.cpp:122-123
+        if (std::fabs(w.yaw) >= 360.f) w.yaw = 0.f;       // :125-128
+        if (std::fabs(w.pitch) >= 360.f) w.pitch = 0.f;
+        // XMMatrixRotationRollPitchYaw(pitch, yaw, 0) (:135-136) is, for DirectXMath's row vectors, Rx(pitch) * Ry(yaw) -- roll, then
+        // pitch, then yaw -- with Rx = [1 0 0; 0 c s; 0 -s c] and Ry = [c 0 -s; 0 1 0; s 0 c].  (0, 0, 1) * Rx = (0, -sin p, cos p), and
+        // that times Ry = (cos p sin y, -sin p, cos p cos y): XMVector3Transform of the forward axis (:138-139), then normalised.
+        const float p = w.pitch * (3.14159265358979323846f / 180.f), y = w.yaw * (3.14159265358979323846f / 180.f);
+        float       f[3] = {std::cos(p) * std::sin(y), -std::sin(p), std::cos(p) * std::cos(y)};
+        const float fl   = std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+        for (float& x : f) x /= fl;
+        // right = normalize(-cross(forward, (0, 1, 0))), up = cross(forward, right)  (:140-146)
+        float       r[3] = {-(f[1] * 0.f - f[2] * 1.f), -(f[2] * 0.f - f[0] * 0.f), -(f[0] * 1.f - f[1] * 0.f)};
+        const float rl   = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        for (float& x : r) x /= rl;
+        const float u[3] = {f[1] * r[2] - f[2] * r[1], f[2] * r[0] - f[0] * r[2], f[0] * r[1] - f[1] * r[0]};
+        for (int k = 0; k < 3; ++k) cd.forward[k] = f[k], cd.right[k] = r[k], cd.up[k] = u[k];
+    }
+    // HandleKeyboard (:50-108): the movement is summed along the (new) axes, then added to the position
+    float movement[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; ++k)
+    {
+        movement[k] += cd.right[k] * in.move_right;
+        movement[k] += cd.forward[k] * in.move_forward;
+        movement[k] += cd.up[k] * in.move_up;
+    }
+    for (int k = 0; k < 3; ++k) cd.position[k] += movement[k];
+}
+}  // namespace
 void SetOption() {}
 
 void Render()
 {
     World& w = world();
     if (!w.session_active) error_throw("Render: no render session");
+    run_input(w);
     run_asset_load(w);
     run_acceleration_structure(w);
     run_camera(w);

@@ -24,6 +24,20 @@ struct RenderSessionParams
     const uint8_t* comm_id     = nullptr;
 };
 
+// What ProcessInput() takes on a display-less node instead of the viewer's Win32 message (main.cpp:12-16 -> InputSystem::ProcessInput,
+// input_system.cpp:36-48): one frame's worth of what the keyboard and the mouse would have added up to.  Consumed by the next
+// Render(), whose InputSystem step applies it the way the reference does (input_system.cpp:31-33: mouse first, then keyboard).
+struct ScriptedInput
+{
+    // HandleKeyboard (input_system.cpp:50-108): displacement along the camera's right (D - A), up (E - Q) and forward (W - S) axes,
+    // i.e. kMovementSpeed * dt per key held
+    float move_right = 0.f, move_up = 0.f, move_forward = 0.f;
+    // HandleMouse (input_system.cpp:109-147): what (mouse delta) * kMouseSensitivity * dt adds to yaw_ / pitch_, in degrees; the
+    // camera basis is rebuilt from (pitch_, yaw_) only when the button is down, i.e. when `rotate` is set
+    float dyaw_deg = 0.f, dpitch_deg = 0.f;
+    bool  rotate = false;
+};
+
 namespace capsaicin
 {
 // Settings carried from SettingsComponent (gui_system.h:20-40); only what the ray passes read.
@@ -39,6 +53,7 @@ struct Settings
     bool  lowres_indirect           = false;   // RaytracingOptions::lowres_indirect, raytracing_system.h:24 (even window sizes)
     bool  use_variance              = true;    // RaytracingOptions::use_variance, raytracing_system.h:25
     bool  fast_weights              = false;   // not a reference option: CapPostSettings::fast_weights (toleranced chain)
+    int   output                    = 0;       // SettingsComponent::output, gui_system.h:11-17, 38: 0 kCombined, 1 kDirect, 2 kIndirect, 3 kVariance
     bool  gather                    = true;    // gui_system.h:20-37
     bool  denoise                   = true;
     bool  eaw5                      = true;
@@ -70,7 +85,7 @@ static_assert(sizeof(CameraData) == 72, "CameraData must stay the reference's 72
 void Init();
 void InitRenderSession(void* params);  // RenderSessionParams*
 void LoadSceneFromOBJ(const std::string& file_name);
-void ProcessInput(void* input);  // interactive input does not exist on a headless node: accepted and ignored
+void ProcessInput(void* input);  // ScriptedInput* (or nullptr: nothing happened); applied by the next Render()
 void Update(float time_ms);
 void Render();
 void SetOption();  // empty stub in the reference as well (capsaicin.cpp:89-92)

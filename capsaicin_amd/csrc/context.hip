@@ -166,6 +166,7 @@ struct CapContext
     ScreenDev     screen{};
     uint64_t      max_batch_paths = 0;
     uint32_t      debug_capacity_div = 1;  // cap_debug_set(CAP_DEBUG_QUEUE_CAPACITY_DIV): tests of the append guard only
+    uint32_t      debug_wide_depth_limit = 0;  // cap_debug_set(CAP_DEBUG_WIDE_DEPTH_LIMIT): pretend the wide kernels' stacks end here
     uint32_t      traversal_mode  = CAP_TRAVERSAL_AUTO;
     uint32_t      bvh_build_mode  = CAP_BVH_BUILD_AUTO;
 
@@ -396,7 +397,8 @@ BvhDev bvh_dev(const CapContext* c)
     static const bool no_wide8 = getenv("CAP_NO_WIDE8") != nullptr || getenv("CAP_BVH_BINARY") != nullptr;
     b.nodes8 = c->nodes8.p, b.tris8 = c->tris8.p;
     b.wide8_ok  = !no_wide8 && c->stack_spill.p && c->wide8_nodes != 0 && c->wide8_depth <= wide8_stack_pairs() + 1u &&
-                 c->wide8_depth <= kWideLdsEntries / 2u + kSpillEntries / 2u + 1u;
+                 c->wide8_depth <= kWideLdsEntries / 2u + kSpillEntries / 2u + 1u &&
+                 (c->debug_wide_depth_limit == 0u || c->wide8_depth <= c->debug_wide_depth_limit);
     b.wide8_top = c->wide8_top;
     b.fan_pairs = c->fan_pairs.p, b.fan_singles = c->fan_singles.p;
     b.fan_pair_count = c->fan_pair_count, b.fan_single_count = c->fan_single_count;
@@ -1015,7 +1017,25 @@ int cap_debug_set(CapContext* c, uint32_t key, uint64_t value)
         if (value < 1 || value > 1024) return fail(CAP_ERR_INVALID_ARG, "cap_debug_set: capacity divisor %llu not in 1..1024", (unsigned long long)value);
         c->debug_capacity_div = (uint32_t)value;
         return CAP_OK;
+    case CAP_DEBUG_WIDE_DEPTH_LIMIT:
+        c->debug_wide_depth_limit = (uint32_t)value;
+        return CAP_OK;
     default: return fail(CAP_ERR_INVALID_ARG, "cap_debug_set: unknown key %u", key);
+    }
+}
+
+int cap_debug_get(CapContext* c, uint32_t key, uint64_t* value)
+{
+    if (!c || !value) return fail(CAP_ERR_INVALID_ARG, "cap_debug_get: NULL argument");
+    switch (key)
+    {
+    case CAP_DEBUG_QUEUE_CAPACITY_DIV: *value = c->debug_capacity_div; return CAP_OK;
+    case CAP_DEBUG_WIDE_DEPTH_LIMIT: *value = c->debug_wide_depth_limit; return CAP_OK;
+    case CAP_DEBUG_WIDE_IN_USE:
+        if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_debug_get: BVH not built");
+        *value = bvh_dev(c).wide8_ok;
+        return CAP_OK;
+    default: return fail(CAP_ERR_INVALID_ARG, "cap_debug_get: unknown key %u", key);
     }
 }
 
@@ -1485,6 +1505,12 @@ int cap_assemble_tiles(CapContext* c, const float* device_src, uint32_t shard_co
     return CAP_OK;
 }
 
+void cap_post_settings_default(CapPostSettings* out)
+{
+    if (!out) return;
+    *out = CapPostSettings{1, 1, 1, 128.0f, 3.0f, 3.0f, 64.0f, 2.0f, 3.0f, 0.975f, 0.9f, 0, 0, 0, 0};
+}
+
 int cap_post_reset(CapContext* c)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_post_reset: ctx is NULL");
@@ -1516,7 +1542,7 @@ static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t fram
     PostChainArgs a{};
     a.settings = PostSettingsDev{s->gather, s->denoise, s->eaw5, s->eaw_normal_sigma, s->eaw_depth_sigma, s->eaw_luma_sigma, s->gather_normal_sigma,
                                  s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback, s->lowres_indirect,
-                                 s->use_variance, s->fast_weights};
+                                 s->disable_variance ? 0 : 1, s->fast_weights, s->output};
     a.width = c->screen.width, a.height = c->screen.height, a.frame_count = frame_count;
     a.camera = camera_dev(c->camera), a.prev_camera = camera_dev(*prev_camera);
     a.indirect = c->post_in[0].p, a.direct = c->post_in[1].p, a.albedo = c->post_in[2].p, a.normal_depth = c->post_in[3].p;
@@ -1585,6 +1611,7 @@ int cap_post_frame_gathered(CapContext* c, const CapPostSettings* s, uint32_t fr
     if (lowres && ((c->screen.width | c->screen.height) & 1u))
         return fail(CAP_ERR_INVALID_ARG, "cap_post_frame_gathered: lowres_indirect needs even width and height (%ux%u)", c->screen.width, c->screen.height);
     if (!(s->eaw_luma_sigma > 0.0f) || !(s->gather_luma_sigma > 0.0f)) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame_gathered: luma sigmas must be > 0");
+    if (s->output < CAP_OUTPUT_COMBINED || s->output > CAP_OUTPUT_VARIANCE) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame_gathered: output %d is not one of CAP_OUTPUT_*", s->output);
     HIP_TRY(hipSetDevice(c->device));
     if (c->post_w != c->screen.width || c->post_h != c->screen.height)
         if (int e = cap_post_reset(c)) return e;
@@ -1646,6 +1673,7 @@ int cap_post_frame(CapContext* c, const CapPostSettings* s, uint32_t frame_count
     if (c->screen.shard_count != 1) return fail(CAP_ERR_UNSUPPORTED, "cap_post_frame: needs an unsharded context (shard_count is %u)", c->screen.shard_count);
     if (!c->aov_valid) return fail(CAP_ERR_STATE, "cap_post_frame: no frame rendered with CAP_RENDER_AOV");
     if (!(s->eaw_luma_sigma > 0.0f) || !(s->gather_luma_sigma > 0.0f)) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame: luma sigmas must be > 0");
+    if (s->output < CAP_OUTPUT_COMBINED || s->output > CAP_OUTPUT_VARIANCE) return fail(CAP_ERR_INVALID_ARG, "cap_post_frame: output %d is not one of CAP_OUTPUT_*", s->output);
     HIP_TRY(hipSetDevice(c->device));
     if (c->post_w != c->screen.width || c->post_h != c->screen.height)
         if (int e = cap_post_reset(c)) return e;

@@ -815,14 +815,26 @@ __global__ __launch_bounds__(kBlock, 4) void k_blur_fast_strided(PostSettingsDev
     out[o] = res;
 }
 
-// combine_illumination.hlsl:16-30, type 0, in place
-__global__ __launch_bounds__(kBlock) void k_combine(float4* io, const float4* albedo, const float4* direct, uint32_t n, uint32_t w, uint32_t aux_tiles_x)
+// combine_illumination.hlsl:16-40, in place.  type = SettingsComponent::output (raytracing_system.cpp:1415): 0 combined, 1 direct,
+// 2 indirect (w = 1), 3 the indirect image's variance channel
+__global__ __launch_bounds__(kBlock) void k_combine(float4* io, const float4* albedo, const float4* direct, uint32_t n, uint32_t w, uint32_t aux_tiles_x,
+                                                    int type)
 {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
     {
         const size_t oa = aux_tiles_x ? aux_index(i % w, i / w, w, aux_tiles_x) : (size_t)i;
-        const float4 in = io[i], a = albedo[oa], d = direct[oa];
-        io[i] = make_float4(in.x * a.x + d.x, in.y * a.y + d.y, in.z * a.z + d.z, 1.0f * a.w + d.w);
+        const float4 in = io[i];
+        if (type == 0)
+        {
+            const float4 a = albedo[oa], d = direct[oa];
+            io[i] = make_float4(in.x * a.x + d.x, in.y * a.y + d.y, in.z * a.z + d.z, 1.0f * a.w + d.w);
+        }
+        else if (type == 1)
+            io[i] = direct[oa];
+        else if (type == 2)
+            io[i] = make_float4(in.x, in.y, in.z, 1.0f);
+        else
+            io[i] = make_float4(in.w, in.w, in.w, 1.0f);
     }
 }
 
@@ -970,7 +982,9 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     {
         // (USE_VAR, FAST) variants; the last a-trous pass combines (its own timestamp label then covers nothing: the reference's
         // "Combine illumination" span is part of "EAW" here)
-        auto blur = [&](uint32_t stride, const float4* in, float4* out, bool last) {
+        const bool fuse_combine = a.settings.output == 0;  // the other output types read the blurred image itself: k_combine after the pass
+        auto blur = [&](uint32_t stride, const float4* in, float4* out, bool last_pass) {
+            const bool last = last_pass && fuse_combine;
             if (fast)
             {
                 const Img none{nullptr, 0, 0};
@@ -1036,13 +1050,14 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
             blur(7u, a.temp[1], a.temp[0], true);
         }
         mark(3);
+        if (!fuse_combine) hipLaunchKernelGGL(k_combine, dim3(cg), block, 0, stream, a.temp[0], a.albedo, a.direct, W * H, W, a.tiled, a.settings.output);
     }
     else
     {
         (void)hipMemcpyAsync(a.temp[0], a.indirect_history[dst], bytes, hipMemcpyDeviceToDevice, stream);
         // CombineIllumination (cpp:1400-1435)
         mark(3);
-        hipLaunchKernelGGL(k_combine, dim3(cg), block, 0, stream, a.temp[0], a.albedo, a.direct, W * H, W, a.tiled);
+        hipLaunchKernelGGL(k_combine, dim3(cg), block, 0, stream, a.temp[0], a.albedo, a.direct, W * H, W, a.tiled, a.settings.output);
     }
     // ApplyTAA (cpp:1344-1398)
     mark(4);

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "capsaicin.h"
 
@@ -18,7 +19,8 @@ int main(int argc, char** argv)
     bool                cornell_camera = true, realtime = false, feedback = true, lowres = false;
     float               move[3] = {0.f, 0.f, 0.f};  // camera translation per frame (a scripted fly-through, input_system.cpp:49-148)
     float               view[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // --camera: position, forward, focal length
-    bool                custom_view = false;
+    bool                custom_view = false, print_cameras = false;
+    std::string         script;  // --script: one line per frame, "right up forward dyaw dpitch" (ScriptedInput; degrees)
     for (int i = 1; i < argc; ++i)
     {
         auto next = [&]() { return i + 1 < argc ? argv[++i] : ""; };
@@ -36,6 +38,8 @@ int main(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--lowres")) lowres = true;  // half-resolution interleaved indirect (lowres_indirect)
         else if (!std::strcmp(argv[i], "--move"))
             for (int k = 0; k < 3; ++k) move[k] = (float)std::atof(next());
+        else if (!std::strcmp(argv[i], "--script")) script = next();
+        else if (!std::strcmp(argv[i], "--print-cameras")) print_cameras = true;  // the camera of every frame on stderr, as hex floats
         else if (!std::strcmp(argv[i], "--camera"))
         {
             for (int k = 0; k < 7; ++k) view[k] = (float)std::atof(next());
@@ -43,7 +47,7 @@ int main(int argc, char** argv)
         }
         else
         {
-            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--gpus N] [--default-camera | --camera px py pz fx fy fz focal] [--realtime [--no-feedback] [--lowres] [--move dx dy dz]]\n", argv[0]);
+            std::fprintf(stderr, "usage: %s [--scene f.obj] [--out f.ppm] [--width W] [--height H] [--frames N] [--bounces D] [--device i] [--gpus N] [--default-camera | --camera px py pz fx fy fz focal] [--realtime [--no-feedback] [--lowres] [--move dx dy dz] [--script file] [--print-cameras]]\n", argv[0]);
             return 2;
         }
     }
@@ -79,9 +83,43 @@ int main(int argc, char** argv)
             cam.up[0] = 0.f, cam.up[1] = 1.f, cam.up[2] = 0.f;
             cam.focal_length = 0.035f;
         }
+        // fly-camera script (the replay of what InputSystem would have seen, input_system.cpp:49-148): line f is applied by frame f's
+        // Render(); a frame without a line gets no input
+        std::vector<ScriptedInput> steps;
+        if (!script.empty())
+        {
+            std::FILE* sf = std::fopen(script.c_str(), "r");
+            if (!sf)
+            {
+                std::fprintf(stderr, "fatal: cannot open script %s\n", script.c_str());
+                return 1;
+            }
+            char line[256];
+            while (std::fgets(line, sizeof(line), sf))
+            {
+                if (line[0] == '#' || line[0] == '\n') continue;
+                ScriptedInput in;
+                if (std::sscanf(line, "%f %f %f %f %f", &in.move_right, &in.move_up, &in.move_forward, &in.dyaw_deg, &in.dpitch_deg) != 5)
+                {
+                    std::fprintf(stderr, "fatal: script line is not `right up forward dyaw dpitch`: %s", line);
+                    std::fclose(sf);
+                    return 1;
+                }
+                in.rotate = in.dyaw_deg != 0.f || in.dpitch_deg != 0.f;  // the mouse button is down exactly while it turns the view
+                steps.push_back(in);
+            }
+            std::fclose(sf);
+        }
         for (int f = 0; f < frames; ++f)
         {
+            if ((size_t)f < steps.size()) capsaicin::ProcessInput(&steps[(size_t)f]);
             capsaicin::Render();  // one Render() per WM_PAINT in the reference (main.cpp:17-19)
+            if (print_cameras)
+            {
+                const auto& c = capsaicin::GetCamera();
+                std::fprintf(stderr, "camera %d: %a %a %a  %a %a %a  %a %a %a  %a %a %a\n", f, c.position[0], c.position[1], c.position[2], c.forward[0],
+                             c.forward[1], c.forward[2], c.right[0], c.right[1], c.right[2], c.up[0], c.up[1], c.up[2]);
+            }
             for (int k = 0; k < 3; ++k) capsaicin::GetCamera().position[k] += move[k];
         }
         capsaicin::SaveFramePPM(out);

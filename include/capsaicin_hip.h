@@ -219,9 +219,16 @@ int cap_set_batch_paths(CapContext* ctx, uint64_t max_paths);
  * be seen to fire -- entries beyond a sub-queue are dropped and counted, never written. */
 enum
 {
-    CAP_DEBUG_QUEUE_CAPACITY_DIV = 1
+    CAP_DEBUG_QUEUE_CAPACITY_DIV = 1,
+    /* The extension- and shadow-ray kernels walk the compressed 8-wide view of the tree while its depth fits their per-lane stacks
+     * (LDS part + spill slice: 21 levels) and fall back to the binary tree's kernels beyond.  WIDE_DEPTH_LIMIT (0 = none) lowers that
+     * bound so that the fallback can be exercised on ordinary scenes; WIDE_IN_USE (read-only) says which kernels the next render
+     * takes. */
+    CAP_DEBUG_WIDE_DEPTH_LIMIT   = 2,
+    CAP_DEBUG_WIDE_IN_USE        = 3
 };
 int cap_debug_set(CapContext* ctx, uint32_t key, uint64_t value);
+int cap_debug_get(CapContext* ctx, uint32_t key, uint64_t* value);
 /* Traversal strategy of the trace kernels (same hits either way): AUTO picks EXHAUSTIVE for scenes of at most 64
  * triangles (wave-uniform test of every triangle, no stack) and STACK (LBVH + per-lane LDS stack) otherwise. */
 typedef enum CapTraversal
@@ -300,16 +307,32 @@ typedef struct CapPostSettings
     float   taa_feedback;              /* 0.9   */
     int32_t lowres_indirect;           /* false: RaytracingOptions::lowres_indirect, UPSCALE2X in Gather and Accumulate
                                           (spatial_gather.hlsl:36-46, temporal_accumulation.hlsl:228-235, 307-313) */
-    int32_t use_variance;              /* true: RaytracingOptions::use_variance (raytracing_system.h:25): the USE_VARIANCE define of
-                                          eaw_blur.hlsl:68,114,127,162 (raytracing_system.cpp:669-673).  Off: no luma edge-stopping and
-                                          no a-trous kernel weights in Blur, variance channel 0 */
+    /* Every field from here on reads 0 as the reference's default, so that a caller who fills the struct positionally up to
+     * lowres_indirect (the round-1 form) -- or memsets it and sets what it knows -- runs the reference's default configuration. */
+    int32_t disable_variance;          /* false: NOT RaytracingOptions::use_variance (raytracing_system.h:25, default true): the
+                                          USE_VARIANCE define of eaw_blur.hlsl:68,114,127,162 (raytracing_system.cpp:669-673).  Set:
+                                          no luma edge-stopping and no a-trous kernel weights in Blur, variance channel 0 */
     int32_t fast_weights;              /* false.  Not a reference option: evaluates the edge-stopping weights with the hardware's
                                           v_exp_f32 / v_log_f32 / v_rcp_f32 instead of the arithmetic contract's polynomials and IEEE
                                           divisions.  The exact mode (0) is bit-identical to the oracle; this one is held to a stated
                                           tolerance against it over a multi-frame sequence (tests/test_post_gpu.py), per colour channel
                                           with e = |fast - exact| / (|exact| + 1e-3): median e <= 2e-5, 99 % of the channels
                                           e <= 4e-3, every channel e <= 3e-2 (TAA's variance clipping amplifies in flat regions) */
+    int32_t output;                    /* 0: SettingsComponent::output (gui_system.h:11-17, 38), passed to CombineIllumination as
+                                          `type` (raytracing_system.cpp:1415; combine_illumination.hlsl:26-40): CAP_OUTPUT_COMBINED
+                                          indirect * albedo + direct, CAP_OUTPUT_DIRECT, CAP_OUTPUT_INDIRECT (the denoised indirect
+                                          term, w = 1), CAP_OUTPUT_VARIANCE (its variance channel: indirect.www after the last blur) */
 } CapPostSettings;
+enum
+{
+    CAP_OUTPUT_COMBINED = 0, /* kCombined */
+    CAP_OUTPUT_DIRECT   = 1, /* kDirect   */
+    CAP_OUTPUT_INDIRECT = 2, /* kIndirect */
+    CAP_OUTPUT_VARIANCE = 3  /* kVariance */
+};
+/* The reference's default configuration (gui_system.h:20-40, raytracing_system.h:22-27): gather, denoise, eaw5 on; sigmas 128 / 3 / 3
+ * and 64 / 2 / 3; feedbacks 0.975 / 0.9; every later field 0. */
+void cap_post_settings_default(CapPostSettings* out);
 /* Runs the chain on the planes of the last frame rendered with CAP_RENDER_AOV (frame_count = that frame's index; the
  * camera is the one set for it; prev_camera = the previous frame's, CameraComponent/prev_camera of
  * temporal_accumulation.hlsl:10-11) and keeps the histories for the next call.  Needs an unsharded context: the stencils read

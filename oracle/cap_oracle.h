@@ -153,6 +153,8 @@ typedef struct OraclePostSettings
                                         `indirect` argument of oracle_post_frame is then the (W/2)*(H/2) image */
     int   use_variance;              /* true: RaytracingOptions::use_variance (raytracing_system.h:25) = the USE_VARIANCE define of
                                         eaw_blur.hlsl (raytracing_system.cpp:669-673); CALCULATE_VARIANCE (cpp:618-622) is read by no shader */
+    int   output;                    /* 0: SettingsComponent::output (gui_system.h:11-17, 38) = CombineIllumination's `type`
+                                        (raytracing_system.cpp:1415; combine_illumination.hlsl:26-40): 0 combined, 1 direct, 2 indirect, 3 variance */
 } OraclePostSettings;
 
 void* oracle_post_create(uint32_t width, uint32_t height);

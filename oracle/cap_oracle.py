@@ -34,10 +34,10 @@ class PostSettings(C.Structure):
     _fields_ = [("gather", C.c_int), ("denoise", C.c_int), ("eaw5", C.c_int), ("eaw_normal_sigma", C.c_float),
                 ("eaw_depth_sigma", C.c_float), ("eaw_luma_sigma", C.c_float), ("gather_normal_sigma", C.c_float),
                 ("gather_depth_sigma", C.c_float), ("gather_luma_sigma", C.c_float), ("temporal_upscale_feedback", C.c_float),
-                ("taa_feedback", C.c_float), ("lowres_indirect", C.c_int), ("use_variance", C.c_int)]
+                ("taa_feedback", C.c_float), ("lowres_indirect", C.c_int), ("use_variance", C.c_int), ("output", C.c_int)]
 
     def __init__(self, **kw):
-        super().__init__(1, 1, 1, 128.0, 3.0, 3.0, 64.0, 2.0, 3.0, 0.975, 0.9, 0, 1)
+        super().__init__(1, 1, 1, 128.0, 3.0, 3.0, 64.0, 2.0, 3.0, 0.975, 0.9, 0, 1, 0)
         for k, v in kw.items():
             setattr(self, k, v)
 

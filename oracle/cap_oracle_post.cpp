@@ -614,11 +614,18 @@ int oracle_post_frame(void* handle, const OraclePostSettings* s, uint32_t frame_
     }
     else
         c.temp[0] = c.indirect_history[dst];
-    // CombineIllumination type 0 (combine_illumination.hlsl:24,29), in place
+    // CombineIllumination (combine_illumination.hlsl:16-40), in place; type = SettingsComponent::output (raytracing_system.cpp:1415)
     for (size_t i = 0; i < c.temp[0].px.size(); ++i)
     {
         f4 in = c.temp[0].px[i], a = alb.px[i], d = dir.px[i];
-        c.temp[0].px[i] = f4{in.x * a.x + d.x, in.y * a.y + d.y, in.z * a.z + d.z, 1.0f * a.w + d.w};
+        switch (s->output)
+        {
+        case 0: c.temp[0].px[i] = f4{in.x * a.x + d.x, in.y * a.y + d.y, in.z * a.z + d.z, 1.0f * a.w + d.w}; break;  // :29 indirect = (xyz, 1)
+        case 1: c.temp[0].px[i] = d; break;                                                                          // :32
+        case 2: c.temp[0].px[i] = f4{in.x, in.y, in.z, 1.0f}; break;                                                 // :35
+        case 3: c.temp[0].px[i] = f4{in.w, in.w, in.w, 1.0f}; break;                                                 // :38 .www
+        default: return 3;
+        }
     }
     // ApplyTAA (cpp:1344-1398)
     taa(*s, *cam, *prev_cam, c.temp[0], nd, c.combined_history[src], c.combined_history[dst]);

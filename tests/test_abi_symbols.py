@@ -33,6 +33,19 @@ def test_pod_layouts_match_the_reference():
     assert capi.CameraData.forward.offset == 32 and capi.CameraData.up.offset == 48 and capi.CameraData.sensor_size.offset == 64
 
 
+def test_post_settings_zero_is_the_reference_default(native_lib):
+    """a CapPostSettings filled positionally up to lowres_indirect (the round-1 form) leaves the later
+    fields zero -- which must be the reference's defaults: USE_VARIANCE on (raytracing_system.h:25), exact weights, kCombined."""
+    d = capi.PostSettings()
+    assert (d.gather, d.denoise, d.eaw5, d.lowres_indirect) == (1, 1, 1, 0)
+    assert (d.eaw_normal_sigma, d.eaw_depth_sigma, d.eaw_luma_sigma) == (128.0, 3.0, 3.0)
+    assert (d.gather_normal_sigma, d.gather_depth_sigma, d.gather_luma_sigma) == (64.0, 2.0, 3.0)
+    assert abs(d.temporal_upscale_feedback - 0.975) < 1e-7 and abs(d.taa_feedback - 0.9) < 1e-7
+    assert (d.disable_variance, d.fast_weights, d.output) == (0, 0, 0) and d.use_variance == 1
+    # the fields behind lowres_indirect are the struct's tail: twelve leading fields = 48 bytes
+    assert capi.PostSettings.disable_variance.offset == 48 and ctypes.sizeof(capi.PostSettings) == 60
+
+
 def test_no_gpu_fails_loudly(native_lib):
     if capi.device_count() > 0:
         return

@@ -122,6 +122,18 @@ def test_16m_triangles(native_lib, bluenoise):
     assert s.guard_shade == 0 and s.guard_trace_any == 0 and s.guard_append == 0 and s.rays_primary == W * H
     O, sc, ocam = _oracle(arrays)
     _compare_crops(r, sc, O, ocam, bluenoise, frame, min(64, os.cpu_count() or 8))
+    # the same frame through the binary tree's kernels, which take over when the wide view is deeper than the wide kernels' stacks
+    # (here: the bound lowered by hand): this tree is 36 deep, so these are the 64-entry instantiations nothing else reaches
+    assert info.max_depth > 32 and info.stack_entries == 64 and r.debug_get(capi.Renderer.DEBUG_WIDE_IN_USE) == 1
+    rays_wide = (s.rays_primary, s.rays_extension, s.rays_shadow)
+    r.debug_set(capi.Renderer.DEBUG_WIDE_DEPTH_LIMIT, 2)
+    assert r.debug_get(capi.Renderer.DEBUG_WIDE_IN_USE) == 0
+    r.stats_reset()
+    r.render(frame, 1, D, capi.RENDER_AOV)
+    s = r.stats()
+    assert (s.rays_primary, s.rays_extension, s.rays_shadow) == rays_wide and s.guard_shade == 0 and s.guard_trace_any == 0
+    _compare_crops(r, sc, O, ocam, bluenoise, frame, min(64, os.cpu_count() or 8))
+    r.debug_set(capi.Renderer.DEBUG_WIDE_DEPTH_LIMIT, 0)
     spp = 2
     r.accum_reset()
     r.stats_reset()

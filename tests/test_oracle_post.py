@@ -155,3 +155,26 @@ def test_deterministic():
             out = chain.frame(O.PostSettings(), f, cam, cam, wall_planes(w, h, cam, rng=rng))
         outs.append(out)
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+def test_output_selector_on_sky_pixels():
+    """SettingsComponent::output = CombineIllumination's `type` (combine_illumination.hlsl:26-40; raytracing_system.cpp:1415).  On
+    sky pixels every other pass is a pass-through (see test_sky_pixels_pass_through), so the chain's output IS Combine's:
+    0 indirect * albedo + direct, 1 direct, 2 (indirect.xyz, 1), 3 indirect.www -- and a sky pixel's variance channel is what
+    Accumulate left there, 0 (temporal_accumulation.hlsl:232 returns before the moments are touched)."""
+    w, h = 40, 24
+    rng = np.random.default_rng(7)
+    cam = camera(w, h)
+    planes = {k: rng.uniform(0.0, 8.0, (h, w, 4)).astype(np.float32) for k in ("indirect", "direct", "albedo")}
+    planes["normal_depth"] = np.zeros((h, w, 4), np.float32)
+    ind = np.minimum(planes["indirect"][..., :3], np.float32(10.0))
+    want = {0: ind * planes["albedo"][..., :3] + planes["direct"][..., :3], 1: planes["direct"][..., :3], 2: ind}
+    for output in (0, 1, 2, 3):
+        chain = O.PostChain(w, h)
+        out = chain.frame(O.PostSettings(output=output), 0, cam, cam, planes)
+        if output == 3:
+            assert np.all(out[:-1, :-1, 0] == out[:-1, :-1, 1]) and np.all(out[:-1, :-1, 1] == out[:-1, :-1, 2])  # .www
+        else:
+            assert np.array_equal(out[:-1, :-1, :3].view(np.uint32), want[output].astype(np.float32)[:-1, :-1].view(np.uint32)), output
+    with pytest.raises(RuntimeError):
+        O.PostChain(w, h).frame(O.PostSettings(output=4), 0, cam, cam, planes)

@@ -4,7 +4,9 @@ headless src/viewer/main.cpp:50-107.  The viewer runs as a child process, exactl
 compared with the oracle's frames pushed through the composite blit (gamma 1 / 2.2 and vertical flip, simple.hlsl:40-46):
  * accumulate mode: plain mean of N frames;
  * --realtime --move: the reference's own per-frame pipeline (ray passes with G-buffer feedback -> reconstruction chain), camera
-   translated every frame (the scripted stand-in for input_system.cpp:49-148).
+   translated every frame;
+ * --realtime --script: the same with a fly-camera script -- per-frame keyboard displacement and mouse yaw / pitch replayed through
+   ProcessInput() and the host layer's InputSystem step (input_system.cpp:49-148).
 The per-pass timing table must carry the reference's timestamp labels (gui_system.cpp:94-104; raytracing_system.cpp:1024, 1099,
 1207 and the reconstruction passes)."""
 import os
@@ -110,6 +112,62 @@ def test_realtime_pipeline_with_camera_motion(native_lib, bluenoise, cornell_pat
     same_up_to_one_code(got, blit(want), "frame %d of the realtime loop" % (n - 1))
     for label in LABELS:
         assert label + ":" in log
+
+
+def test_realtime_pipeline_with_fly_camera_script(native_lib, bluenoise, cornell_path, tmp_path):
+    """--script: the replay of what InputSystem would have seen (input_system.cpp:49-148), with ROTATION: per frame the viewer hands
+    a ScriptedInput to ProcessInput(), and the host layer's InputSystem step turns the accumulated (pitch, yaw) into the camera basis
+    the way HandleMouse does -- forward = (0, 0, 1) * XMMatrixRotationRollPitchYaw(pitch, yaw, 0) = (cos p sin y, -sin p, cos p cos y),
+    right = normalize(-cross(forward, (0, 1, 0))), up = cross(forward, right) (input_system.cpp:130-146) -- then moves along the new
+    axes like HandleKeyboard.  Checked twice: the cameras the viewer reports against this derivation in float64 (to 1e-6: libm's
+    sinf / cosf vs numpy's), and the final frame of the real-time loop (G-buffer feedback on, reconstruction chain) against the
+    oracle fed with exactly the reported cameras."""
+    O, sc = oracle_scene(cornell_path)
+    w, h, n, D = 120, 88, 6, 2
+    steps = [(0.0, 0.0, 0.0, 0.0, 0.0), (0.01, 0.0, 0.02, 1.5, 0.0), (0.0, 0.005, 0.02, 1.5, -0.75), (0.0, 0.0, 0.0, 0.0, 0.0),
+             (-0.02, 0.0, 0.03, -2.0, 0.5), (0.0, 0.0, 0.01, 0.0, 0.0)]
+    script = tmp_path / "fly.txt"
+    script.write_text("# right up forward dyaw dpitch\n" + "".join("%g %g %g %g %g\n" % s_ for s_ in steps))
+    got, log = run_viewer(["--width", w, "--height", h, "--frames", n, "--bounces", D, "--realtime", "--script", str(script), "--print-cameras"], tmp_path)
+    reported = {}
+    for line in log.splitlines():
+        if line.startswith("camera "):
+            head, vals = line.split(":")
+            reported[int(head.split()[1])] = [float.fromhex(v) for v in vals.split()]
+    assert sorted(reported) == list(range(n))
+    # the derivation, in float64, from the Cornell view (forward (0, 0, -1): yaw 180 degrees, pitch 0)
+    base = capi.cornell_camera(w, h)
+    pos = np.float64(list(base.position))
+    fwd, right, up = (np.float64(list(v)) for v in (base.forward, base.right, base.up))
+    yaw, pitch = 180.0, 0.0
+    for f, (mr, mu, mf, dyaw, dpitch) in enumerate(steps):
+        if dyaw != 0.0 or dpitch != 0.0:
+            yaw, pitch = yaw + dyaw, pitch + dpitch
+            p_, y_ = np.radians(pitch), np.radians(yaw)
+            fwd = np.float64([np.cos(p_) * np.sin(y_), -np.sin(p_), np.cos(p_) * np.cos(y_)])
+            fwd /= np.linalg.norm(fwd)
+            right = -np.cross(fwd, (0.0, 1.0, 0.0))
+            right /= np.linalg.norm(right)
+            up = np.cross(fwd, right)
+        pos = pos + right * mr + fwd * mf + up * mu
+        assert np.allclose(reported[f], np.concatenate([pos, fwd, right, up]), rtol=0, atol=2e-6), f
+    assert abs(np.dot(fwd, np.float64(list(base.forward)))) < 0.9999  # the view did turn
+
+    def cam_of(vals):
+        c = capi.CameraData.from_buffer_copy(bytes(base))
+        c.position[:], c.forward[:], c.right[:], c.up[:] = vals[0:3], vals[3:6], vals[6:9], vals[9:12]
+        return c
+
+    chain, s = O.PostChain(w, h), O.PostSettings()
+    prev_nd, hist = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    prev = want = None
+    for f in range(n):
+        cam = cam_of(reported[f])
+        prev = prev if prev is not None else cam
+        ref = sc.render_frame(ocam_of(O, cam), bluenoise, w, h, f, D, threads=8, feedback=(ocam_of(O, prev), prev_nd, hist))
+        want = chain.frame(s, f, ocam_of(O, cam), ocam_of(O, prev), ref)
+        prev, prev_nd, hist = cam, ref["normal_depth"], want
+    same_up_to_one_code(got, blit(want), "frame %d of the scripted fly-through" % (n - 1))
 
 
 def test_png_tga_and_jpeg_textures_through_the_host_layer(native_lib, bluenoise, tmp_path):
