@@ -82,6 +82,23 @@ def roofline_object(kernel_name, counters_key, kernel_bytes, launches, kernel_ms
     return o
 
 
+def host_cores():
+    """The CPU share this process really has: os.cpu_count() is the machine (256 hardware threads on the GPU box), but the box gives
+    one GPU's job a cgroup quota (cpu.max: 16 cores' worth) -- 256 threads on it measured 8.7 x one thread in rounds 3 and 4."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle (kind "port": scalar C++ restatement, BVH mode) on the same scene/camera/depth, 1 frame at a time."""
     from capsaicin_amd import capi
@@ -93,11 +110,11 @@ def cpu_baseline(budget_s=12.0):
     cam = capi.cornell_camera(WIDTH, HEIGHT)
     ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0],
                          cam.sensor_size[1], cam.focal_length)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     # All cores: frames side by side, each on its own band of threads (the oracle threads a frame over interleaved rows; one
     # frame at a time on 256 threads spent most of its time starting and joining them: 9x over one thread in round 3).
     import concurrent.futures as cf
-    side = max(1, min(16, cores // 16))
+    side = max(1, min(8, cores // 4))  # frames side by side, each on its own band of threads
     per = max(1, cores // side)
 
     def one(frame):
@@ -121,7 +138,7 @@ def cpu_baseline(budget_s=12.0):
     r1 = sc.render_frame(ocam1, bn, w1, h1, 0, DEPTH, flags=O.FLAG_USE_BVH, threads=1)
     el1 = time.time() - t1
     v, v1 = rays / el / 1e6, sum(r1["rays"]) / el1 / 1e6
-    return {"value": v, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": v, "unit": "Mrays/s", "cores": cores, "hardware_threads": os.cpu_count(), "kind": "port",
             "sample": "%d frame(s) of %dx%d depth %d (of the %d spp workload), oracle BVH mode, %d frames side by side x %d threads, %.1f s" %
                       (frames, WIDTH, HEIGHT, DEPTH, SPP, side, per, el),
             "scaling_over_single_thread": v / v1,

@@ -1153,7 +1153,14 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             HIP_TRY(hipStreamSynchronize(c->stream));  // growing frees the old buffers
             if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
         }
-        if (ensure_lane1(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
+        if (ensure_lane1(c, slots, num_bounces) != CAP_OK)
+        {
+            // the second working set doubles the batch's memory (~28 GB at the default budget): without it the batches of this call
+            // simply run one after the other on lane 0
+            (void)hipGetLastError();
+            c->lane1 = CapContext::Lane{};
+            two_lanes = false;
+        }
     }
     const uint32_t ring = c->frames_next;
     c->frames_next      = (c->frames_next + 1) % CapContext::kFrameRing;
@@ -1219,11 +1226,26 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
          c->lane1.pl_direct.p, c->lane1.pl_albedo.p, c->lane1.counters.p, c->lane1.stack_spill.p, std::min(c->lane1.s_org.n, c->lane1.s_con.n),
          c->stream2}};
     const uint32_t n_batches = (n_frames + slots - 1) / slots;
+    // Every way out of this function after the fork -- the early returns of HIP_TRY and of the launch tracing included -- leaves the
+    // context's stream, the one callers order cap_sync / cap_readback / buffer growth behind, waiting for lane 1 (an error
+    // between fork and join used to leave lane-1 work running that nothing waited for).
+    struct LaneJoin
+    {
+        CapContext* c;
+        bool        armed = false;
+        ~LaneJoin()
+        {
+            if (!armed) return;
+            if (hipEventRecord(c->join_ev, c->stream2) != hipSuccess || hipStreamWaitEvent(c->stream, c->join_ev, 0) != hipSuccess)
+                (void)hipStreamSynchronize(c->stream2);
+        }
+    } lane_join{c};
     if (two_lanes)
     {
         // lane 1 starts behind everything queued on the context's stream so far (the frame constants' upload, earlier calls)
         HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
+        lane_join.armed = true;
     }
     hipEvent_t last_resolve = nullptr;  // the accumulation buffer takes the batches in frame order, whichever lane ran them
     uint32_t   batch        = 0;
@@ -1403,6 +1425,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         // the context's stream -- the one callers order their work behind -- ends the call behind lane 1 as well
         HIP_TRY(hipEventRecord(c->join_ev, c->stream2));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev, 0));
+        lane_join.armed = false;
     }
     total.reset();
     HIP_TRY(hipEventRecord(c->frames_event[ring], c->stream));

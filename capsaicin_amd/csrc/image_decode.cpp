@@ -520,8 +520,15 @@ bool decode_bmp(const Bytes& d, Bytes* rgba, uint32_t* w, uint32_t* h)
     else if (hsz == 108 || hsz == 124)
         mr = u32(54), mg = u32(58), mb = u32(62), ma = u32(66);
     const bool flip = H > 0;
+    if (H == INT32_MIN) return false;  // (its negation is not an int32)
     if (H < 0) H = -H;
     if (W <= 0 || H <= 0 || (uint64_t)W * (uint64_t)H > kMaxPixels) return false;
+    // Cheap refusal BEFORE the output is allocated: the pixel rows alone need this many bytes behind the headers, so a
+    // short file that declares a huge extent costs nothing (the exact position checks follow where the layout is known)
+    {
+        const uint64_t row_bits = (uint64_t)W * (uint64_t)(bpp > 0 ? bpp : 1);
+        if (((row_bits + 7) >> 3) * (uint64_t)H > (uint64_t)d.size()) return false;
+    }
     int64_t psize = 0;
     if (hsz == 12)
     {

@@ -356,7 +356,13 @@ int cap_post_frame_gathered(CapContext* ctx, const CapPostSettings* settings, ui
  * image of this frame (rt_indirect.hlsl:116-145), which only the root has.  After the chain of frame f the root exports the two
  * images (cap_feedback_buffer_floats floats: width*height*4 each, output first), ONE broadcast carries them to the other ranks,
  * and those import them before cap_render(f + 1, .., CAP_RENDER_GBUFFER_FEEDBACK).  Frame 0 needs nothing (cleared histories
- * everywhere). */
+ * everywhere).
+ * Layout of the buffer (a contract between builds: ranks exchange it): plane 0 = the chain's output of frame f,
+ * current_frame_output() (RGBA as cap_post_readback returns it); plane 1 = frame f's normal/depth image as the CHAIN keeps it for
+ * the next frame -- the DECODED unit normal in .xyz (OctDecode of gbuffer_normal_depth.xy) and the raw depth in .w -- not the
+ * oct-encoded G-buffer plane of CAP_BUF_NORMAL_DEPTH (that was its content until round 3).  The indirect pass's feedback branch and
+ * Accumulate read only .w; both planes are written and read by cap_feedback_export / _import only, as a pair
+ * (tests/test_post_gpu.py::test_gbuffer_feedback_on_shards round-trips them across every frame of a sequence). */
 int cap_feedback_buffer_floats(CapContext* ctx, size_t* out_floats);
 int cap_feedback_export(CapContext* ctx, float* device_dst);
 int cap_feedback_import(CapContext* ctx, const float* device_src, uint32_t frame_count);

@@ -168,3 +168,23 @@ def test_bench_two_ranks(native_lib):
     rp = d["config"]["rays_per_step"]
     assert (rp["primary"], rp["extension"], rp["shadow"]) == (s.rays_primary, s.rays_extension, s.rays_shadow)
     r.close()
+    # what a SCALE run needs from the line: which exchange the step ended with and where each rank's time went
+    assert d["exchange"] == d["config"]["exchange"] == "torch.distributed.gather"  # the gloo rehearsal's path; nccl: cap_comm_gather_frame
+    assert len(d["stage_ms_per_rank"]) == 2
+    for st in d["stage_ms_per_rank"]:
+        assert set(st) == {"primary", "trace_closest", "trace_any", "shade", "resolve", "total"} and st["total"] > 0 and st["trace_closest"] > 0
+    assert d["roofline"]["stage_ms"]["total"] == d["stage_ms_per_rank"][0]["total"]
+
+
+def test_bench_two_ranks_sponza_workload(native_lib):
+    """--workload sponza: BASELINE configs[3] as the sharded workload (the second scaling curve), same rehearsal."""
+    env = dict(os.environ, CAP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "sponza", "--spp", "2"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["triangles"] > 250_000 and "sponza_class" in d["config"]["workload"] and "configs[3]" in d["metric"]
+    assert d["exchange"] == "torch.distributed.gather" and len(d["stage_ms_per_rank"]) == 2
+    assert all(st["shade"] > 0 and st["trace_any"] > 0 for st in d["stage_ms_per_rank"])  # the tree path's stand-alone stages ran
+    assert d["config"]["rays_per_step"]["primary"] == 2 * 1920 * 1080

@@ -144,3 +144,26 @@ def test_oversized_truncated_and_bomb_inputs_end_as_errors(native_lib):
             pass
     with pytest.raises(capi.CapError):
         capi.image_decode(b"P6\n40000 40000\n255\n" + b"\0" * 100, "big.ppm")
+
+
+def test_bmp_header_cannot_buy_memory(native_lib):
+    """a 26-byte BMP that declares 8192 x 8192 pixels used to make the decoder allocate and touch 256 MB before it noticed
+    that the file cannot back the header (16 decode threads of the host layer: 4 GB).  The refusal now comes before the allocation --
+    seen here as peak resident memory of the process -- and a height of INT32_MIN (whose negation overflows) is refused as well."""
+    import resource
+    import struct
+
+    def bmp(w, h, bpp=24, body=b""):
+        return b"BM" + struct.pack("<IHHI", 54 + len(body), 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, w, h, 1, bpp, 0, 0, 0, 0, 0, 0) + body
+
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for k in range(40):
+        with pytest.raises(capi.CapError):
+            capi.image_decode(bmp(8192, 8192), "huge.bmp")
+    with pytest.raises(capi.CapError):
+        capi.image_decode(bmp(4, -2147483648), "minint.bmp")
+    after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert after - before < 64 * 1024, "the refused files grew the process by %d KiB" % (after - before)
+    # a file that does back its header still decodes
+    body = bytes(range(3 * 4 * 2)) + b""
+    assert capi.image_decode(bmp(4, 2, 24, body), "ok.bmp").shape == (2, 4, 4)

@@ -70,7 +70,7 @@ int main(int argc, char** argv)
             printf("image %s: %d prefixes decoded, %d refused\n", argv[i], ok, bad);
             {
                 srand(12345);
-                for (int trial = 0; trial < 400; ++trial)
+                for (int trial = 0; trial < 400 && d.size() > 2; ++trial)  // (a fixture of two bytes or fewer has nothing to edit)
                 {
                     std::vector<uint8_t> part(d);
                     for (int e = 1 + rand() % 4; e > 0; --e) part[2 + rand() % (part.size() - 2)] = (uint8_t)rand();

@@ -1,6 +1,9 @@
 #!/bin/bash
-ROOT=${GRAFT_REPO_ROOT}
+# Per-launch durations of a Cornell step with very little work (1 spp and 8 spp at 1080p): T = fixed cost + work, the measurement
+# behind the 77-us-per-launch finding of round 3 (kernels.hip flush_stats).  Run through gpurun.
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_tiny
 cat > /tmp/tiny_step.py <<PY
