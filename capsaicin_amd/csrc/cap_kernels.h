@@ -21,6 +21,11 @@ struct LaunchCfg
 // work: kQueueClasses zeroed chunk-grab counters (kCounterStride apart) for the persistent wide-tree variant, or NULL
 void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraDev& cam, const ScreenDev& screen,
                           const FrameConst* frames, uint32_t n_slots, float4* hits, uint32_t* work);
+// Camera rays written as a ray queue whose entry i belongs to path i (= slot * Ppad + local pixel): q.org_tmin / q.dir_tmax hold
+// n_slots * Ppad entries, q.count the 64 sub-queue counters (set by the kernel), q.class_capacity = ceil(n_slots * Ppad / 64) rounded
+// up to a multiple of 64.  launch_trace_closest8 on it writes hits[i] exactly where launch_trace_primary would have.
+void launch_raygen_identity(const LaunchCfg& cfg, const CameraDev& cam, const ScreenDev& screen, const FrameConst* frames, uint32_t n_slots,
+                            const RayQueue& q);
 // Closest hit for the extension-ray queue (rt_indirect.hlsl:173).
 void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits);
 // The same on the compressed 8-wide view of the tree (trace8.hip; needs bvh.wide8_ok).  work: kQueueClasses zeroed chunk-grab counters.

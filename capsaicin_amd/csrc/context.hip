@@ -83,6 +83,9 @@ struct DevBuf
     }
 };
 
+// camera rays take the per-lane wide kernel instead of the packet walk from this many triangles per pixel on (measured: cap_render)
+constexpr double kPrimaryWideTrianglesPerPixel = 1.0;
+
 // guard block of a context (ShadeArgs::shaded_counter): {-, malformed path ids seen by shade, by trace_any, last offender, appends
 // beyond a class's capacity, -, -, -}
 constexpr size_t kGuardWords = 8;
@@ -450,7 +453,7 @@ int ensure_wavefront(CapContext* c, uint32_t slots, uint32_t bounces)
     HIP_TRY(c->aov_geo.ensure(c->screen.pixels_padded));
     HIP_TRY(c->aov_nd.ensure(c->screen.pixels_padded));
     // queue counters (ext + shadow share words) + chunk-grab counters of the fused and of the any-hit launch, per bounce
-    HIP_TRY(c->counters.ensure(3 * (size_t)(bounces + 1) * kQueueClasses * kCounterStride));
+    HIP_TRY(c->counters.ensure((3 * (size_t)(bounces + 1) + 1) * kQueueClasses * kCounterStride));  // + 1: the camera rays' identity queue
     if (!c->shaded_counter.p)
     {
         HIP_TRY(c->shaded_counter.ensure(kGuardWords));
@@ -485,7 +488,7 @@ int ensure_lane1(CapContext* c, uint32_t slots, uint32_t bounces)
     HIP_TRY(L.pl_color.ensure(planes_np));
     HIP_TRY(L.pl_direct.ensure(planes_np));
     HIP_TRY(L.pl_albedo.ensure(planes_np));
-    HIP_TRY(L.counters.ensure(3 * (size_t)(bounces + 1) * kQueueClasses * kCounterStride));
+    HIP_TRY(L.counters.ensure((3 * (size_t)(bounces + 1) + 1) * kQueueClasses * kCounterStride));
     if (c->stack_spill.n) HIP_TRY(L.stack_spill.ensure(c->stack_spill.n));
     if (!c->stream2)
     {
@@ -1138,7 +1141,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
     {
         const size_t planes_np = (size_t)slots * c->screen.pixels_padded;
-        const bool   grows     = c->pl_color.n < planes_np || c->counters.n < 3 * (size_t)(num_bounces + 1) * kQueueClasses * kCounterStride ||
+        const bool   grows     = c->pl_color.n < planes_np || c->counters.n < (3 * (size_t)(num_bounces + 1) + 1) * kQueueClasses * kCounterStride ||
                            !c->accum.p || c->accum.n < c->screen.pixels_padded;
         if (grows) HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -1317,6 +1320,22 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             return e == hipSuccess ? CAP_OK : CAP_ERR_HIP;
         };
         bool primary_shaded = false;  // tree path: bounce 0's shading done by the camera-ray kernel
+        // Camera rays of a DENSE scene.  The packet walk (one node sequence per 8x8-pixel tile) is the fast form while a tile's 64
+        // rays meet few triangles: 9.3 per packet on the 262 k-triangle hall at 1080p (0.13 triangles per pixel).  At 16.8 M
+        // triangles (8 per pixel) a tile covers hundreds of leaves, every lane pays for every one of them, and the stage was 7.2 of the
+        // big_variant's 24 ms: there the rays go through k_trace_closest8 like extension rays do, one lane each.  Same hit rule, same
+        // bits.  The wide view's padding budget assumes ray origins inside the scene bounds (wide_builder.cpp): a camera outside them
+        // keeps the packet walk.
+        bool primary_wide = false;
+        if (!fused && bvh.wide8_ok && c->tri_count > kExhaustiveMax)
+        {
+            static const int force = getenv("CAP_PRIMARY_WIDE") ? atoi(getenv("CAP_PRIMARY_WIDE")) : -1;  // A/B switch: 0 never, 1 whenever allowed
+            bool inside = true;
+            for (int k = 0; k < 3; ++k)
+                inside = inside && c->camera.position[k] >= c->bvh_info.bounds_lo[k] && c->camera.position[k] <= c->bvh_info.bounds_hi[k];
+            const double per_pixel = (double)c->tri_count / std::max(1.0, (double)c->screen.width * c->screen.height);
+            primary_wide = inside && (force >= 0 ? force != 0 : per_pixel >= kPrimaryWideTrianglesPerPixel);
+        }
         for (uint32_t b = 0; b <= D; ++b)
         {
             const int pi = (int)(b & 1u), po = pi ^ 1;
@@ -1341,8 +1360,19 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                 {
                     {
                         StageTimer t(c, ST_PRIMARY, st);
-                        primary_shaded = launch_primary_shade(cfg, bvh, sa, L.hits, ext);
-                        if (!primary_shaded) launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, L.hits, sa.work);
+                        if (primary_wide)
+                        {
+                            // dense scene: camera rays as an identity queue through the wide per-lane kernel (see above)
+                            const uint32_t id_cap = (((max_count + kQueueClasses - 1) / kQueueClasses) + 63u) & ~63u;
+                            const RayQueue idq{L.q_org[0], L.q_dir[0], nullptr, L.counters + 3 * counter_words, id_cap, nullptr};
+                            launch_raygen_identity(cfg, cam, c->screen, frames, ns, idq);
+                            launch_trace_closest8(cfg, bvh, idq, max_count, L.hits, sa.work);
+                        }
+                        else
+                        {
+                            primary_shaded = launch_primary_shade(cfg, bvh, sa, L.hits, ext);
+                            if (!primary_shaded) launch_trace_primary(cfg, bvh, cam, c->screen, frames, ns, L.hits, sa.work);
+                        }
                     }
                     if (aov_slot != ~0u) launch_geo_aov(cfg, scene, L.hits + (size_t)aov_slot * Ppad, Ppad, c->aov_geo.p);
                 }

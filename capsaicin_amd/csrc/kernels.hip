@@ -594,6 +594,42 @@ __global__ __launch_bounds__(kBlock, 8) void k_trace_primary_packet(BvhDev bvh, 
     }
 }
 
+// Camera rays as an "identity queue" for the wide closest-hit kernel (dense scenes, see launch_raygen_identity): entry i is the ray
+// of (frame slot, local pixel) = (i / Ppad, i % Ppad), so the hit record lands where the bounce-0 shade stage looks for it.
+// Padding lanes of partial tiles get an empty interval.  The 64 sub-queue counters are written here too: class k owns entries
+// [k * capacity, min((k + 1) * capacity, total)).
+__global__ __launch_bounds__(kBlock) void k_raygen_identity(CameraDev cam, ScreenDev screen, const FrameConst* frames, uint32_t n_slots, float4* org,
+                                                            float4* dir, uint32_t* count, uint32_t capacity)
+{
+    const uint32_t Ppad = screen.pixels_padded, total = n_slots * Ppad;
+    if (blockIdx.x == 0 && threadIdx.x < kQueueClasses)
+    {
+        const uint64_t begin = (uint64_t)threadIdx.x * capacity;
+        count[threadIdx.x * kCounterStride] = begin < total ? (uint32_t)(total - begin < capacity ? total - begin : capacity) : 0u;
+    }
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock)
+    {
+        const uint32_t slot = i / Ppad, pl = i - slot * Ppad;
+        uint32_t       x = 0, y = 0;
+        const bool     alive = local_pixel_to_xy(screen, pl, x, y);
+        const v3       d     = alive ? primary_dir(cam, screen, frames[slot], x, y) : mk3(0.f, 0.f, 1.f);
+        org[i] = make_float4(cam.position[0], cam.position[1], cam.position[2], 0.0f);
+        dir[i] = make_float4(d.x, d.y, d.z, alive ? kPrimaryFar : 0.0f);
+    }
+}
+
+void launch_raygen_identity(const LaunchCfg& cfg, const CameraDev& cam, const ScreenDev& screen, const FrameConst* frames, uint32_t n_slots,
+                            const RayQueue& q)
+{
+    const uint32_t total = n_slots * screen.pixels_padded;
+    uint32_t       g     = (total + kBlock - 1) / kBlock;
+    const uint32_t cap   = (cfg.cu_count ? cfg.cu_count : 256u) * 8u;
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL(k_raygen_identity, dim3(g), dim3(kBlock), 0, cfg.stream, cam, screen, frames, n_slots, q.org_tmin, q.dir_tmax, q.count,
+                       q.class_capacity);
+}
+
 template <int STACK>
 __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_closest(BvhDev bvh, RayQueue q, float4* hits)
 {
