@@ -280,17 +280,23 @@ def ext_variant(dev, stream, steps, spp=SPP):
             "roofline": roof, "stage_ms": stage_ms(ep)}
 
 
-def tree_rooflines(tp, key, scene_note):
+def tree_rooflines(tp, key, scene_note, dense=False):
     """The tree path's two priced kernels from one stage-timed render: k_trace_closest8 -- (A) queue bytes, 32-B ray read + 16-B hit
     written, and (A + B) with the nodes and triangle records a ray requests (instrumented build, tools/w8_counts.py,
-    committed with the counter passes) -- and k_shade (144 B per shaded vertex; escapes priced separately)."""
+    committed with the counter passes) -- and k_shade (144 B per shaded vertex; escapes priced separately).
+    dense: the scene has >= 1 triangle per pixel, so the camera rays went through k_trace_closest8 as well (context.hip primary_wide):
+    one more launch per batch, timed under the primary stage together with the 0.1 ms of k_raygen_identity that feeds it; its rays,
+    launches and time are part of the kernel's totals here, as they are of the counter passes' per-dispatch averages."""
     pmc, _ = committed_counters(key)
     trav = pmc.get("traversal_bytes_per_ray") if pmc else None
-    troof = roofline_object("k_trace_closest8 (extension rays, compressed 8-wide tree)", key, BYTES_CLOSEST * tp.rays_extension,
-                            tp.launches_trace_closest, tp.ms_trace_closest, tp.rays_extension)
+    k_rays, k_ms, k_launches = tp.rays_extension, tp.ms_trace_closest, tp.launches_trace_closest
+    if dense:
+        k_rays, k_ms, k_launches = k_rays + tp.rays_primary, k_ms + tp.ms_primary, k_launches + tp.launches_trace_closest // DEPTH
+    troof = roofline_object("k_trace_closest8 (%s rays, compressed 8-wide tree)" % ("camera + extension" if dense else "extension"), key,
+                            BYTES_CLOSEST * k_rays, k_launches, k_ms, k_rays)
     troof["bound_note"] = scene_note
     if trav:
-        ab = (BYTES_CLOSEST + trav) * tp.rays_extension / (tp.ms_trace_closest * 1e-3) / 1e9
+        ab = (BYTES_CLOSEST + trav) * k_rays / (k_ms * 1e-3) / 1e9
         troof.update({"traversal_bytes_per_ray": trav, "node_steps_per_ray": pmc.get("node_steps_per_ray"),
                       "triangle_tests_per_ray": pmc.get("triangle_tests_per_ray"), "achieved_with_traversal_bytes": ab,
                       "frac_with_traversal_bytes": ab / HBM_PEAK_GBS, "frac_with_traversal_bytes_of_achievable": ab / HBM_ACHIEVABLE_GBS})
@@ -353,9 +359,11 @@ def big_variant(dev, stream):
     dt, bs = timed(r, 0, BIG_SPP, DEPTH, 0, 2)
     check_guards(bs, "big_variant")
     _, bp = timed(r, 0, BIG_SPP, DEPTH, capi.RENDER_STAGE_TIMERS, 1)
+    n_tri_per_pixel = bi.triangle_count / float(WIDTH * HEIGHT)
     troof, sroof = tree_rooflines(bp, "big", "16.8 M triangles: the wide nodes and intersection records no longer fit the Infinity Cache, so "
                                   "`traffic` (measured HBM bytes) approaches the (A + B) bytes a ray requests; frac = (A) alone, "
-                                  "frac_with_traversal_bytes = (A + B) against the 8 TB/s peak, traffic_frac = measured bytes against it")
+                                  "frac_with_traversal_bytes = (A + B) against the 8 TB/s peak, traffic_frac = measured bytes against it",
+                                  dense=n_tri_per_pixel >= 1.0)
     r.close()
     rays = bs.rays_primary + bs.rays_extension + bs.rays_shadow
     n = int(bi.triangle_count)

@@ -113,6 +113,7 @@ SYMBOLS = {
     "cap_debug_get": (_i, [_vp, _u32, C.POINTER(_u64)]),
     "cap_render": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "cap_accum_reset": (_i, [_vp]),
+    "cap_accum_import": (_i, [_vp, _vp, _u64]),
     "cap_sync": (_i, [_vp]),
     "cap_readback": (_i, [_vp, _i, _vp]),
     "cap_stats_get": (_i, [_vp, C.POINTER(Stats)]),
@@ -441,6 +442,12 @@ class Renderer:
 
     def accum_reset(self):
         _check(lib().cap_accum_reset(self.ctx), "cap_accum_reset")
+
+    def accum_import(self, sum_rgba, frames):
+        """Continues a dumped accumulation: sum_rgba = readback(BUF_ACCUM_SUM) of the interrupted render, frames = its frame count."""
+        a = np.ascontiguousarray(sum_rgba, np.float32)
+        assert a.shape == (self.height, self.width, 4)
+        _check(lib().cap_accum_import(self.ctx, _p(a), int(frames)), "cap_accum_import")
 
     def sync(self):
         _check(lib().cap_sync(self.ctx), "cap_sync")

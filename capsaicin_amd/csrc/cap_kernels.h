@@ -92,6 +92,8 @@ void launch_resolve(const LaunchCfg& cfg, const Planes& planes, uint32_t n_slots
 // plane_kind: 0 copy, 1 combined (color*albedo+direct from the three planes at slot offset), 2 mean (xyz / w)
 void launch_untile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* src, const float4* albedo, const float4* direct,
                    int plane_kind, float4* image);
+// the inverse of launch_untile(.., 0, ..): a row-major image into this shard's tile order (cap_accum_import)
+void launch_tile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* image, float4* dst);
 // s0 may be null (its image is produced elsewhere)
 void launch_untile4(const LaunchCfg& cfg, const ScreenDev& screen, const float4* s0, const float4* s1, const float4* s2, const float4* s3,
                     float4* d0, float4* d1, float4* d2, float4* d3);

@@ -1067,6 +1067,24 @@ int cap_accum_reset(CapContext* c)
     return CAP_OK;
 }
 
+int cap_accum_import(CapContext* c, const float* sum_rgba, uint64_t frames)
+{
+    if (!c || !sum_rgba) return fail(CAP_ERR_INVALID_ARG, "cap_accum_import: NULL argument");
+    if (!c->screen.width) return fail(CAP_ERR_STATE, "cap_accum_import: resolution not set");
+    HIP_TRY(hipSetDevice(c->device));
+    if (sync_and_collect(c) != CAP_OK) return CAP_ERR_HIP;
+    const size_t npix = (size_t)c->screen.width * c->screen.height;
+    HIP_TRY(c->image_tmp.ensure(npix));
+    HIP_TRY(c->accum.ensure(c->screen.pixels_padded));
+    HIP_TRY(hipMemcpyAsync(c->image_tmp.p, sum_rgba, sizeof(float4) * npix, hipMemcpyHostToDevice, c->stream));
+    LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * 8u, 32};
+    launch_tile(cfg, c->screen, c->image_tmp.p, c->accum.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the host buffer is borrowed for the duration of the call only
+    c->frames_accumulated = frames;
+    return CAP_OK;
+}
+
 int cap_sync(CapContext* c)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_sync: ctx is NULL");

@@ -2609,6 +2609,23 @@ void launch_untile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* 
     hipLaunchKernelGGL(k_untile, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, screen, src, albedo, direct, plane_kind, image);
 }
 
+// row-major image -> this shard's tile-ordered buffer (the inverse of k_untile, kind 0); padding lanes and other shards' pixels: 0
+__global__ __launch_bounds__(kBlock) void k_tile(ScreenDev sc, const float4* image, float4* dst)
+{
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < sc.pixels_padded; pl += gridDim.x * kBlock)
+    {
+        uint32_t x, y;
+        dst[pl] = local_pixel_to_xy(sc, pl, x, y) ? image[(size_t)y * sc.width + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+void launch_tile(const LaunchCfg& cfg, const ScreenDev& screen, const float4* image, float4* dst)
+{
+    uint32_t g = (screen.pixels_padded + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_tile, dim3(g ? g : 1), dim3(kBlock), 0, cfg.stream, screen, image, dst);
+}
+
 __global__ __launch_bounds__(kBlock) void k_tiles_mean(const float4* accum, uint32_t Ppad, float4* dst)
 {
     for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < Ppad; pl += gridDim.x * kBlock)

@@ -245,6 +245,11 @@ int cap_set_traversal(CapContext* ctx, uint32_t mode);
  * stream; cap_readback / cap_stats_get / cap_sync wait for it. */
 int cap_render(CapContext* ctx, uint32_t frame_begin, uint32_t n_frames, uint32_t num_bounces, uint32_t flags);
 int cap_accum_reset(CapContext* ctx);
+/* Resume of a long accumulation (SURVEY.md 5 "checkpoint": dump accumulation + sample index): sum_rgba = width*height*4 floats as
+ * cap_readback(CAP_BUF_ACCUM_SUM) returned them (running sums in .xyz, frames in .w), frames = how many frames they hold; the next
+ * cap_render(frames, n, ..) continues the sum exactly where the dumped one stopped -- the additions are the same, in the same frame
+ * order, so the result is bit-identical to an uninterrupted render.  A sharded context takes its own tiles of the image. */
+int cap_accum_import(CapContext* ctx, const float* sum_rgba, uint64_t frames);
 int cap_sync(CapContext* ctx);
 
 /* dst: width*height*4 floats (host), row 0 = pixel row 0.  Pixels outside this context's shard read 0. */

@@ -208,3 +208,35 @@ def test_full_size_properties(cornell, bluenoise):
     ref = sc.render_frame(_oracle_cam(O, cam), bluenoise, w, h, 0, D, flags=O.FLAG_USE_BVH, threads=8)
     assert_same(got, ref["combined"], "1080p frame 0 combined")
     assert (r.stats().rays_extension - s.rays_extension, ) is not None
+
+
+def test_accum_import_resumes_bit_identically(native_lib, bluenoise, cornell_path):
+    """cap_accum_import (SURVEY.md 5 "checkpoint": dump accumulation + sample index): a render interrupted after 5 of 9 frames, its
+    CAP_BUF_ACCUM_SUM dumped to the host and imported into a FRESH context, continues to the bits of the uninterrupted render -- the
+    resolve adds frames in frame order either way -- on the fused and on the tree path, unsharded and on a shard."""
+    w, h, D = 200, 120, 3
+    for traversal, shard in ((0, (0, 1)), (1, (0, 1)), (0, (1, 3))):
+        def make():
+            r = capi.Renderer(0)
+            r.upload_geometry(capi.Geometry(cornell_path))
+            r.upload_bluenoise(bluenoise)
+            r.build_bvh()
+            r.set_resolution(w, h)
+            r.set_shard(*shard)
+            r.set_camera(capi.cornell_camera(w, h))
+            r.set_traversal(traversal)
+            return r
+        a = make()
+        a.render(0, 9, D, 0)
+        want = a.readback(capi.BUF_ACCUM_SUM)
+        a.accum_reset()
+        a.render(0, 5, D, 0)
+        dump = a.readback(capi.BUF_ACCUM_SUM)
+        a.close()
+        b = make()
+        b.accum_import(dump, 5)
+        b.render(5, 4, D, 0)
+        got = b.readback(capi.BUF_ACCUM_SUM)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (traversal, shard)
+        assert (got[..., 3][got[..., 3] > 0] == 9).all()
+        b.close()
