@@ -21,6 +21,16 @@ constexpr uint32_t kBlock      = 256;  // threads per workgroup (4 waves, one pe
 // its own counter on its own 128-byte line.  A path's class is fixed at bounce 0 (64-path chunk index mod kQueueClasses)
 // and never changes, so sub-queue k can never hold more than the class-k paths: static capacity, no overflow handling.
 constexpr uint32_t kQueueClasses  = 64;
+// Which class a 64-path chunk of bounce 0 gets, and the inverse (the j-th chunk of class k).  Every aligned block of 64 chunks holds
+// each class exactly once, so class k still receives ceil(chunks / 64) chunks -- the static capacity -- but the assignment ROTATES
+// with the block index.  With the plain `chunk mod 64` of rounds 1-3 a class was tied to whatever `chunk mod 64` means on the screen:
+// for a tile-sharded 4096 x 4096 frame (512 tile columns, shard s = tile columns s mod 8) that is ONE 8-pixel-wide column of the
+// image per class for all its frames, the classes' path counts after the first bounce differ by what their columns look at, and a
+// launch lasts as long as its longest class (waves never change class): 23.3 instead of 31.2 Grays/s for one rank's share of
+// BASELINE configs[4] (docs/experiments.md (54)).  The rotation walks every class across all columns.
+constexpr uint32_t kQueueClassBits = 6;
+__host__ __device__ __forceinline__ uint32_t chunk_class(uint32_t chunk) { return (chunk + (chunk >> kQueueClassBits)) & (kQueueClasses - 1u); }
+__host__ __device__ __forceinline__ uint32_t class_chunk(uint32_t j, uint32_t klass) { return (j << kQueueClassBits) | ((klass - j) & (kQueueClasses - 1u)); }
 constexpr uint32_t kCounterStride = 32;  // uint32 words between two class counters (128 B)
 // Words 2 and 3 of a class's counter line: shadow rays answered by the producer's probe, shaded vertices (flush_stats)
 constexpr uint32_t kShadeRec      = 8;   // float4 per shading record

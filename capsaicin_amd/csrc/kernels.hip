@@ -2025,7 +2025,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(ShadeArgs a)
         {
             i      = chunk * 64 + (threadIdx.x & 63u);
             active = true;
-            klass  = (blockIdx.y * (Ppad >> 6) + chunk) % kQueueClasses;  // the path's class for its whole life
+            klass  = chunk_class(blockIdx.y * (Ppad >> 6) + chunk);  // the path's class for its whole life
         }
         else
             active = queue_chunk(a.in.count, a.in.class_capacity, chunk, threadIdx.x & 63u, i, klass);
@@ -2096,7 +2096,7 @@ __global__ __launch_bounds__(kBlock, CAP_PS_BLOCKS) void k_primary_shade(BvhDev 
     st.start();
     while (true)
     {
-        const uint32_t chunk = grab_value(grab) * kQueueClasses + my_class;  // chunk % kQueueClasses: the paths' class, as k_shade<FIRST> assigns it
+        const uint32_t chunk = class_chunk(grab_value(grab), my_class);  // chunk_class(chunk) == my_class: the paths' class, as k_shade<FIRST> assigns it
         if (chunk >= chunks) break;
         grab = grab_issue(a.work, my_class);
         const uint32_t slot = chunk / cps;  // wave-uniform
@@ -2367,8 +2367,8 @@ __global__ __launch_bounds__(kBlock, FB ? 4 : (EXT ? (FIRST ? 5 : CAP_TS_EXT) : 
         float          carried_r1 = 0.f, carried_r2 = 0.f;
         if (FIRST)
         {
-            const uint32_t chunk = j * kQueueClasses + my_class;
-            if (chunk >= chunks) break;
+            const uint32_t chunk = class_chunk(j, my_class);
+            if (chunk >= chunks) break;  // (only in or past the last block of 64 chunks: every earlier block holds each class once)
             grab   = grab_issue(a.work, my_class);
             slot   = chunk / cps;  // wave-uniform
             i      = (chunk - slot * cps) * 64 + lane;
