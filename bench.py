@@ -307,7 +307,8 @@ def tree_rooflines(tp, key, scene_note, dense=False):
     shade_ms, shade_launches = tp.ms_shade, max(1, tp.launches_shade)
     # bounce 0 is shaded by the camera-ray kernel (k_primary_shade): k_shade sees the vertices of bounces >= 1 -- at least
     # shaded_vertices - rays_primary of them (not every camera ray finds a vertex: a lower bound, on purpose)
-    shade_vertices = max(0, tp.shaded_vertices - tp.rays_primary)
+    # (dense scenes: bounce 0 has its own k_shade<FIRST> launch, every vertex is k_shade's)
+    shade_vertices = tp.shaded_vertices if dense else max(0, tp.shaded_vertices - tp.rays_primary)
     sroof = {"bound": "hbm", "kernel": "k_shade, bounces >= 1 (attributes, material, direct light, BSDF sample, queue compaction)",
              "achieved": BYTES_VERTEX * shade_vertices / (shade_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "traffic": (spmc["hbm_bytes_per_launch"] / (shade_ms / shade_launches * 1e-3) / 1e9) if spmc else None,
@@ -316,7 +317,7 @@ def tree_rooflines(tp, key, scene_note, dense=False):
     sroof["frac"] = sroof["achieved"] / HBM_PEAK_GBS
     # the escaped extension rays among k_shade's items: 32 B of queue stream (hit 16 + throughput / path id 16) and a 16-B
     # load-add-store of the path's plane entry for the sky term (rt_indirect.hlsl:94-99) each, without being a vertex
-    escapes = max(0, int(tp.rays_extension) - int(shade_vertices))
+    escapes = max(0, int(tp.rays_extension) + (int(tp.rays_primary) if dense else 0) - int(shade_vertices))
     sroof["escapes_per_step"] = escapes
     sroof["achieved_with_escapes"] = (BYTES_VERTEX * shade_vertices + 64 * escapes) / (shade_ms * 1e-3) / 1e9
     sroof["frac_with_escapes"] = sroof["achieved_with_escapes"] / HBM_PEAK_GBS
@@ -332,7 +333,11 @@ def tree_variant(dev, stream):
     dt, ts = timed(r2, 0, TREE_FULL_SPP, DEPTH, 0, 1)
     check_guards(ts, "tree_variant")
     dt32, ts32 = timed(r2, 0, TREE_SPP, DEPTH, 0, 2)
-    _, tp = timed(r2, 0, TREE_SPP, DEPTH, capi.RENDER_STAGE_TIMERS, 1)
+    # Stage split and rooflines: TWO whole batches (2 x 32 spp), stage-timed, i.e. one after the other on one stream.  A render that
+    # fits one batch would be cut in two halves for the two lanes (context.hip) and keep that cut under the stage timers; whole
+    # batches are what tools/prof.sh profiles (CAP_NO_TWO_LANES=1: a launch's duration is its own), so the per-launch figures of this
+    # line, of profiles/r04_kernel_stats_tree.csv and of the counter passes describe the same launches.
+    _, tp = timed(r2, 0, 2 * TREE_SPP, DEPTH, capi.RENDER_STAGE_TIMERS, 1)
     troof, sroof = tree_rooflines(tp, "tree", "texture-address path + vector-instruction issue + exposed latency (DESIGN.md 5): on this "
                                   "scene the nodes and triangles a ray touches come from L2 / Infinity Cache, not HBM; achieved / frac = "
                                   "queue-stream bytes (A), achieved_with_traversal_bytes = (A + B) requested bytes, traffic = measured HBM bytes")
@@ -342,7 +347,8 @@ def tree_variant(dev, stream):
                         (bi2.triangle_count, WIDTH, HEIGHT, TREE_FULL_SPP, DEPTH),
             "value": rays(ts) / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
             "bvh": {"build": "device PLOC + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
-            "batch_32spp": {"value": rays(ts32) / 2 / dt32 / 1e6, "ms_per_step": dt32 * 1e3, "stage_ms": stage_ms(tp)},
+            "batch_32spp": {"value": rays(ts32) / 2 / dt32 / 1e6, "ms_per_step": dt32 * 1e3,
+                            "stage_ms": {k: v / 2 for k, v in stage_ms(tp).items()}},
             "roofline": troof, "shade_roofline": sroof}
 
 
@@ -358,7 +364,9 @@ def big_variant(dev, stream):
     r.render(0, BIG_SPP, DEPTH, 0)
     dt, bs = timed(r, 0, BIG_SPP, DEPTH, 0, 2)
     check_guards(bs, "big_variant")
-    _, bp = timed(r, 0, BIG_SPP, DEPTH, capi.RENDER_STAGE_TIMERS, 1)
+    # (two whole 8-spp batches, stage-timed: see tree_variant)
+    r.set_batch_paths(BIG_SPP * r.tile_buffer_floats() // 4)
+    _, bp = timed(r, 0, 2 * BIG_SPP, DEPTH, capi.RENDER_STAGE_TIMERS, 1)
     n_tri_per_pixel = bi.triangle_count / float(WIDTH * HEIGHT)
     troof, sroof = tree_rooflines(bp, "big", "16.8 M triangles: the wide nodes and intersection records no longer fit the Infinity Cache, so "
                                   "`traffic` (measured HBM bytes) approaches the (A + B) bytes a ray requests; frac = (A) alone, "
@@ -373,7 +381,7 @@ def big_variant(dev, stream):
             "bvh": {"build": "device PLOC + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi.max_depth), "build_ms": float(bi.build_ms),
                     "wide_nodes": winfo[0], "wide_depth": winfo[1], "triangles_per_s_build": n / (bi.build_ms * 1e-3),
                     "resident_bytes": {"wide_nodes": 80 * winfo[0], "intersection_records": 64 * n, "shading_records": 128 * n}},
-            "scene_setup_s": setup_s, "roofline": troof, "shade_roofline": sroof, "stage_ms": stage_ms(bp)}
+            "scene_setup_s": setup_s, "roofline": troof, "shade_roofline": sroof, "stage_ms": {k: v / 2 for k, v in stage_ms(bp).items()}}
 
 
 def config3_variant(dev, stream):
