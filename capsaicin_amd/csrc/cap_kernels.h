@@ -37,6 +37,11 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
                       uint32_t pixels_padded, uint32_t n_slots, uint64_t* guard, uint32_t* work, bool mostly_unoccluded,
                       const FrameConst* frames);
 
+// The same for the reference model's shadow rays on the wide view with lane refill (trace8.hip): dense scenes, where a traversal step's
+// round trip ends in HBM.  Needs bvh.wide8_ok and the zeroed grab counters `work`.
+void launch_trace_any8_refill(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target, uint32_t pixels_padded,
+                              uint32_t n_slots, uint64_t* guard, uint32_t* work, const FrameConst* frames);
+
 // ---- shade ----
 struct ShadeArgs
 {

@@ -85,6 +85,8 @@ struct DevBuf
 
 // camera rays take the per-lane wide kernel instead of the packet walk from this many triangles per pixel on (measured: cap_render)
 constexpr double kPrimaryWideTrianglesPerPixel = 1.0;
+// shadow rays take the lane-refill kernel from this many bytes of wide nodes + intersection records on (measured: cap_render)
+constexpr uint64_t kAnyRefillTreeBytes = 512ull << 20;
 
 // guard block of a context (ShadeArgs::shaded_counter): {-, malformed path ids seen by shade, by trace_any, last offender, appends
 // beyond a class's capacity, -, -, -}
@@ -1344,6 +1346,18 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         // big_variant's 24 ms: there the rays go through k_trace_closest8 like extension rays do, one lane each.  Same hit rule, same
         // bits.  The wide view's padding budget assumes ray origins inside the scene bounds (wide_builder.cpp): a camera outside them
         // keeps the packet walk.
+        // Shadow rays of the reference model where the tree is far beyond the caches: the wide view with lane refill instead of chunk
+        // by chunk (trace8.hip k_trace_any8_refill).  Measured per 8 spp at 1080p, any-hit stage (tools/primary_ab.py): 262 k triangles
+        // (21 MB of wide nodes and intersection records) 1.89 -> 1.99 ms, 4.2 M (325 MB) 3.02 -> 3.02, 16.8 M (1.3 GB) 5.46 -> 4.01:
+        // lanes are throughput only where a step's round trip ends in HBM.  The switch sits at twice the 256-MiB Infinity Cache;
+        // A/B: CAP_ANY_REFILL=0|1.
+        bool any_refill = false;
+        if (!fused && !ext && bvh.wide8_ok && c->tri_count > kExhaustiveMax)
+        {
+            static const int force = getenv("CAP_ANY_REFILL") ? atoi(getenv("CAP_ANY_REFILL")) : -1;
+            const uint64_t tree_bytes = (uint64_t)c->wide8_nodes * kWideNodeWords * 4u + (uint64_t)c->tri_count * 64u;
+            any_refill = force >= 0 ? force != 0 : tree_bytes >= kAnyRefillTreeBytes;
+        }
         bool primary_wide = false;
         if (!fused && bvh.wide8_ok && c->tri_count > kExhaustiveMax)
         {
@@ -1404,8 +1418,12 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             if (!sa.inline_nee && !(fused && sa.wave_ring && b != 0))
             {
                 StageTimer t(c, ST_ANY, st, b == 0 ? ST_DIRECT : ST_NONE);
-                launch_trace_any(cfg_any, bvh, sa.shadow, max_count, b == 0 ? L.pl_direct : L.pl_color, Ppad, ns, c->shaded_counter.p,
-                                 work_any + b * per_queue, /* next-event estimation: most shadow rays reach the light */ ext, frames);
+                if (any_refill)
+                    launch_trace_any8_refill(cfg_any, bvh, sa.shadow, max_count, b == 0 ? L.pl_direct : L.pl_color, Ppad, ns, c->shaded_counter.p,
+                                             work_any + b * per_queue, frames);
+                else
+                    launch_trace_any(cfg_any, bvh, sa.shadow, max_count, b == 0 ? L.pl_direct : L.pl_color, Ppad, ns, c->shaded_counter.p,
+                                     work_any + b * per_queue, /* next-event estimation: most shadow rays reach the light */ ext, frames);
                 ++c->stats.launches_trace_any;
                 if (traced("trace_any", b)) return fail(CAP_ERR_HIP, "trace_any failed");
             }

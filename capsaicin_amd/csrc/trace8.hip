@@ -182,6 +182,151 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
 #endif
 }
 
+// Shadow rays of the reference model on the wide view with the closest-hit kernel's lane refill (dense scenes only, see
+// launch_trace_any8_refill): a lane that is done -- occluded at its first hit, or through the tree without one -- takes the next entry of
+// its class from the wave's LDS buffer.  The per-chunk kernel (k_trace_any<24>) keeps a wave on one chunk until its LONGEST ray is done,
+// with 29 of 64 lanes active on average; where the tree is cache-resident that costs nothing (a load sequence is paid per lane:
+// docs/experiments.md (44)), but where a step's round trip ends in HBM an iteration lasts 4 us whatever the number of lanes in it, and
+// lanes are throughput.  Same tests, same additions to the same plane entries by their only writers: bit-identical.
+// Entry format (reference model): (origin, path id) (contribution, -); direction = the light of the path's frame, tmin / tmax constants.
+__global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_any8_refill(BvhDev bvh, ShadowQueue q, float4* target, uint32_t pixels_padded,
+                                                                             uint32_t n_slots, uint64_t* guard, uint32_t* work, const FrameConst* frames,
+                                                                             uint32_t refill_idle)
+{
+    __shared__ uint2  lds_stack[kW8Lds * kBlock];
+    __shared__ float4 lds_rays[kBlock];  // per wave: 64 x (origin, path id)
+    __shared__ float4 lds_light[kMaxFrameSlots];
+    for (uint32_t k = threadIdx.x; k < n_slots && k < kMaxFrameSlots; k += kBlock)
+        lds_light[k] = make_float4(frames[k].light_dir[0], frames[k].light_dir[1], frames[k].light_dir[2], 0.f);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    float4* const  rbuf = lds_rays + (threadIdx.x >> 6) * 64u;
+    const uint32_t my_class = wave_global_id() % kQueueClasses;
+    uint32_t       n_class  = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.count[my_class * kCounterStride]);
+    n_class                 = n_class < q.class_capacity ? n_class : q.class_capacity;
+
+    uint32_t grab   = grab_issue(work, my_class);
+    uint32_t pend_n = 0, pend_base = 0, buf_n = 0, buf_pos = 0, buf_base = 0;
+    float4   pa = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto     fetch = [&]() {  // wave-uniform
+        const uint32_t start = grab_value(grab) * 64u;
+        pend_n               = 0;
+        if (start >= n_class) return;
+        pend_n    = n_class - start < 64u ? n_class - start : 64u;
+        pend_base = my_class * q.class_capacity + start;
+        if (lane < pend_n) pa = q.org_tmin[pend_base + lane];
+        grab = grab_issue(work, my_class);
+    };
+    fetch();
+
+    WideStack<kW8Lds> st{lds_stack + threadIdx.x, wide_spill_of_thread(bvh), 0};
+    bool              alive = false;
+    Ray               r     = make_ray(mk3(0, 0, 0), mk3(0, 0, 1), 0.f, 0.f);
+    WideRay           w     = make_wide_ray(r.o, r.d);
+    WideCursor        c;
+    wide_cursor_root(c);
+    uint32_t entry = 0;
+    size_t   idx   = 0;
+    bool     good  = false;
+    while (true)
+    {
+        unsigned long long m_alive = __ballot(alive);
+        if (64u - (uint32_t)__popcll(m_alive) >= refill_idle)
+        {
+            for (int rep = 0; rep < 2; ++rep)
+            {
+                if (buf_pos >= buf_n)
+                {
+                    if (pend_n == 0) break;
+                    if (lane < pend_n) rbuf[lane] = pa;
+                    buf_n = pend_n, buf_pos = 0, buf_base = pend_base;
+                    fetch();
+                    wave_handoff();
+                }
+                const unsigned long long idle = ~m_alive;
+                const uint32_t n_idle = (uint32_t)__popcll(idle), avail = buf_n - buf_pos;
+                const uint32_t take   = avail < n_idle ? avail : n_idle;
+                const uint32_t rank   = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!alive && rank < take)
+                {
+                    const uint32_t e   = buf_pos + rank;
+                    const float4   a   = rbuf[e];
+                    const uint32_t pid = f2u(a.w);
+                    entry = buf_base + e;
+                    good  = (pid >> kPidShift) < n_slots && (pid & kPidMask) < pixels_padded;
+                    idx   = (size_t)(pid >> kPidShift) * pixels_padded + (pid & kPidMask);
+                    if (!good)
+                    {
+                        // never true for a well-formed queue; reported through CapStats::guard_* instead of faulting
+                        atomicAdd((unsigned long long*)guard + 2, 1ull);
+                        guard[3] = ((uint64_t)entry << 32) | pid;
+                    }
+                    const float4 L = lds_light[good ? (pid >> kPidShift) : 0u];
+                    r = make_ray(mk3(a.x, a.y, a.z), mk3(L.x, L.y, L.z), kRayEps, good ? kRayFar : 0.0f);  // malformed entry: empty interval
+                    w = make_wide_ray(r.o, r.d);
+                    wide_cursor_root(c);
+                    st.sp = 0, alive = true;
+                }
+                buf_pos += take;
+                m_alive = __ballot(alive);
+                if (m_alive == ~0ull) break;
+            }
+        }
+        if (m_alive == 0ull)
+        {
+            if (buf_pos >= buf_n && pend_n == 0) break;  // feed ended and every lane retired
+            continue;
+        }
+        const bool    tri_lane = alive && c.t_hits != 0u, node_lane = alive && c.t_hits == 0u;
+        const float4* src      = bvh.nodes8;
+        if (tri_lane)
+            src = bvh.tris8 + 4 * (size_t)wide_pick_triangle(c);
+        else if (node_lane)
+        {
+            bool           rest;
+            const uint32_t node = wide_pick_child(c, w.octinv, rest);
+            if (rest) st.push(c.g_base, c.g_mask);
+            src = bvh.nodes8 + 5 * (size_t)node;
+        }
+        WideNode nd;
+        nd.h0 = nd.h1 = nd.q2 = nd.q3 = nd.q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (alive) nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2], nd.q3 = src[3];
+        if (node_lane) nd.q4 = src[4];
+        bool occluded = false;
+        if (tri_lane) occluded = tri_occludes(r, nd.h0, nd.h1, nd.q2);
+        if (node_lane) wide_node_test(nd, w, r.tmin, r.tmax, c);
+        if (occluded)
+            alive = false;  // lighting.h:57: an occluded ray adds nothing
+        else if (alive && c.t_hits == 0u && (c.g_mask >> 24) == 0u)
+        {
+            if (st.sp == 0)
+            {
+                // through the tree without an occluder: the contribution evaluated at shading time is added (lighting.h:57-60)
+                if (good)
+                {
+                    const float4 con = q.contrib_pid[entry], cur = target[idx];
+                    target[idx]      = make_float4(cur.x + con.x, cur.y + con.y, cur.z + con.z, cur.w);
+                }
+                alive = false;
+            }
+            else
+                st.pop(c);
+        }
+    }
+}
+
+void launch_trace_any8_refill(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target, uint32_t pixels_padded,
+                              uint32_t n_slots, uint64_t* guard, uint32_t* work, const FrameConst* frames)
+{
+    uint32_t g = (max_count + kBlock - 1) / kBlock;
+    uint32_t cap = cfg.cu_count ? cfg.cu_count * (uint32_t)CAP_W8_BLOCKS : cfg.grid_blocks;
+    if ((uint64_t)cap * kBlock > bvh.spill_threads) cap = bvh.spill_threads / kBlock;  // every thread owns a spill slice
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    static const uint32_t refill = getenv("CAP_W8_REFILL") ? (uint32_t)atoi(getenv("CAP_W8_REFILL")) : (uint32_t)CAP_W8_REFILL;
+    hipLaunchKernelGGL(k_trace_any8_refill, dim3(g), dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard, work, frames, refill);
+}
+
 #ifdef CAP_W8_COUNT
 extern "C" int cap_debug_w8_counts(unsigned long long* out, int reset)
 {

@@ -13,7 +13,7 @@ spp = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 r, bi = bench.make_hall(0, None, scale=scale)
 r.render(0, spp, bench.DEPTH, 0)
 _, s = bench.timed(r, 0, spp, bench.DEPTH, capi.RENDER_STAGE_TIMERS, 2)
-print("scale %g (%d triangles, %.2f per pixel) CAP_PRIMARY_WIDE=%s: primary %.2f closest %.2f any %.2f shade %.2f total %.2f ms per %d spp" %
-      (scale, bi.triangle_count, bi.triangle_count / (bench.WIDTH * bench.HEIGHT), os.environ.get("CAP_PRIMARY_WIDE", "auto"), s.ms_primary / 2,
+print("scale %g (%d triangles, %.2f per pixel) CAP_PRIMARY_WIDE=%s CAP_ANY_REFILL=%s: primary %.2f closest %.2f any %.2f shade %.2f total %.2f ms per %d spp" %
+      (scale, bi.triangle_count, bi.triangle_count / (bench.WIDTH * bench.HEIGHT), os.environ.get("CAP_PRIMARY_WIDE", "auto"), os.environ.get("CAP_ANY_REFILL", "auto"), s.ms_primary / 2,
        s.ms_trace_closest / 2, s.ms_trace_any / 2, s.ms_shade / 2, s.ms_total / 2, spp))
 r.close()
