@@ -166,3 +166,49 @@ def test_no_wide8_child_process_is_bit_identical(native_lib, bluenoise, tmp_path
         for i, pl in enumerate(planes):
             assert np.array_equal(bits(pl), bits(child["%s_p%d" % (scene, i)])), (scene, i)
         r.close()
+
+
+CHILD_DENSE = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import test_fallback_kernels_gpu as T
+from capsaicin_amd import capi
+bn = capi.load_bluenoise()
+out = {{}}
+for scene in ("soup", "hall"):
+    for shard in ((0, 1), (1, 3)):
+        r, info = T.make(scene, bn, 160, 96, capi.Renderer.BVH_BUILD_AUTO)
+        r.set_shard(*shard)
+        planes, acc, rays = T.render_all(r, 2, 3, 4)
+        key = "%s_%d_%d" % (scene, shard[0], shard[1])
+        out[key + "_acc"] = acc
+        out[key + "_rays"] = np.uint64(rays)
+        for i, p in enumerate(planes):
+            out["%s_p%d" % (key, i)] = p
+        r.close()
+np.savez({path!r}, **out)
+"""
+
+
+def test_dense_scene_kernels_forced_on_small_scenes(native_lib, bluenoise, tmp_path):
+    """The two kernels dense scenes switch to -- camera rays as an identity queue through k_trace_closest8 (from one triangle per
+    pixel on) and shadow rays through k_trace_any8_refill (from 512 MiB of tree on) -- forced on small scenes in a child process
+    (CAP_PRIMARY_WIDE=1 CAP_ANY_REFILL=1), unsharded and on shard 1 of 3: all six planes, the accumulated image and the ray counters
+    are those of this process, which takes the packet walk and the per-chunk kernel.  (At their own sizes:
+    tests/test_big_scene_gpu.py.)"""
+    path = str(tmp_path / "dense.npz")
+    env = dict(os.environ, CAP_PRIMARY_WIDE="1", CAP_ANY_REFILL="1")
+    p = subprocess.run([sys.executable, "-c", CHILD_DENSE.format(root=ROOT, tests=os.path.join(ROOT, "tests"), path=path)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    child = np.load(path)
+    for scene in ("soup", "hall"):
+        for shard in ((0, 1), (1, 3)):
+            r, info = make(scene, bluenoise, 160, 96, capi.Renderer.BVH_BUILD_AUTO)
+            r.set_shard(*shard)
+            planes, acc, rays = render_all(r, 2, 3, 4)
+            key = "%s_%d_%d" % (scene, shard[0], shard[1])
+            assert np.array_equal(bits(acc), bits(child[key + "_acc"])) and tuple(int(x) for x in child[key + "_rays"]) == rays, key
+            for i, pl in enumerate(planes):
+                assert np.array_equal(bits(pl), bits(child["%s_p%d" % (key, i)])), (key, i)
+            r.close()
