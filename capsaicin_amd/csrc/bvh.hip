@@ -490,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_level(WideCollapseArgs a)
     for (uint32_t k = 0; k < kWideLeafMax; ++k)
         for (int s = 0; s < 8; ++s)
             if (leaf_n[s] > k) a.tri_src[at++] = leaf_tri[s][k];
-    uint32_t* o = a.nodes8 + (size_t)w * kWideNodeWords;
+    uint32_t* o = a.nodes8 + (size_t)w * kWideNodeStride;
     for (uint32_t k = 0; k < kWideNodeWords; ++k) o[k] = word[k];
 }
 }  // namespace

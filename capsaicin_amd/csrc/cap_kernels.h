@@ -154,7 +154,7 @@ void launch_bvh_finish_host(hipStream_t stream, const BvhBuildArgs& a);
 // Compressed 8-wide view (wide_builder.cpp builds the nodes on the host): intersection records into its leaf order.
 void     launch_gather_wide(hipStream_t stream, const uint32_t* tri_src, const float4* tris_sorted, uint32_t n, float4* tris8);
 // Device-side collapse of the device-built binary tree (needs BvhBuildArgs::keys[1] = the subtree counts launch_bvh_build leaves
-// there).  task: capacity words of scratch; alloc: 2 words; nodes8: capacity * kWideNodeWords words; tri_src: n_tris words.
+// there).  task: capacity words of scratch; alloc: 2 words; nodes8: capacity * kWideNodeStride words; tri_src: n_tris words.
 struct WideCollapseArgs
 {
     const float4*   bnodes;

@@ -31,6 +31,13 @@
 namespace cap
 {
 constexpr uint32_t kWideNodeWords = 20;     // 80 B
+// Words between two nodes in device memory.  20: packed (a node straddles 128-byte lines: 1.5 on average).  32: every node in its own
+// 128-byte line -- what an L2 miss fetches (docs/experiments.md (58)).
+#ifndef CAP_WIDE_STRIDE_WORDS
+#define CAP_WIDE_STRIDE_WORDS 20
+#endif
+constexpr uint32_t kWideNodeStride = CAP_WIDE_STRIDE_WORDS;
+static_assert(kWideNodeStride >= kWideNodeWords && kWideNodeStride % 4u == 0u, "node stride: whole 16-byte pieces");
 constexpr uint32_t kWideLeafMax   = 3;      // triangles per leaf child (k = 0..2: the three byte lanes of tvalid)
 constexpr float    kWidePad       = 4e-6f;  // child boxes grow by this times max(scene diagonal extent, largest |coordinate|)
 constexpr uint32_t kWideTopNodes  = 73;     // nodes 0 .. kWideTopNodes-1 (breadth-first: root, its children, their children at most)

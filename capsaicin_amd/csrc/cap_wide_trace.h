@@ -203,7 +203,7 @@ __device__ __forceinline__ bool traverse_any8(const BvhDev& bvh, const Ray& r, u
                     st.spill[st.sp - kPairs] = make_uint2(c.g_base, c.g_mask);
                 ++st.sp;
             }
-            src = bvh.nodes8 + 5 * (size_t)node;
+            src = bvh.nodes8 + (kWideNodeStride / 4u) * (size_t)node;
         }
         WideNode nd;
         nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2], nd.q3 = src[3];

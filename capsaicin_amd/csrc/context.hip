@@ -853,7 +853,7 @@ int cap_bvh_build(CapContext* c)
         {
             // the device built the binary tree: collapse it there too (bvh.hip k_wide_level), nothing leaves the GPU
             const uint32_t cap = n / 2u + 16u;  // an inner child stands for >= 4 triangles
-            HIP_TRY(c->nodes8.ensure(5 * std::max<size_t>((size_t)cap + 1, kWideTopNodes)));
+            HIP_TRY(c->nodes8.ensure((kWideNodeStride / 4) * std::max<size_t>((size_t)cap + 1, kWideTopNodes)));
             HIP_TRY(c->wide_task.ensure(cap));
             HIP_TRY(c->wide_alloc.ensure(2));
             double m = 0.0;
@@ -877,8 +877,9 @@ int cap_bvh_build(CapContext* c)
             WideTree wt;
             build_wide_tree(n >= 2 ? bnodes_host.data() : nullptr, n, bi.bounds_lo, bi.bounds_hi, wt);
             wn = wt.nodes.size() / kWideNodeWords, wdepth = wt.depth, wtop = wt.top_nodes;
-            HIP_TRY(c->nodes8.ensure(5 * std::max<size_t>(wn + 1, kWideTopNodes)));
-            HIP_TRY(hipMemcpy(c->nodes8.p, wt.nodes.data(), sizeof(uint32_t) * wt.nodes.size(), hipMemcpyHostToDevice));
+            HIP_TRY(c->nodes8.ensure((kWideNodeStride / 4) * std::max<size_t>(wn + 1, kWideTopNodes)));
+            if (wn) HIP_TRY(hipMemcpy2D(c->nodes8.p, sizeof(uint32_t) * kWideNodeStride, wt.nodes.data(), sizeof(uint32_t) * kWideNodeWords,
+                                        sizeof(uint32_t) * kWideNodeWords, wn, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(c->wide_src.p, wt.tri_src.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
         }
         launch_gather_wide(c->stream, c->wide_src.p, c->tris_sorted.p, n, c->tris8.p);
@@ -960,7 +961,9 @@ int cap_bvh_wide_readback(CapContext* c, uint32_t* nodes, uint32_t* tri_src, uin
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     info[0] = c->wide8_nodes, info[1] = c->wide8_depth, info[2] = c->wide8_top;
-    if (nodes && c->wide8_nodes) HIP_TRY(hipMemcpy(nodes, c->nodes8.p, sizeof(uint32_t) * kWideNodeWords * c->wide8_nodes, hipMemcpyDeviceToHost));
+    if (nodes && c->wide8_nodes)
+        HIP_TRY(hipMemcpy2D(nodes, sizeof(uint32_t) * kWideNodeWords, c->nodes8.p, sizeof(uint32_t) * kWideNodeStride, sizeof(uint32_t) * kWideNodeWords,
+                            c->wide8_nodes, hipMemcpyDeviceToHost));
     if (tri_src && c->tri_count) HIP_TRY(hipMemcpy(tri_src, c->wide_src.p, sizeof(uint32_t) * c->tri_count, hipMemcpyDeviceToHost));
     return CAP_OK;
 }
@@ -1355,7 +1358,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         if (!fused && !ext && bvh.wide8_ok && c->tri_count > kExhaustiveMax)
         {
             static const int force = getenv("CAP_ANY_REFILL") ? atoi(getenv("CAP_ANY_REFILL")) : -1;
-            const uint64_t tree_bytes = (uint64_t)c->wide8_nodes * kWideNodeWords * 4u + (uint64_t)c->tri_count * 64u;
+            const uint64_t tree_bytes = (uint64_t)c->wide8_nodes * kWideNodeStride * 4u + (uint64_t)c->tri_count * 64u;
             any_refill = force >= 0 ? force != 0 : tree_bytes >= kAnyRefillTreeBytes;
         }
         bool primary_wide = false;

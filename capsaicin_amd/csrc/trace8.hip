@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
             W8_COUNT(7, (rest && st.sp >= kW8Lds) ? 1 : 0);
             W8_COUNT(3, node < kWideTopNodes ? 1 : 0);
             if (rest) st.push(c.g_base, c.g_mask);
-            src = bvh.nodes8 + 5 * (size_t)node;
+            src = bvh.nodes8 + (kWideNodeStride / 4u) * (size_t)node;
         }
         W8_COUNT(2, lane == 0 ? 1 : 0);
         WideNode nd;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_any8_refill(Bvh
             bool           rest;
             const uint32_t node = wide_pick_child(c, w.octinv, rest);
             if (rest) st.push(c.g_base, c.g_mask);
-            src = bvh.nodes8 + 5 * (size_t)node;
+            src = bvh.nodes8 + (kWideNodeStride / 4u) * (size_t)node;
         }
         WideNode nd;
         nd.h0 = nd.h1 = nd.q2 = nd.q3 = nd.q4 = make_float4(0.f, 0.f, 0.f, 0.f);

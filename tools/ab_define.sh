@@ -7,6 +7,6 @@ what=$1; shift
 run() { python bench.py --only $what --steps 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1])['result']; print('  value %.0f  ms %.2f  stages %s' % (d['value'], d['ms_per_step'], {k: round(v, 2) for k, v in (d.get('stage_ms') or d.get('batch_32spp', {}).get('stage_ms', {})).items()}))"; }
 echo "baseline"; run; run
 for def in "$@"; do
-    (cd capsaicin_amd/csrc && make -B kernels.o trace8.o EXTRA="$def" > /dev/null 2>&1 && make EXTRA="$def" > /dev/null 2>&1) || { echo "build failed: $def"; continue; }
+    (cd capsaicin_amd/csrc && make -B kernels.o trace8.o bvh.o context.o EXTRA="$def" > /dev/null 2>&1 && make EXTRA="$def" > /dev/null 2>&1) || { echo "build failed: $def"; continue; }
     echo "$def"; run; run
 done
