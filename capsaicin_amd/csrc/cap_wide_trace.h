@@ -206,14 +206,15 @@ __device__ __forceinline__ bool traverse_any8(const BvhDev& bvh, const Ray& r, u
             src = bvh.nodes8 + (kWideNodeStride / 4u) * (size_t)node;
         }
         WideNode nd;
-        nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2], nd.q3 = src[3];
+        nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2];
         if (tri_lane)
         {
+            // (an occlusion test reads 48 of the record's 64 bytes: the triangle id in the fourth piece is the closest hit's business)
             if (tri_occludes(r, nd.h0, nd.h1, nd.q2)) return true;
         }
         else
         {
-            nd.q4 = src[4];
+            nd.q3 = src[3], nd.q4 = src[4];
             wide_node_test(nd, w, r.tmin, r.tmax, c);
         }
         // nothing due: the next node group off the stack, or done

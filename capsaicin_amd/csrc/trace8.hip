@@ -290,8 +290,8 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_any8_refill(Bvh
         }
         WideNode nd;
         nd.h0 = nd.h1 = nd.q2 = nd.q3 = nd.q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (alive) nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2], nd.q3 = src[3];
-        if (node_lane) nd.q4 = src[4];
+        if (alive) nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2];
+        if (node_lane) nd.q3 = src[3], nd.q4 = src[4];  // (a triangle lane needs 48 of its record's 64 bytes: no id for an occlusion test)
         bool occluded = false;
         if (tri_lane) occluded = tri_occludes(r, nd.h0, nd.h1, nd.q2);
         if (node_lane) wide_node_test(nd, w, r.tmin, r.tmax, c);
