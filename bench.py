@@ -329,7 +329,9 @@ def tree_variant(dev, stream):
     depth 8; the stage split and the rooflines come from one stage-timed 32-spp batch (sub-key batch_32spp)."""
     from capsaicin_amd import capi
     r2, bi2 = make_hall(dev, stream)
-    r2.render(0, TREE_SPP, DEPTH, 0)
+    # warm-up with the batch structure of the timed render (two lanes, 32 frame slots each): a working set that still has to grow
+    # inside the timed region costs a fresh 14-GB hipMalloc per lane, 0.4 s each
+    r2.render(0, 2 * TREE_SPP, DEPTH, 0)
     dt, ts = timed(r2, 0, TREE_FULL_SPP, DEPTH, 0, 1)
     check_guards(ts, "tree_variant")
     dt32, ts32 = timed(r2, 0, TREE_SPP, DEPTH, 0, 2)
@@ -422,7 +424,7 @@ def config5_share(dev, stream):
     spp, depth = 1024, 16
     r = make_cornell(dev, stream, w, h, ext=True, shard=(0, 8))
     fl = capi.RENDER_EXT_MATERIALS
-    r.render(0, 16, depth, fl)
+    r.render(0, 64, depth, fl)  # two whole batches of 32 frame slots: every buffer at its final size before the timed render
     dt, st = timed(r, 0, spp, depth, fl, 1)
     check_guards(st, "config5_share")
     r.close()
