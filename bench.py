@@ -756,6 +756,8 @@ def main():
                    # BASELINE configs[1] reads "Lambert+GGX": that literal configuration is the EXT model's line below (ext_variant);
                    # `value` is the reference's own shading model on the same scene, camera, resolution, spp and depth
                    "value_literal_config": ext.get("value") if isinstance(ext, dict) else None,
+                   # the north star's roofline target is about traversal-bound frames: big_variant's closest-hit kernel (16.8 M triangles)
+                   "north_star_traversal_bound": big.get("north_star") if isinstance(big, dict) else None,
                    "exchange": exchange, "stage_ms_per_rank": stage_ms_per_rank,
                    "roofline": roofline, "ext_variant": ext, "tree_variant": tree, "big_variant": big, "config3_variant": c3,
                    "config5_share": c5, "shard_cost": shard_costs, "post_chain": post_chain}
