@@ -43,6 +43,15 @@ def kernel_source_sha():
     return h.hexdigest()
 
 
+def build_extra():
+    """The EXTRA flags libcapsaicin_hip.so was linked with (capsaicin_amd/build_flags.txt, written by the Makefile): "" for the product
+    build.  tools/ab_define.sh and tools/prof_all.sh leave diagnostic builds behind if they are interrupted before their exit trap."""
+    try:
+        return open(os.path.join(ROOT, "capsaicin_amd", "build_flags.txt")).read().strip().partition("=")[2].strip()
+    except OSError:
+        return ""
+
+
 def committed_counters(key):
     """Per-launch HBM bytes / vector instructions of one kernel from the newest profiles/rNN_traffic.json (PMC passes of this very
     command, tools/make_traffic.py; counters cannot be collected from inside the timed process).  None when the kernel sources
@@ -50,6 +59,8 @@ def committed_counters(key):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
     if not files:
         return None, None
+    if build_extra():
+        return None, "not quoted: diagnostic build (EXTRA=%s)" % build_extra()
     try:
         tj = json.load(open(files[-1]))
         if tj.get("source_sha256") != kernel_source_sha():

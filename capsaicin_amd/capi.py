@@ -41,7 +41,7 @@ class Stats(C.Structure):
                 ("launches_shade", C.c_uint64), ("rays_extension_bounce0", C.c_uint64), ("rays_shadow_bounce0", C.c_uint64),
                 ("guard_shade", C.c_uint64), ("guard_trace_any", C.c_uint64), ("guard_last", C.c_uint64), ("ms_post", C.c_double),
                 ("post_frames", C.c_uint64), ("ms_direct", C.c_double), ("ms_post_pass", C.c_double * 5), ("shadow_entries", C.c_uint64),
-                ("shadow_entries_bounce0", C.c_uint64), ("guard_append", C.c_uint64)]
+                ("shadow_entries_bounce0", C.c_uint64), ("guard_append", C.c_uint64), ("lane1_dropped", C.c_uint64)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n == "ms_post_pass" else getattr(self, n)) for n, _ in self._fields_}
@@ -423,7 +423,7 @@ class Renderer:
         """0 auto, 1 LBVH + LDS stack, 2 exhaustive (small scenes)."""
         _check(lib().cap_set_traversal(self.ctx, mode), "cap_set_traversal")
 
-    DEBUG_QUEUE_CAPACITY_DIV, DEBUG_WIDE_DEPTH_LIMIT, DEBUG_WIDE_IN_USE = 1, 2, 3
+    DEBUG_QUEUE_CAPACITY_DIV, DEBUG_WIDE_DEPTH_LIMIT, DEBUG_WIDE_IN_USE, DEBUG_FAIL_LANE1, DEBUG_LANES_USED = 1, 2, 3, 4, 5
 
     def debug_set(self, key, value):
         _check(lib().cap_debug_set(self.ctx, key, value), "cap_debug_set")

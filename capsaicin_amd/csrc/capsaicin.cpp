@@ -88,6 +88,8 @@ struct World
     ScriptedInput input;
     bool          input_pending = false, angles_valid = false;
     float         yaw = 0.f, pitch = 0.f;
+    float         forward_written[3] = {0.f, 0.f, 0.f};  // the forward axis run_input last wrote: a host that has since rewritten
+                                                        // the basis through GetCamera() invalidates the accumulated angles
     std::string assets_dir;
 };
 
@@ -250,6 +252,7 @@ void InitRenderSession(void* params)
     World& w = world();
     if (!params) error_throw("InitRenderSession: params is null");
     w.session = *static_cast<RenderSessionParams*>(params);
+    w.angles_valid = false;  // a new session starts from the camera as it stands, not from an earlier session's mouse angles
     info("capsaicin::InitRenderSession()");
     const RenderSessionParams& sp = w.session;
     if (!sp.gpus || !sp.shard_count || sp.shard_index >= sp.shard_count) error_throw("InitRenderSession: bad shard description");
@@ -312,6 +315,8 @@ void run_input(World& w)
         // The reference's yaw_ / pitch_ start at 0 with the camera looking down +z (camera_system.cpp:25-33).  A session whose
         // camera was placed through GetCamera() continues from THAT view [not-ref]: the angles whose rotation gives its forward
         // vector, forward = (sin yaw cos pitch, -sin pitch, cos yaw cos pitch) -- see below.
+        if (w.angles_valid && (cd.forward[0] != w.forward_written[0] || cd.forward[1] != w.forward_written[1] || cd.forward[2] != w.forward_written[2]))
+            w.angles_valid = false;  // the host placed the camera itself since the last rotation: continue from its view
         if (!w.angles_valid)
         {
             const float fy = std::fmin(1.f, std::fmax(-1.f, cd.forward[1]));
@@ -332,9 +337,15 @@ void run_input(World& w)
         // right = normalize(-cross(forward, (0, 1, 0))), up = cross(forward, right)  (:140-146)
         float       r[3] = {-(f[1] * 0.f - f[2] * 1.f), -(f[2] * 0.f - f[0] * 0.f), -(f[0] * 1.f - f[1] * 0.f)};
         const float rl   = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-        for (float& x : r) x /= rl;
+        // Looking straight up or down (pitch = +-90 degrees) -cross(forward, (0, 1, 0)) has no length: the reference divides by it and
+        // puts NaNs into the basis (input_system.cpp:140-143).  Here the previous right axis is kept [not-ref], so the basis stays
+        // orthonormal and cap_camera_set never sees a NaN.
+        if (rl > 0.f)
+            for (float& x : r) x /= rl;
+        else
+            for (int k = 0; k < 3; ++k) r[k] = cd.right[k];
         const float u[3] = {f[1] * r[2] - f[2] * r[1], f[2] * r[0] - f[0] * r[2], f[0] * r[1] - f[1] * r[0]};
-        for (int k = 0; k < 3; ++k) cd.forward[k] = f[k], cd.right[k] = r[k], cd.up[k] = u[k];
+        for (int k = 0; k < 3; ++k) cd.forward[k] = f[k], cd.right[k] = r[k], cd.up[k] = u[k], w.forward_written[k] = f[k];
     }
     // HandleKeyboard (:50-108): the movement is summed along the (new) axes, then added to the position
     float movement[3] = {0.f, 0.f, 0.f};

@@ -172,6 +172,11 @@ struct CapContext
     uint64_t      max_batch_paths = 0;
     uint32_t      debug_capacity_div = 1;  // cap_debug_set(CAP_DEBUG_QUEUE_CAPACITY_DIV): tests of the append guard only
     uint32_t      debug_wide_depth_limit = 0;  // cap_debug_set(CAP_DEBUG_WIDE_DEPTH_LIMIT): pretend the wide kernels' stacks end here
+    bool          debug_fail_lane1 = false;    // cap_debug_set(CAP_DEBUG_FAIL_LANE1): the second working set "cannot be allocated"
+    // The smallest second working set (paths = slots x padded pixels) whose allocation has failed since the last call that can free
+    // memory: cap_render does not try that size or a larger one again (every call repeated ~28 GB of hipMalloc / hipFree).
+    uint64_t      lane1_failed_paths = 0;
+    uint32_t      lanes_last_render = 0;       // cap_debug_get(CAP_DEBUG_LANES_USED)
     uint32_t      traversal_mode  = CAP_TRAVERSAL_AUTO;
     uint32_t      bvh_build_mode  = CAP_BVH_BUILD_AUTO;
 
@@ -993,6 +998,7 @@ int cap_set_resolution(CapContext* c, uint32_t width, uint32_t height)
     update_screen(c, width, height, c->screen.shard_index, c->screen.shard_count);
     if ((uint64_t)c->screen.pixels_padded > kPidMask) return fail(CAP_ERR_UNSUPPORTED, "too many pixels per shard");
     c->accum.release();
+    c->lane1_failed_paths = 0;
     c->post_w = c->post_h = 0;  // histories restart at the next cap_post_frame
     c->post_last_dst = -1;
     return CAP_OK;
@@ -1006,6 +1012,7 @@ int cap_set_shard(CapContext* c, uint32_t shard_index, uint32_t shard_count)
     HIP_TRY(hipStreamSynchronize(c->stream));
     update_screen(c, c->screen.width, c->screen.height, shard_index, shard_count);
     c->accum.release();
+    c->lane1_failed_paths = 0;
     return CAP_OK;
 }
 
@@ -1013,6 +1020,7 @@ int cap_set_batch_paths(CapContext* c, uint64_t max_paths)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_batch_paths: ctx is NULL");
     c->max_batch_paths = max_paths;
+    c->lane1_failed_paths = 0;
     return CAP_OK;
 }
 
@@ -1028,6 +1036,10 @@ int cap_debug_set(CapContext* c, uint32_t key, uint64_t value)
     case CAP_DEBUG_WIDE_DEPTH_LIMIT:
         c->debug_wide_depth_limit = (uint32_t)value;
         return CAP_OK;
+    case CAP_DEBUG_FAIL_LANE1:
+        c->debug_fail_lane1 = value != 0;
+        if (!value) c->lane1_failed_paths = 0;  // "memory has been released"
+        return CAP_OK;
     default: return fail(CAP_ERR_INVALID_ARG, "cap_debug_set: unknown key %u", key);
     }
 }
@@ -1039,6 +1051,8 @@ int cap_debug_get(CapContext* c, uint32_t key, uint64_t* value)
     {
     case CAP_DEBUG_QUEUE_CAPACITY_DIV: *value = c->debug_capacity_div; return CAP_OK;
     case CAP_DEBUG_WIDE_DEPTH_LIMIT: *value = c->debug_wide_depth_limit; return CAP_OK;
+    case CAP_DEBUG_FAIL_LANE1: *value = c->debug_fail_lane1 ? 1u : 0u; return CAP_OK;
+    case CAP_DEBUG_LANES_USED: *value = c->lanes_last_render; return CAP_OK;
     case CAP_DEBUG_WIDE_IN_USE:
         if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_debug_get: BVH not built");
         *value = bvh_dev(c).wide8_ok;
@@ -1172,6 +1186,11 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     // render launches what the plain one does -- and run one after the other on lane 0)
     if ((flags & CAP_RENDER_STAGE_TIMERS) || getenv("CAP_TRACE_LAUNCHES")) two_lanes = false;
     if (ensure_wavefront(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
+    if (two_lanes && c->lane1_failed_paths && (uint64_t)slots * Ppad >= c->lane1_failed_paths)
+    {
+        two_lanes = false;  // this size has already failed and nothing has been freed since: one lane, without asking again
+        ++c->stats.lane1_dropped;
+    }
     if (two_lanes)
     {
         if (c->lane1.pl_color.n < (size_t)slots * Ppad || c->lane1.counters.n < c->counters.n)
@@ -1179,15 +1198,19 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             HIP_TRY(hipStreamSynchronize(c->stream));  // growing frees the old buffers
             if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
         }
-        if (ensure_lane1(c, slots, num_bounces) != CAP_OK)
+        if (c->debug_fail_lane1 || ensure_lane1(c, slots, num_bounces) != CAP_OK)
         {
             // the second working set doubles the batch's memory (~28 GB at the default budget): without it the batches of this call
-            // simply run one after the other on lane 0
+            // simply run one after the other on lane 0 -- counted in CapStats::lane1_dropped, and not tried again at this
+            // size until something is freed
             (void)hipGetLastError();
             c->lane1 = CapContext::Lane{};
+            c->lane1_failed_paths = (uint64_t)slots * Ppad;
+            ++c->stats.lane1_dropped;
             two_lanes = false;
         }
     }
+    c->lanes_last_render = two_lanes ? 2u : 1u;
     const uint32_t ring = c->frames_next;
     c->frames_next      = (c->frames_next + 1) % CapContext::kFrameRing;
     if (!c->frames_event[ring]) HIP_TRY(hipEventCreateWithFlags(&c->frames_event[ring], hipEventDisableTiming));

@@ -315,6 +315,15 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_any8_refill(Bvh
     }
 }
 
+// Idle lanes at which a wave refills (A/B switch CAP_W8_REFILL), clamped to 1..64: above 64 the refill condition is never true, no
+// lane ever gets a ray and the persistent loop would spin for ever.
+static uint32_t w8_refill_idle()
+{
+    const char* e = getenv("CAP_W8_REFILL");
+    const long  v = e ? atol(e) : (long)CAP_W8_REFILL;
+    return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v);
+}
+
 void launch_trace_any8_refill(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue& q, uint32_t max_count, float4* target, uint32_t pixels_padded,
                               uint32_t n_slots, uint64_t* guard, uint32_t* work, const FrameConst* frames)
 {
@@ -323,7 +332,7 @@ void launch_trace_any8_refill(const LaunchCfg& cfg, const BvhDev& bvh, const Sha
     if ((uint64_t)cap * kBlock > bvh.spill_threads) cap = bvh.spill_threads / kBlock;  // every thread owns a spill slice
     if (g > cap) g = cap;
     if (g == 0) g = 1;
-    static const uint32_t refill = getenv("CAP_W8_REFILL") ? (uint32_t)atoi(getenv("CAP_W8_REFILL")) : (uint32_t)CAP_W8_REFILL;
+    static const uint32_t refill = w8_refill_idle();
     hipLaunchKernelGGL(k_trace_any8_refill, dim3(g), dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard, work, frames, refill);
 }
 
@@ -366,7 +375,7 @@ void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQue
         hipLaunchKernelGGL(k_trace_closest8_empty, dim3(g), dim3(kBlock), 0, cfg.stream, q, hits);
         return;
     }
-    static const uint32_t refill = getenv("CAP_W8_REFILL") ? (uint32_t)atoi(getenv("CAP_W8_REFILL")) : (uint32_t)CAP_W8_REFILL;
+    static const uint32_t refill = w8_refill_idle();
     hipLaunchKernelGGL(k_trace_closest8, dim3(g), dim3(kBlock), 0, cfg.stream, bvh, q, hits, work, refill);
 }
 }  // namespace cap

@@ -141,6 +141,10 @@ typedef struct CapStats
      * NOT stored -- nothing is written out of bounds -- and their paths are lost; guard_last then holds the two counter values the
      * offending wave saw (extension << 32 | shadow).  cap_debug_set(CAP_DEBUG_QUEUE_CAPACITY_DIV) provokes it for the tests. */
     uint64_t guard_append;
+    /* cap_render calls that wanted two batch lanes (tree path, see cap_render) and ran on one because the second working set could not
+     * be allocated: same image, ~7 % less throughput.  A size that has failed is not tried again until cap_set_resolution /
+     * cap_set_shard / cap_set_batch_paths change what is needed. */
+    uint64_t lane1_dropped;
 } CapStats;
 
 typedef struct CapBvhInfo
@@ -225,7 +229,11 @@ enum
      * bound so that the fallback can be exercised on ordinary scenes; WIDE_IN_USE (read-only) says which kernels the next render
      * takes. */
     CAP_DEBUG_WIDE_DEPTH_LIMIT   = 2,
-    CAP_DEBUG_WIDE_IN_USE        = 3
+    CAP_DEBUG_WIDE_IN_USE        = 3,
+    /* FAIL_LANE1 (0 / 1): the allocation of cap_render's second batch lane fails (what running out of HBM does), so that the one-lane
+     * fallback and CapStats::lane1_dropped can be tested; LANES_USED (read-only): the lanes the last cap_render ran on (1 or 2). */
+    CAP_DEBUG_FAIL_LANE1         = 4,
+    CAP_DEBUG_LANES_USED         = 5
 };
 int cap_debug_set(CapContext* ctx, uint32_t key, uint64_t value);
 int cap_debug_get(CapContext* ctx, uint32_t key, uint64_t* value);
