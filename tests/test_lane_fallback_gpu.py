@@ -21,7 +21,7 @@ def bits(a):
 
 def test_one_lane_fallback_is_bit_identical_and_counted(native_lib, bluenoise):
     import make_sponza_class as gen
-    pos, nrm, uv, idx, meshes, texs = gen.arrays(0.1, 32)
+    pos, nrm, uv, idx, meshes, texs = gen.arrays(0.1, 64)
     w, h, spp, D = 96, 64, 4, 3
     r = capi.Renderer(0)
     r.upload_scene(pos, nrm, uv, idx, meshes)

@@ -11,7 +11,7 @@ python tools/make_traffic.py "$TAG" gpurun_out/w8_counts.json gpurun_out/w8_coun
 python tools/prof_summary.py > "profiles/${TAG}_rocprofv3_summary.txt" 2>&1
 # one table per workload (cornell / ext / tree on one lane / big on one lane): every avg_launch_ms of the bench line can be
 # recomputed from one file
-for wl in cornell ext tree big; do
+for wl in cornell ext tree big config3 config5; do
     f=$(ls -t gpurun_out/prof_${wl}_kt/*/*kernel_stats.csv 2>/dev/null | head -1)
     [ -n "$f" ] && cp "$f" "profiles/${TAG}_kernel_stats_${wl}.csv"
 done

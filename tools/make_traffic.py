@@ -19,7 +19,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 # key -> (workload whose passes are read, kernel name)
 KERNELS = {"headline": ("cornell", "k_trace_shade<false, false, false, true>"), "ext": ("ext", "k_trace_shade<false, true, false, true>"),
            "tree": ("tree", "k_trace_closest8"), "tree_shade": ("tree", "k_shade<"), "tree_any": ("tree", "k_trace_any<"),
-           "big": ("big", "k_trace_closest8"), "big_shade": ("big", "k_shade<"), "big_any": ("big", "k_trace_any<")}
+           "big": ("big", "k_trace_closest8"), "big_shade": ("big", "k_shade<"), "big_any": ("big", "k_trace_any"),
+           "config3": ("config3", "k_trace_shade<false, true, false, true>"), "config5": ("config5", "k_trace_shade<false, true, false, true>")}
+# every kernel of a render step (tree path): bench.py big_variant.step_traffic = the FRAME's measured bytes, not one kernel's
+STEP_KERNELS = ("k_trace_closest8", "k_trace_any", "k_shade<", "k_raygen_identity", "k_resolve", "k_primary_shade", "k_trace_primary")
 
 
 def listed_passes():
@@ -66,6 +69,13 @@ for key, (wl, name) in KERNELS.items():
     if n3:
         k["valu_insts_per_launch"] = valu / n3
     out["kernels"][key] = k
+for wl in ("big", "tree"):
+    fetch = sum(total("prof_%s_pmc_FETCH_SIZE" % wl, "FETCH_SIZE", k)[0] for k in STEP_KERNELS)
+    write = sum(total("prof_%s_pmc_WRITE_SIZE" % wl, "WRITE_SIZE", k)[0] for k in STEP_KERNELS)
+    n = total("prof_%s_pmc_FETCH_SIZE" % wl, "FETCH_SIZE", "k_trace_closest8")[1]
+    if n:
+        out["kernels"][wl + "_step"] = {"workload": wl, "kernels": list(STEP_KERNELS), "closest8_dispatches": n, "FETCH_SIZE_KB_sum": fetch,
+                                        "WRITE_SIZE_KB_sum": write, "bytes_per_closest_dispatch": (2.0 * fetch + write) * 1024.0 / n}
 for key, arg in (("tree", 2), ("big", 3)):
     if len(sys.argv) <= arg or key not in out["kernels"] or not os.path.exists(sys.argv[arg]):
         continue
