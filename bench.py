@@ -532,6 +532,7 @@ def realtime_frame_variant(dev, stream):
         r.post_reset()
 
         def frame(f):
+            r.set_prev_camera(cam)  # static camera: the previous frame's is this one (raytracing_system.cpp:268-276)
             r.render(f, 1, 1, fl)
             r.post_frame(ps, f, cam)
 

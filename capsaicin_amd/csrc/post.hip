@@ -222,8 +222,8 @@ __global__ __launch_bounds__(kBlock) void k_untile_decode(ScreenDev sc, const fl
     }
 }
 
-// spatial_gather.hlsl:28-109.  nd = decoded (normal.xyz, depth) image of k_decode_normals.
-// UP (UPSCALE2X, :36-46, :83-87): the grid and `color` are half resolution and the G-buffer is read at (xy << 1) + (ox, oy).
+// spatial_gather.hlsl:28-109 in its UPSCALE2X form (the full-resolution form is k_stencil_lds<kGather> below).  nd = decoded
+// (normal.xyz, depth) image.  UP (UPSCALE2X, :36-46, :83-87): the grid and `color` are half resolution and the G-buffer is read at (xy << 1) + (ox, oy).
 // The taps are bounded by the FULL window size, as the host passes it (raytracing_system.cpp:1562-1569): a tap beyond the
 // half-resolution image reads a G-buffer texel outside the window, i.e. depth 0, and is skipped as background.
 template <bool UP, bool FAST = false>
@@ -353,249 +353,171 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32
 
 __device__ __forceinline__ v3 remove_fireflies(float4 v) { return mk3(fminf(v.x, 10.0f), fminf(v.y, 10.0f), fminf(v.z, 10.0f)); }
 
-// eaw_blur.hlsl:142-223.  USE_VAR = the USE_VARIANCE define (:162-165): without it the pass-through pixels carry variance 0.
-template <bool USE_VAR, bool FAST>
-__global__ __launch_bounds__(kBlock) void k_blur_disocclusion(PostSettingsDev s, Img color, Img nd, Img moments, float4* out)
-{
-    uint32_t x, y;
-    if (!pixel_of_thread(color.w, color.h, x, y)) return;
-    const float  hist = ld(moments, x, y).w;
-    const float4 cg   = ld(nd, x, y);
-    const v3     cn   = xyz(cg);
-    const float  cd   = cg.w;
-    const float4 cv   = ld(color, x, y);
-    const v3     cc   = remove_fireflies(cv);
-    float4       res  = make_float4(cc.x, cc.y, cc.z, USE_VAR ? cv.w : 0.0f);
-    if (!(cd < 1e-5f || hist >= 8.0f))
-    {
-        const float s_depth = cd * s.eaw_depth_sigma, s_normal = s.eaw_normal_sigma, s_luma = s.eaw_luma_sigma;
-        const float f_depth = FAST ? fast_neg_inv(s_depth) : 0.f, f_luma = FAST ? fast_neg_inv(s_luma) : 0.f, lcc = luminance(cc);
-        v3          filtered = mk3(0.f, 0.f, 0.f);
-        float       fm0 = 0.0f, fm1 = 0.0f, total = 0.0f;
-        for (int dy = -3; dy <= 3; ++dy)
-            for (int dx = -3; dx <= 3; ++dx)
-            {
-                const int sx = (int)x + dx, sy = (int)y + dy;
-                if (sx < 0 || sy < 0 || sx >= (int)color.w || sy >= (int)color.h) continue;
-                const v3     c = remove_fireflies(ldi(color, sx, sy));
-                const float4 g = ldi(nd, sx, sy);
-                const float4 m = ldi(moments, sx, sy);
-                if (g.w < 1e-5f) continue;
-                const v3    n   = xyz(g);
-                float       wgt;
-                if (FAST)
-                    wgt = fast_normal_weight(cn, n, s_normal) * fast_exp_weight(cd, g.w, f_depth * kInv7.v[dy + 3][dx + 3]) * fast_exp_weight(lcc, luminance(c), f_luma);
-                else
-                    wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * kLen7.v[dy + 3][dx + 3]) * luma_weight(lcc, luminance(c), s_luma);
-                filtered = filtered + c * wgt;
-                fm0 += wgt * m.x, fm1 += wgt * m.y;
-                total += wgt;
-            }
-        const float rt = FAST ? fast_rcp(total) : 0.f;
-        const v3    r  = (total < kEpsPost) ? cc : (FAST ? filtered * rt : div3(filtered, total));
-        const float m0 = (total < kEpsPost) ? 0.0f : (FAST ? fm0 * rt : fm0 / total), m1 = (total < kEpsPost) ? 0.0f : (FAST ? fm1 * rt : fm1 / total);
-        const float boost = FAST ? 8.0f * fast_rcp(hist) : 8.0f / hist;
-        res = make_float4(r.x, r.y, r.z, boost * fabsf(m1 - m0 * m0));
-    }
-    out[(size_t)y * color.w + x] = res;
-}
-
-// eaw_blur.hlsl:48-137.  USE_VAR = the USE_VARIANCE define (:68, :114, :127).  COMBINE: the chain's last a-trous pass also does
-// CombineIllumination (combine_illumination.hlsl:16-30, type 0) on its result -- the operations of k_combine on the same
-// operands, so the same bits, and the blurred image is neither written nor read back in between.
-template <bool USE_VAR, bool FAST, bool COMBINE>
-__global__ __launch_bounds__(kBlock) void k_blur(PostSettingsDev s, uint32_t stride, Img color, Img nd, float4* out, const float4* albedo,
-                                                 const float4* direct, uint32_t aux_tiles_x)
-{
-    uint32_t x, y;
-    if (!pixel_of_thread(color.w, color.h, x, y)) return;
-    const float4 cg   = ld(nd, x, y);
-    const v3     cn   = xyz(cg);
-    const float  cd   = cg.w;
-    const float4 cv   = ld(color, x, y);
-    const v3     cc   = remove_fireflies(cv);
-    const float  cvar = USE_VAR ? cv.w : 0.0f;
-    float4       res  = make_float4(cc.x, cc.y, cc.z, cvar);
-    if (!(cd < 1e-5f))
-    {
-        const float kw[3]   = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
-        const float s_depth = cd * (float)stride * s.eaw_depth_sigma, s_normal = s.eaw_normal_sigma;
-        const float s_luma  = s.eaw_luma_sigma * sqrtf(fmaxf(0.0f, cvar + kEpsPost));
-        const float f_depth = FAST ? fast_neg_inv(s_depth) : 0.f, f_luma = FAST ? fast_neg_inv(s_luma) : 0.f, lcc = luminance(cc);
-        v3          filtered = mk3(0.f, 0.f, 0.f);
-        float       fvar = 0.0f, total = 0.0f;
-#pragma unroll
-        for (int dy = -2; dy <= 2; ++dy)
-#pragma unroll
-            for (int dx = -2; dx <= 2; ++dx)
-            {
-                const int sx = (int)x + dx * (int)stride, sy = (int)y + dy * (int)stride;
-                if (sx < 0 || sy < 0 || sx >= (int)color.w || sy >= (int)color.h) continue;
-                const float4 v = ldi(color, sx, sy);
-                const v3     c = remove_fireflies(v);
-                const float4 g = ldi(nd, sx, sy);
-                if (g.w < 1e-5f) continue;
-                const v3    n   = xyz(g);
-                float       lw = 1.0f, hw = 1.0f, wgt;
-                if (USE_VAR)
-                {
-                    lw = FAST ? fast_exp_weight(lcc, luminance(c), f_luma) : luma_weight(lcc, luminance(c), s_luma);
-                    hw = kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy];
-                }
-                if (FAST)
-                    wgt = fast_normal_weight(cn, n, s_normal) * fast_exp_weight(cd, g.w, f_depth * kInv7.v[dy + 3][dx + 3]);
-                else
-                    wgt = normal_weight(cn, n, s_normal) * depth_weight(cd, g.w, s_depth * sqrtf((float)(dx * dx + dy * dy)));
-                const float k   = wgt * hw * lw;
-                filtered = filtered + c * k;
-                total += k;
-                if (USE_VAR) fvar += hw * hw * wgt * wgt * lw * lw * v.w;
-            }
-        const float rt = FAST ? fast_rcp(total) : 0.f;
-        const v3    r  = (total < kEpsPost) ? cc : (FAST ? filtered * rt : div3(filtered, total));
-        const float rv = (total < kEpsPost) ? cvar : (FAST ? fvar * (rt * rt) : fvar / (total * total));
-        res = make_float4(r.x, r.y, r.z, rv);
-    }
-    const size_t o = (size_t)y * color.w + x;
-    if (COMBINE)
-    {
-        const size_t oa = aux_index(x, y, color.w, aux_tiles_x);
-        const float4 a = albedo[oa], d = direct[oa];
-        res = make_float4(res.x * a.x + d.x, res.y * a.y + d.y, res.z * a.z + d.z, 1.0f * a.w + d.w);
-    }
-    out[o] = res;
-}
-
 // ------------------------------------------------------------------------------------------------
-// CapPostSettings::fast_weights: the three 7x7 / 5x5 stencils restructured for the toleranced mode.  With the weights at ~12
-// instructions the per-pixel kernels above are no longer bound by arithmetic but by their control flow (two skip branches per tap,
-// each followed by dependent loads: 90 us per a-trous pass against 143 exact, where the instruction count fell 2.7 x) and by the
-// CU's 64 B/clk load path (50 x 16 B per pixel).  So:
-//   * no branches in the tap loop: a tap outside the image or on the background gets weight 0 by a select;
-//   * stride 1 (Gather, BlurDisocclusion, the first a-trous pass): the workgroup's 32 x 8 pixels + halo are staged once in LDS --
-//     (colour | variance) and (normal | depth) as two float4 tiles, texels outside the image stored as background -- and the taps
-//     are ds_read_b128 at compile-time offsets;
-//   * strides 3 / 5 / 7: the same loop on global loads with clamped coordinates (all in bounds, so the compiler batches them).
-// Same formulas as the exact kernels, other evaluation order nowhere: only the weights' arithmetic differs.
+// The three stencil filters -- Gather (spatial_gather.hlsl:28-109, 7 x 7), BlurDisocclusion (eaw_blur.hlsl:142-223, 7 x 7) and the
+// a-trous Blur passes (eaw_blur.hlsl:48-137, 5 x 5 at strides 1, 3, 5, 7) -- as LDS-tiled kernels, in BOTH weight modes (round 5;
+// until round 4 the exact mode read every tap from global memory behind two skip branches).
+//   * A workgroup stages its footprint once -- (colour | variance) and (decoded normal | depth) as two float4 tiles -- and the taps
+//     are ds_read_b128 at compile-time offsets; the XCD-aware tile order keeps neighbouring tiles' halos in one L2.
+//   * No branches in the tap loop.  A tap outside the image or on the background gets weight 0 by a select, and its texel is staged
+//     with colour 0 (and moments 0): the skipped tap of the reference then adds c * 0 = +0 to sums of non-negative terms, which
+//     leaves every sum's bits as they are -- so the exact mode stays bit-identical to the oracle's `continue` (tests/test_post_gpu.py).
+//   * Exact mode (FAST = false): the three weights in the contract's arithmetic, multiplied in the reference's order.
+//     fast_weights (FAST = true): the product of the three weights as ONE exponential, 2^(s_n log2(n.n') - |d - d'| / s_d - |l - l'| / s_l)
+//     -- one v_log_f32 and one v_exp_f32 per tap -- and v_rcp_f32 for the final divisions; toleranced (header, tests).
+//   * Strides 3 / 5 / 7: a pixel's 25 taps all lie in rows congruent to its own modulo the stride, so a workgroup takes 8 rows of ONE
+//     row phase (y = phase + stride * j) and 64 contiguous columns: a footprint of (64 + 4 stride) x 12 texels = 29 / 32 / 35 KB of LDS
+//     -- four 512-thread workgroups per CU, staging and arithmetic of different workgroups overlap -- where round 3's square 64 x 16 tile
+//     with its 2-stride halo on every side took 68 / 97 / 129.5 KB and ran one workgroup per CU at strides 5 and 7 (2.2 staged texels
+//     per pixel instead of 4.0 at stride 7).
 // ------------------------------------------------------------------------------------------------
-// XCD-aware workgroup -> tile mapping for the tiled kernels.  Workgroups are dealt round-robin to the eight XCDs, so with the plain
-// row-major mapping horizontally adjacent tiles -- whose halos overlap -- sit on different XCDs and every XCD's L2 fetches its own
-// copy of the shared texels.  Here XCD k (workgroup id mod 8) takes the k-th eighth of the tiles in row-major order: a band of
-// adjacent tile rows, whose halos meet in one L2.  (Speed only: the mapping is a bijection whatever the placement.)
-// The grid has 8 * ceil(tiles / 8) workgroups (xcd_grid); the few whose tile index falls off the end leave at once (returns false).
-__device__ __forceinline__ bool xcd_tile(uint32_t tiles_x, uint32_t tiles_y, uint32_t& bx, uint32_t& by)
+// XCD-aware workgroup -> tile mapping.  Workgroups are dealt round-robin to the eight XCDs, so with the plain row-major mapping
+// horizontally adjacent tiles -- whose halos overlap -- sit on different XCDs and every XCD's L2 fetches its own copy of the shared
+// texels.  Here XCD k (workgroup id mod 8) takes the k-th eighth of the tiles in linear order: a band of adjacent tile rows, whose
+// halos meet in one L2.  (Speed only: the mapping is a bijection whatever the placement.)  The grid has 8 * ceil(tiles / 8)
+// workgroups (xcd_grid); the few whose tile index falls off the end leave at once (returns false).
+__device__ __forceinline__ bool xcd_tile_index(uint32_t n, uint32_t& t)
 {
-    const uint32_t n = tiles_x * tiles_y, per = (n + 7u) / 8u, id = blockIdx.x;
-    const uint32_t t = (id % 8u) * per + id / 8u;
-    by = t / tiles_x, bx = t - by * tiles_x;
+    const uint32_t per = (n + 7u) / 8u, id = blockIdx.x;
+    t = (id % 8u) * per + id / 8u;
     return t < n;
 }
-inline uint32_t xcd_grid(uint32_t tiles_x, uint32_t tiles_y) { return 8u * ((tiles_x * tiles_y + 7u) / 8u); }
-
-enum FastKind
+__device__ __forceinline__ bool xcd_tile(uint32_t tiles_x, uint32_t tiles_y, uint32_t& bx, uint32_t& by)
 {
-    kFastGather = 0,
-    kFastDisocclusion,
-    kFastBlur
-};
+    uint32_t t;
+    if (!xcd_tile_index(tiles_x * tiles_y, t)) return false;
+    by = t / tiles_x, bx = t - by * tiles_x;
+    return true;
+}
+inline uint32_t xcd_grid(uint32_t tiles) { return 8u * ((tiles + 7u) / 8u); }
 
-struct FastCenter
+// kernel_weights[abs(d)] of eaw_blur.hlsl:50: {1, 2/3, 1/6} (selects, so that a loop index that is not unrolled stays a scalar)
+__device__ __forceinline__ float atrous_kernel(int d)
 {
-    v3    cn, cc;
-    float cd, lcc, f_depth, f_luma, s_normal;
-};
-
-// weight of one tap (0 when it does not take part); hw = the a-trous kernel weight where the pass has one
-// The product of the three weights as ONE exponential: 2^(s_n log2(n.n') - |d - d'| / s_d - |l - l'| / s_l) -- one v_log_f32 and one
-// v_exp_f32 per tap (quarter rate: a transcendental costs four plain instructions) instead of one and three.  log2(0) = -inf
-// carries a normal weight of 0 through the sum.
-template <bool LUMA>
-__device__ __forceinline__ float fast_tap_weight(const FastCenter& k, float4 g, v3 c, float inv_len, bool inside)
-{
-    float e = k.s_normal * __builtin_amdgcn_logf(fmaxf(dot3(k.cn, xyz(g)), 0.0f));
-    e       = fmaf(fabsf(k.cd - g.w), k.f_depth * inv_len, e);
-    if (LUMA) e = fmaf(fabsf(k.lcc - luminance(c)), k.f_luma, e);
-    const float w = __builtin_amdgcn_exp2f(e);
-    return (inside && !(g.w < 1e-5f)) ? w : 0.0f;
+    d = d < 0 ? -d : d;
+    return d == 0 ? 1.0f : (d == 1 ? 2.0f / 3.0f : 1.0f / 6.0f);
 }
 
-template <int KIND, int R, bool USE_VAR, bool COMBINE>
-__global__ __launch_bounds__(kBlock) void k_stencil_fast_lds(PostSettingsDev s, Img color, Img nd, Img moments, float4* out, const float4* albedo,
-                                                             const float4* direct)
+enum StencilKind
+{
+    kGather = 0,
+    kDisocclusion,
+    kBlur
+};
+
+struct TapCenter
+{
+    v3    cn, cc;
+    float cd, lcc;
+    float s_normal, s_depth, s_luma;  // exact mode: the sigmas as the reference forms them
+    float f_depth, f_luma;            // fast mode: -log2(e) / sigma (0 where the reference's sigma is 0: weight 1)
+};
+
+// Weights of one tap.  Exact: wgt = normal * depth (the reference's first two factors, in its order) and lw = the luminance weight
+// (1 when the pass has none).  Fast: wgt = the whole product from one exponential, lw = 1.
+// len / inv_len: length(float2(dx, dy)) of the tap and its reciprocal (0 for the centre: the reference's sigma * 0 gives weight 1).
+template <bool FAST, bool LUMA>
+__device__ __forceinline__ void tap_weights(const TapCenter& k, float4 g, v3 c, float len, float inv_len, float& wgt, float& lw)
+{
+    if (FAST)
+    {
+        float e = k.s_normal * __builtin_amdgcn_logf(fmaxf(dot3(k.cn, xyz(g)), 0.0f));  // log2(0) = -inf carries a normal weight of 0
+        e       = fmaf(fabsf(k.cd - g.w), k.f_depth * inv_len, e);
+        if (LUMA) e = fmaf(fabsf(k.lcc - luminance(c)), k.f_luma, e);
+        wgt = __builtin_amdgcn_exp2f(e), lw = 1.0f;
+    }
+    else
+    {
+        wgt = normal_weight(k.cn, xyz(g), k.s_normal) * depth_weight(k.cd, g.w, k.s_depth * len);
+        lw  = LUMA ? luma_weight(k.lcc, luminance(c), k.s_luma) : 1.0f;
+    }
+}
+
+// One texel of a stencil footprint for the LDS tiles: outside the image -> depth 0 (= background, never taken) and colour 0; a
+// background texel inside the image keeps its (normal | depth) and gets colour 0 -- a tap of weight 0 still multiplies what it
+// reads, so EVERY plane of an entry that can be a skipped tap is a defined, finite 0.
+template <bool CLAMP, bool MOMENTS>
+__device__ __forceinline__ void stage_texel(const Img& color, const Img& nd, const Img& moments, int sx, int sy, float4& c, float4& g, float2& mm)
+{
+    const bool   in = sx >= 0 && sy >= 0 && sx < (int)color.w && sy < (int)color.h;
+    const size_t o  = in ? (size_t)sy * color.w + sx : 0;  // (clamped address: the loads are unconditional, their values selected)
+    const float4 gv = nd.p[o], v = color.p[o];
+    float        m0 = 0.f, m1 = 0.f;
+    if (MOMENTS)
+    {
+        const float4 t = moments.p[o];
+        m0 = t.x, m1 = t.y;
+    }
+    const bool take = in && !(gv.w < 1e-5f);
+    const float cx = CLAMP ? fminf(v.x, 10.0f) : v.x, cy = CLAMP ? fminf(v.y, 10.0f) : v.y, cz = CLAMP ? fminf(v.z, 10.0f) : v.z;  // remove_fireflies
+    c  = make_float4(take ? cx : 0.f, take ? cy : 0.f, take ? cz : 0.f, take ? v.w : 0.f);
+    g  = make_float4(in ? gv.x : 0.f, in ? gv.y : 0.f, in ? gv.z : 0.f, in ? gv.w : 0.f);
+    mm = make_float2(take ? m0 : 0.f, take ? m1 : 0.f);
+}
+
+// Stride-1 stencils on a 32 x 8 pixel tile + halo R: Gather (R = 3), BlurDisocclusion (R = 3), the first a-trous pass (R = 2).
+// USE_VAR = the USE_VARIANCE define of eaw_blur.hlsl (:68, :114, :127, :162-165).
+template <int KIND, int R, bool USE_VAR, bool FAST>
+__global__ __launch_bounds__(kBlock) void k_stencil_lds(PostSettingsDev s, Img color, Img nd, Img moments, float4* out)
 {
     constexpr int TW = 32 + 2 * R, TH = 8 + 2 * R;
     __shared__ float4 t_col[TW * TH], t_nd[TW * TH];
-    __shared__ float2 t_mom[KIND == kFastDisocclusion ? TW * TH : 1];
-    const int W = (int)color.w, H = (int)color.h;
+    __shared__ float2 t_mom[KIND == kDisocclusion ? TW * TH : 1];
+    const int W = (int)color.w;
     uint32_t  bx, by;
     if (!xcd_tile((color.w + 31u) / 32u, (color.h + 7u) / 8u, bx, by)) return;  // workgroup-uniform
     const int      x0 = (int)(bx * 32u) - R, y0 = (int)(by * 8u) - R;
     const uint32_t x = bx * 32u + (threadIdx.x & 31u), y = by * 8u + (threadIdx.x >> 5);
     const bool     in_image = x < color.w && y < color.h;
+    const size_t   o        = (size_t)y * W + x;
+    // the centre pixel comes from global memory: a background centre passes its own colour through, which the tile does not hold
+    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f), cg = cv;
+    float  hist = 0.0f;
+    if (in_image)
+    {
+        cv = color.p[o], cg = nd.p[o];
+        if (KIND == kDisocclusion) hist = moments.p[o].w;
+    }
+    const bool pass = cg.w < 1e-5f || (KIND == kDisocclusion && hist >= 8.0f);
     // BlurDisocclusion passes most pixels through once the history is eight frames long: a workgroup of such pixels stages nothing
     bool needs_taps = true;
-    if (KIND == kFastDisocclusion)
-    {
-        const bool mine = in_image && !(ld(nd, x, y).w < 1e-5f || ld(moments, x, y).w >= 8.0f);
-        needs_taps      = __syncthreads_or(mine ? 1 : 0) != 0;
-    }
+    if (KIND == kDisocclusion) needs_taps = __syncthreads_or((in_image && !pass) ? 1 : 0) != 0;
     if (needs_taps)
     {
         for (int e = (int)threadIdx.x; e < TW * TH; e += (int)kBlock)
         {
-            const int  sx = x0 + e % TW, sy = y0 + e / TW;
-            const bool in = sx >= 0 && sy >= 0 && sx < W && sy < H;
-            float4     c = make_float4(0.f, 0.f, 0.f, 0.f), g = c;
-            float2     mm = make_float2(0.f, 0.f);
-            if (in)
-            {
-                const size_t o = (size_t)sy * W + sx;
-                c = color.p[o], g = nd.p[o];
-                if (KIND != kFastGather) c = make_float4(fminf(c.x, 10.0f), fminf(c.y, 10.0f), fminf(c.z, 10.0f), c.w);  // remove_fireflies
-                if (KIND == kFastDisocclusion)
-                {
-                    const float4 m = moments.p[o];
-                    mm             = make_float2(m.x, m.y);
-                }
-            }
-            // outside the image: depth 0 = background, skipped by the taps like the exact kernels' bounds test -- EVERY plane of the
-            // entry is defined: a tap of weight 0 still multiplies what it reads (0 x a stale NaN left in LDS by another kernel
-            // poisoned the border's moments when this entry kept whatever the LDS held)
+            float4 c, g;
+            float2 mm;
+            stage_texel<KIND != kGather, KIND == kDisocclusion>(color, nd, moments, x0 + e % TW, y0 + e / TW, c, g, mm);
             t_col[e] = c, t_nd[e] = g;
-            if (KIND == kFastDisocclusion) t_mom[e] = mm;
+            if (KIND == kDisocclusion) t_mom[e] = mm;
         }
         __syncthreads();
     }
     if (!in_image) return;
-    const size_t o  = (size_t)y * W + x;
-    const int    lc = ((int)(threadIdx.x >> 5) + R) * TW + (int)(threadIdx.x & 31u) + R;
-    float4       cv, cg;
-    if (needs_taps)
-        cv = t_col[lc], cg = t_nd[lc];
-    else
-    {
-        cv = color.p[o], cg = nd.p[o];
-        cv = make_float4(fminf(cv.x, 10.0f), fminf(cv.y, 10.0f), fminf(cv.z, 10.0f), cv.w);
-    }
-    FastCenter k;
-    k.cn = xyz(cg), k.cd = cg.w, k.cc = xyz(cv), k.lcc = luminance(k.cc);
-    const float cvar = (KIND == kFastGather) ? 0.0f : (USE_VAR ? cv.w : 0.0f);
+    TapCenter k;
+    k.cn = xyz(cg), k.cd = cg.w;
+    k.cc = KIND == kGather ? xyz(cv) : remove_fireflies(cv), k.lcc = luminance(k.cc);
+    const float cvar = (KIND == kGather) ? 0.0f : (USE_VAR ? cv.w : 0.0f);
     float4      res  = make_float4(k.cc.x, k.cc.y, k.cc.z, cvar);
-    const float hist = KIND == kFastDisocclusion ? ld(moments, x, y).w : 0.0f;
-    const bool  pass = k.cd < 1e-5f || (KIND == kFastDisocclusion && hist >= 8.0f);
-    if (KIND == kFastGather) res.w = pass ? 0.0f : 1.0f;
+    if (KIND == kGather) res.w = pass ? 0.0f : 1.0f;
     if (!pass)
     {
-        const float sd = KIND == kFastGather ? s.gather_depth_sigma : s.eaw_depth_sigma;
-        float       sl = KIND == kFastGather ? s.gather_luma_sigma : s.eaw_luma_sigma;
-        if (KIND == kFastBlur) sl *= sqrtf(fmaxf(0.0f, cvar + kEpsPost));
-        k.s_normal = KIND == kFastGather ? s.gather_normal_sigma : s.eaw_normal_sigma;
-        k.f_depth = fast_neg_inv(k.cd * sd), k.f_luma = fast_neg_inv(sl);
-        constexpr bool LUMA = KIND != kFastBlur || USE_VAR;
-        const float    kw[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
+        const float sd = KIND == kGather ? s.gather_depth_sigma : s.eaw_depth_sigma;
+        float       sl = KIND == kGather ? s.gather_luma_sigma : s.eaw_luma_sigma;
+        if (KIND == kBlur) sl = sl * sqrtf(fmaxf(0.0f, cvar + kEpsPost));
+        k.s_normal = KIND == kGather ? s.gather_normal_sigma : s.eaw_normal_sigma;
+        k.s_depth = k.cd * sd, k.s_luma = sl;  // (the stride-1 a-trous pass: cd * (float)1 * sigma = cd * sigma)
+        k.f_depth = FAST ? fast_neg_inv(k.s_depth) : 0.f, k.f_luma = FAST ? fast_neg_inv(sl) : 0.f;
+        constexpr bool LUMA = KIND != kBlur || USE_VAR;
         v3             filtered = mk3(0.f, 0.f, 0.f);
         float          total = 0.0f, a0 = 0.0f, a1 = 0.0f;  // a0: variance sum (Blur) or first moment (Disocclusion); a1: second moment
-#pragma unroll
+        const int      lc = ((int)(threadIdx.x >> 5) + R) * TW + (int)(threadIdx.x & 31u) + R;
+        // fast mode: fully unrolled (offsets, tap lengths and kernel weights fold into immediates; ~25 instructions per tap).  Exact
+        // mode: one row of taps per iteration -- at ~150 instructions per tap a fully unrolled 7 x 7 body would be 50 KB of code that
+        // every wave streams through once, against a 64-KB instruction cache shared by two CUs
+        constexpr int UNROLL_Y = FAST ? 2 * R + 1 : 1;
+#pragma unroll UNROLL_Y
         for (int dy = -R; dy <= R; ++dy)
 #pragma unroll
             for (int dx = -R; dx <= R; ++dx)
@@ -603,212 +525,115 @@ __global__ __launch_bounds__(kBlock) void k_stencil_fast_lds(PostSettingsDev s, 
                 const int    e = lc + dy * TW + dx;
                 const float4 v = t_col[e], g = t_nd[e];
                 const v3     c = xyz(v);
-                const float  w = fast_tap_weight<LUMA>(k, g, c, kInv7.v[dy + 3][dx + 3], true);
-                const float  hw = (KIND == kFastBlur && USE_VAR) ? kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy] : 1.0f;
-                const float  kk = w * hw;
-                filtered = filtered + c * kk;
-                total += kk;
-                if (KIND == kFastBlur && USE_VAR) a0 += (kk * kk) * v.w;
-                if (KIND == kFastDisocclusion)
+                float        wgt, lw;
+                tap_weights<FAST, LUMA>(k, g, c, kLen7.v[dy + 3][dx + 3], kInv7.v[dy + 3][dx + 3], wgt, lw);
+                wgt = (g.w < 1e-5f) ? 0.0f : wgt;
+                if (KIND == kBlur)
                 {
-                    const float2 m = t_mom[e];
-                    a0 += w * m.x, a1 += w * m.y;
+                    const float hw = USE_VAR ? atrous_kernel(dx) * atrous_kernel(dy) : 1.0f;
+                    const float kk = FAST ? wgt * hw : wgt * hw * lw;
+                    filtered = filtered + c * kk;
+                    total += kk;
+                    if (USE_VAR) a0 += FAST ? (kk * kk) * v.w : hw * hw * wgt * wgt * lw * lw * v.w;
+                }
+                else
+                {
+                    const float w = FAST ? wgt : wgt * lw;
+                    filtered = filtered + c * w;
+                    total += w;
+                    if (KIND == kDisocclusion)
+                    {
+                        const float2 m = t_mom[e];
+                        a0 += w * m.x, a1 += w * m.y;
+                    }
                 }
             }
         const bool  empty = total < kEpsPost;
-        const float rt    = fast_rcp(total);
-        const v3    r     = empty ? k.cc : filtered * rt;
+        const float rt    = FAST ? fast_rcp(total) : 0.f;
+        const v3    r     = empty ? k.cc : (FAST ? filtered * rt : div3(filtered, total));
         float       rw    = res.w;
-        if (KIND == kFastBlur) rw = empty ? cvar : a0 * (rt * rt);
-        if (KIND == kFastDisocclusion)
+        if (KIND == kBlur) rw = empty ? cvar : (FAST ? a0 * (rt * rt) : a0 / (total * total));
+        if (KIND == kDisocclusion)
         {
-            const float m0 = empty ? 0.0f : a0 * rt, m1 = empty ? 0.0f : a1 * rt;
-            rw             = (8.0f * fast_rcp(hist)) * fabsf(m1 - m0 * m0);
+            const float m0 = empty ? 0.0f : (FAST ? a0 * rt : a0 / total), m1 = empty ? 0.0f : (FAST ? a1 * rt : a1 / total);
+            const float boost = FAST ? 8.0f * fast_rcp(hist) : 8.0f / hist;
+            rw                = boost * fabsf(m1 - m0 * m0);
         }
         res = make_float4(r.x, r.y, r.z, rw);
-    }
-    if (COMBINE)
-    {
-        const float4 a = albedo[o], d = direct[o];
-        res = make_float4(res.x * a.x + d.x, res.y * a.y + d.y, res.z * a.z + d.z, 1.0f * a.w + d.w);
     }
     out[o] = res;
 }
 
-// The a-trous passes of stride 3, 5, 7 from an LDS tile.  From global memory (k_blur_fast_strided below, kept as the fallback
-// for images narrower than a tile) these passes sit at 74 us whatever is done to their instruction stream: a 32 x 8 workgroup's 25
-// taps span (32 + 4 s) x (8 + 4 s) texels, more than the CU's 32-KB L1 holds beside its neighbours', so the 800 B per pixel come
-// from L2 (22 TB/s achieved).  A 64 x 16 workgroup stages that footprint once -- 4.0 texels per pixel at stride 7 instead of 25,
-// 129 KB of the CU's 160 KB of LDS -- and its taps are ds_read_b128.
-constexpr int kFastTileW = 64, kFastTileH = 16;
-// (STRIDE is a template parameter so that the tile is a static array: 68, 97 and 129.5 KB for strides 3, 5, 7 -- no dynamic-LDS
-// attribute to set before the launch)
-template <int STRIDE, bool USE_VAR, bool COMBINE>
-__global__ __launch_bounds__(kFastTileW * kFastTileH) void k_blur_fast_tile(PostSettingsDev s, Img color, Img nd, float4* out, const float4* albedo,
-                                                                            const float4* direct, uint32_t aux_tiles_x)
+// The a-trous passes of stride 3, 5, 7: 64 columns x 8 rows of one row phase per 512-thread workgroup (see the block comment above).
+// COMBINE: the chain's last a-trous pass also does CombineIllumination (combine_illumination.hlsl:16-30, type 0) on its result --
+// the operations of k_combine on the same operands, so the same bits, and the blurred image is neither written nor read back.
+constexpr int kPhaseW = 64, kPhaseH = 8;
+inline uint32_t phase_tiles_per_phase(uint32_t h, uint32_t stride) { return ((h + stride - 1) / stride + kPhaseH - 1) / kPhaseH; }
+template <int STRIDE, bool USE_VAR, bool FAST, bool COMBINE>
+__global__ __launch_bounds__(kPhaseW * kPhaseH) void k_blur_phase(PostSettingsDev s, Img color, Img nd, float4* out, const float4* albedo,
+                                                                    const float4* direct, uint32_t aux_tiles_x, uint32_t tiles_x, uint32_t tiles_per_phase)
 {
-    constexpr int stride = STRIDE, halo = 2 * STRIDE;
-    constexpr int TW = kFastTileW + 2 * halo, TH = kFastTileH + 2 * halo;
+    constexpr int HX = 2 * STRIDE, TW = kPhaseW + 2 * HX, TH = kPhaseH + 4;
     __shared__ float4 t_col[TW * TH], t_nd[TW * TH];
     const int W = (int)color.w, H = (int)color.h;
-    uint32_t  bx, by;
-    if (!xcd_tile((color.w + kFastTileW - 1) / kFastTileW, (color.h + kFastTileH - 1) / kFastTileH, bx, by)) return;  // workgroup-uniform
-    const int x0 = (int)bx * kFastTileW - halo, y0 = (int)by * kFastTileH - halo;
-    for (int e = (int)threadIdx.x; e < TW * TH; e += kFastTileW * kFastTileH)
+    uint32_t  t;
+    if (!xcd_tile_index(tiles_x * tiles_per_phase * (uint32_t)STRIDE, t)) return;  // workgroup-uniform
+    // linear tile index: columns fastest, then the 8-row groups of a phase (neighbours share 4 of their 12 staged rows), then the phase
+    const uint32_t tx = t % tiles_x, rest = t / tiles_x, jt = rest % tiles_per_phase, py = rest / tiles_per_phase;
+    const int      x0 = (int)tx * kPhaseW - HX, j0 = (int)jt * kPhaseH - 2;
+    for (int e = (int)threadIdx.x; e < TW * TH; e += kPhaseW * kPhaseH)
     {
-        const int  ty = e / TW, tx = e - ty * TW;
-        const int  sx = x0 + tx, sy = y0 + ty;
-        float4     c = make_float4(0.f, 0.f, 0.f, 0.f), g = c;
-        if (sx >= 0 && sy >= 0 && sx < W && sy < H)
-        {
-            const size_t o = (size_t)sy * W + sx;
-            c = color.p[o], g = nd.p[o];
-            c = make_float4(fminf(c.x, 10.0f), fminf(c.y, 10.0f), fminf(c.z, 10.0f), c.w);  // remove_fireflies
-        }
-        t_col[e] = c, t_nd[e] = g;  // outside the image: depth 0 = background
+        const int ty = e / TW, txx = e - ty * TW;
+        float4    c, g;
+        float2    mm;
+        stage_texel<true, false>(color, nd, nd, x0 + txx, (int)py + STRIDE * (j0 + ty), c, g, mm);
+        t_col[e] = c, t_nd[e] = g;
     }
     __syncthreads();
-    const int lx = (int)(threadIdx.x % kFastTileW), ly = (int)(threadIdx.x / kFastTileW);
-    const int x = (int)bx * kFastTileW + lx, y = (int)by * kFastTileH + ly;
+    const int lx = (int)(threadIdx.x % kPhaseW), ly = (int)(threadIdx.x / kPhaseW);
+    const int x = (int)tx * kPhaseW + lx, y = (int)py + STRIDE * ((int)jt * kPhaseH + ly);
     if (x >= W || y >= H) return;
     const size_t o  = (size_t)y * W + x;
-    const int    lc = (ly + halo) * TW + lx + halo;
-    const float4 cv = t_col[lc], cg = t_nd[lc];
-    FastCenter   k;
-    k.cn = xyz(cg), k.cd = cg.w, k.cc = xyz(cv), k.lcc = luminance(k.cc);
+    const float4 cv = color.p[o], cg = nd.p[o];  // (a background centre passes its own colour through: not from the tile)
+    TapCenter    k;
+    k.cn = xyz(cg), k.cd = cg.w, k.cc = remove_fireflies(cv), k.lcc = luminance(k.cc);
     const float cvar = USE_VAR ? cv.w : 0.0f;
     float4      res  = make_float4(k.cc.x, k.cc.y, k.cc.z, cvar);
     if (!(k.cd < 1e-5f))
     {
         k.s_normal = s.eaw_normal_sigma;
-        k.f_depth  = fast_neg_inv(k.cd * (float)stride * s.eaw_depth_sigma);
-        k.f_luma   = fast_neg_inv(s.eaw_luma_sigma * sqrtf(fmaxf(0.0f, cvar + kEpsPost)));
-        const float kw[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
+        k.s_depth  = k.cd * (float)STRIDE * s.eaw_depth_sigma;
+        k.s_luma   = s.eaw_luma_sigma * sqrtf(fmaxf(0.0f, cvar + kEpsPost));
+        k.f_depth = FAST ? fast_neg_inv(k.s_depth) : 0.f, k.f_luma = FAST ? fast_neg_inv(k.s_luma) : 0.f;
         v3          filtered = mk3(0.f, 0.f, 0.f);
         float       total = 0.0f, fvar = 0.0f;
-        constexpr int row_step = stride * TW;
-#pragma unroll
+        const int   lc = (ly + 2) * TW + lx + HX;
+        constexpr int UNROLL_Y = FAST ? 5 : 1;  // (see k_stencil_lds)
+#pragma unroll UNROLL_Y
         for (int dy = -2; dy <= 2; ++dy)
 #pragma unroll
             for (int dx = -2; dx <= 2; ++dx)
             {
-                const int    e = lc + dy * row_step + dx * stride;
+                const int    e = lc + dy * TW + dx * STRIDE;
                 const float4 v = t_col[e], g = t_nd[e];
                 const v3     c = xyz(v);
-                const float  w = fast_tap_weight<USE_VAR>(k, g, c, kInv7.v[dy + 3][dx + 3], true);
-                const float  hw = USE_VAR ? kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy] : 1.0f;
-                const float  kk = w * hw;
+                float        wgt, lw;
+                tap_weights<FAST, USE_VAR>(k, g, c, kLen7.v[dy + 3][dx + 3], kInv7.v[dy + 3][dx + 3], wgt, lw);
+                wgt = (g.w < 1e-5f) ? 0.0f : wgt;
+                const float hw = USE_VAR ? atrous_kernel(dx) * atrous_kernel(dy) : 1.0f;
+                const float kk = FAST ? wgt * hw : wgt * hw * lw;
                 filtered = filtered + c * kk;
                 total += kk;
-                if (USE_VAR) fvar += (kk * kk) * v.w;
+                if (USE_VAR) fvar += FAST ? (kk * kk) * v.w : hw * hw * wgt * wgt * lw * lw * v.w;
             }
         const bool  empty = total < kEpsPost;
-        const float rt    = fast_rcp(total);
-        const v3    r     = empty ? k.cc : filtered * rt;
-        res = make_float4(r.x, r.y, r.z, empty ? cvar : fvar * (rt * rt));
+        const float rt    = FAST ? fast_rcp(total) : 0.f;
+        const v3    r     = empty ? k.cc : (FAST ? filtered * rt : div3(filtered, total));
+        res = make_float4(r.x, r.y, r.z, empty ? cvar : (FAST ? fvar * (rt * rt) : fvar / (total * total)));
     }
     if (COMBINE)
     {
         const size_t oa = aux_index((uint32_t)x, (uint32_t)y, color.w, aux_tiles_x);
-        const float4 a = albedo[oa], d = direct[oa];
-        res = make_float4(res.x * a.x + d.x, res.y * a.y + d.y, res.z * a.z + d.z, 1.0f * a.w + d.w);
-    }
-    out[o] = res;
-}
-
-// the a-trous passes of stride 3, 5, 7
-template <bool USE_VAR, bool COMBINE>
-__global__ __launch_bounds__(kBlock, 4) void k_blur_fast_strided(PostSettingsDev s, int stride, Img color, Img nd, float4* out, const float4* albedo,
-                                                                  const float4* direct, uint32_t aux_tiles_x)
-{
-    uint32_t x, y;
-    if (!pixel_of_thread(color.w, color.h, x, y)) return;
-    const int    W = (int)color.w, H = (int)color.h;
-    const size_t o = (size_t)y * W + x;
-    const float4 cg = nd.p[o], cv0 = color.p[o];
-    FastCenter   k;
-    k.cn = xyz(cg), k.cd = cg.w, k.cc = remove_fireflies(cv0), k.lcc = luminance(k.cc);
-    const float cvar = USE_VAR ? cv0.w : 0.0f;
-    float4      res  = make_float4(k.cc.x, k.cc.y, k.cc.z, cvar);
-    if (!(k.cd < 1e-5f))
-    {
-        k.s_normal = s.eaw_normal_sigma;
-        k.f_depth  = fast_neg_inv(k.cd * (float)stride * s.eaw_depth_sigma);
-        k.f_luma   = fast_neg_inv(s.eaw_luma_sigma * sqrtf(fmaxf(0.0f, cvar + kEpsPost)));
-        const float kw[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
-        v3          filtered = mk3(0.f, 0.f, 0.f);
-        float       total = 0.0f, fvar = 0.0f;
-        // One row of taps (ten loads) at a time, the NEXT row's loads issued before this row's arithmetic (fully unrolled, the 50
-        // independent loads are all hoisted and 128 registers spill; row by row without the prefetch every row exposes a full L2
-        // round trip: 81 us per pass)
-        float4 v[5], g[5], vn[5], gn[5];
-        // a tap outside the image is loaded from the clamped position and turned into a background texel (depth 0, colour 0) on the
-        // spot: no per-tap flags to keep (ten lane masks per row in flight exhausted the scalar registers)
-        // the five tap columns are the same in every row: clamped offsets and in-image masks once per pixel
-        uint32_t cx[5], mx[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-        {
-            const int sx = (int)x + (i - 2) * stride;
-            cx[i]        = (uint32_t)max(0, min(sx, W - 1));
-            mx[i]        = (sx >= 0 && sx < W) ? ~0u : 0u;
-        }
-        auto load_row = [&](int dy, float4* rv, float4* rg) {
-            const int      sy  = (int)y + dy * stride;
-            const uint32_t my  = (sy >= 0 && sy < H) ? ~0u : 0u;
-            const size_t   row = (size_t)max(0, min(sy, H - 1)) * W;
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-            {
-                const size_t t = row + cx[i];
-                const float4 c = color.p[t], n = nd.p[t];
-                // (bit masks, not selects: the compiler turns a select of a loaded value into a branch around the load)
-                const uint32_t m = mx[i] & my;
-                rv[i] = make_float4(u2f(f2u(c.x) & m), u2f(f2u(c.y) & m), u2f(f2u(c.z) & m), u2f(f2u(c.w) & m));
-                rg[i] = make_float4(n.x, n.y, n.z, u2f(f2u(n.w) & m));
-            }
-        };
-        auto tap_row = [&](int dy, const float4* rv, const float4* rg) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-            {
-                const int   dx = i - 2;
-                const v3    c  = remove_fireflies(rv[i]);
-                const float w  = fast_tap_weight<USE_VAR>(k, rg[i], c, kInv7.v[dy + 3][dx + 3], true);
-                const float hw = USE_VAR ? kw[dx < 0 ? -dx : dx] * kw[dy < 0 ? -dy : dy] : 1.0f;
-                const float kk = w * hw;
-                filtered = filtered + c * kk;
-                total += kk;
-                if (USE_VAR) fvar += (kk * kk) * rv[i].w;
-            }
-        };
-        // straight-line ping-pong over the five rows: a row's loads are in flight under the previous row's arithmetic; the
-        // scheduling barriers keep the compiler from hoisting later rows' loads (three rows live spill)
-        load_row(-2, v, g);
-        load_row(-1, vn, gn);
-        __builtin_amdgcn_sched_barrier(0);
-        tap_row(-2, v, g);
-        __builtin_amdgcn_sched_barrier(0);
-        load_row(0, v, g);
-        __builtin_amdgcn_sched_barrier(0);
-        tap_row(-1, vn, gn);
-        __builtin_amdgcn_sched_barrier(0);
-        load_row(1, vn, gn);
-        __builtin_amdgcn_sched_barrier(0);
-        tap_row(0, v, g);
-        __builtin_amdgcn_sched_barrier(0);
-        load_row(2, v, g);
-        __builtin_amdgcn_sched_barrier(0);
-        tap_row(1, vn, gn);
-        tap_row(2, v, g);
-        const bool  empty = total < kEpsPost;
-        const float rt    = fast_rcp(total);
-        const v3    r     = empty ? k.cc : filtered * rt;
-        res = make_float4(r.x, r.y, r.z, empty ? cvar : fvar * (rt * rt));
-    }
-    if (COMBINE)
-    {
-        const size_t oa = aux_index(x, y, color.w, aux_tiles_x);
         const float4 a = albedo[oa], d = direct[oa];
         res = make_float4(res.x * a.x + d.x, res.y * a.y + d.y, res.z * a.z + d.z, 1.0f * a.w + d.w);
     }
@@ -925,9 +750,10 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
 {
     const uint32_t W = a.width, H = a.height;
     const dim3     grid((W + 31) / 32, (H + 7) / 8), block(kBlock);
-    const dim3     xgrid(xcd_grid((W + 31) / 32, (H + 7) / 8));  // the LDS-tiled kernels' 1-D grid (xcd_tile)
+    const dim3     xgrid(xcd_grid(((W + 31) / 32) * ((H + 7) / 8)));  // the 32 x 8 LDS-tiled kernels' 1-D grid (xcd_tile)
     const size_t   bytes = sizeof(float4) * (size_t)W * H;
     auto           img   = [&](const float4* p) { return Img{p, W, H}; };
+    const Img      none{nullptr, 0, 0};
     const uint32_t src = (a.frame_count + 1) % 2, dst = a.frame_count % 2;  // raytracing_system.cpp:1709-1710, 1754-1755
     uint32_t cg = (W * H + kBlock - 1) / kBlock;  // grid of the streaming (stencil-free) kernels
     if (cg > 4096) cg = 4096;
@@ -964,10 +790,9 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     else if (a.settings.gather)
     {
         if (fast)
-            hipLaunchKernelGGL((k_stencil_fast_lds<kFastGather, 3, true, false>), xgrid, block, 0, stream, a.settings, indirect_in, img(a.normals),
-                               Img{nullptr, 0, 0}, a.indirect_temp, nullptr, nullptr);
+            hipLaunchKernelGGL((k_stencil_lds<kGather, 3, true, true>), xgrid, block, 0, stream, a.settings, indirect_in, img(a.normals), none, a.indirect_temp);
         else
-            hipLaunchKernelGGL((k_gather<false, false>), grid, block, 0, stream, a.settings, indirect_in, img(a.normals), a.indirect_temp, 0, 0);
+            hipLaunchKernelGGL((k_stencil_lds<kGather, 3, true, false>), xgrid, block, 0, stream, a.settings, indirect_in, img(a.normals), none, a.indirect_temp);
     }
     else
         (void)hipMemcpyAsync(a.indirect_temp, indirect, sizeof(float4) * (size_t)IW * IH, hipMemcpyDeviceToDevice, stream);
@@ -983,65 +808,37 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
         // (USE_VAR, FAST) variants; the last a-trous pass combines (its own timestamp label then covers nothing: the reference's
         // "Combine illumination" span is part of "EAW" here)
         const bool fuse_combine = a.settings.output == 0;  // the other output types read the blurred image itself: k_combine after the pass
+#define CAP_MODES(KERNEL_UV_F, ...)                                                  \
+    {                                                                                 \
+        if (use_var && fast) { KERNEL_UV_F(true, true, __VA_ARGS__); }                \
+        else if (use_var) { KERNEL_UV_F(true, false, __VA_ARGS__); }                  \
+        else if (fast) { KERNEL_UV_F(false, true, __VA_ARGS__); }                     \
+        else { KERNEL_UV_F(false, false, __VA_ARGS__); }                              \
+    }
+#define CAP_STENCIL(UV, F, KIND, R, IN, MOM, OUT) hipLaunchKernelGGL((k_stencil_lds<KIND, R, UV, F>), xgrid, block, 0, stream, a.settings, IN, img(a.normals), MOM, OUT)
+#define CAP_PHASE(UV, F, S, CB, IN, OUT)                                                                                                        \
+    hipLaunchKernelGGL((k_blur_phase<S, UV, F, CB>), pgrid, pblock, 0, stream, a.settings, IN, img(a.normals), OUT, (CB) ? a.albedo : nullptr,   \
+                       (CB) ? a.direct : nullptr, a.tiled, ptx, ptp)
         auto blur = [&](uint32_t stride, const float4* in, float4* out, bool last_pass) {
             const bool last = last_pass && fuse_combine;
-            if (fast)
+            if (stride == 1u)
             {
-                const Img none{nullptr, 0, 0};
-                if (stride == 1u && use_var)
-                    hipLaunchKernelGGL((k_stencil_fast_lds<kFastBlur, 2, true, false>), xgrid, block, 0, stream, a.settings, img(in), img(a.normals), none, out, nullptr, nullptr);
-                else if (stride == 1u)
-                    hipLaunchKernelGGL((k_stencil_fast_lds<kFastBlur, 2, false, false>), xgrid, block, 0, stream, a.settings, img(in), img(a.normals), none, out, nullptr, nullptr);
-                else if (W >= (uint32_t)kFastTileW && H >= (uint32_t)kFastTileH && (stride == 3u || stride == 5u || stride == 7u))
-                {
-                    const dim3 tgrid(xcd_grid((W + kFastTileW - 1) / kFastTileW, (H + kFastTileH - 1) / kFastTileH)), tblock(kFastTileW * kFastTileH);
-#define CAP_TILE(S, UV, CB)                                                                                                            \
-    hipLaunchKernelGGL((k_blur_fast_tile<S, UV, CB>), tgrid, tblock, 0, stream, a.settings, img(in), img(a.normals), out, (CB) ? a.albedo : nullptr, \
-                       (CB) ? a.direct : nullptr, a.tiled)
-#define CAP_TILE_S(S)                                                                                                                  \
-    {                                                                                                                                  \
-        if (use_var && last) CAP_TILE(S, true, true);                                                                                  \
-        else if (use_var) CAP_TILE(S, true, false);                                                                                    \
-        else if (last) CAP_TILE(S, false, true);                                                                                       \
-        else CAP_TILE(S, false, false);                                                                                                \
-    }
-                    if (stride == 3u) CAP_TILE_S(3)
-                    else if (stride == 5u) CAP_TILE_S(5)
-                    else CAP_TILE_S(7)
-#undef CAP_TILE_S
-#undef CAP_TILE
-                }
-                else if (use_var && last)
-                    hipLaunchKernelGGL((k_blur_fast_strided<true, true>), grid, block, 0, stream, a.settings, (int)stride, img(in), img(a.normals), out, a.albedo, a.direct, a.tiled);
-                else if (use_var)
-                    hipLaunchKernelGGL((k_blur_fast_strided<true, false>), grid, block, 0, stream, a.settings, (int)stride, img(in), img(a.normals), out, nullptr, nullptr, a.tiled);
-                else if (last)
-                    hipLaunchKernelGGL((k_blur_fast_strided<false, true>), grid, block, 0, stream, a.settings, (int)stride, img(in), img(a.normals), out, a.albedo, a.direct, a.tiled);
-                else
-                    hipLaunchKernelGGL((k_blur_fast_strided<false, false>), grid, block, 0, stream, a.settings, (int)stride, img(in), img(a.normals), out, nullptr, nullptr, a.tiled);
+                CAP_MODES(CAP_STENCIL, kBlur, 2, img(in), none, out);
                 return;
             }
-#define CAP_BLUR(UV, F)                                                                                                                            \
-    if (last)                                                                                                                                      \
-        hipLaunchKernelGGL((k_blur<UV, F, true>), grid, block, 0, stream, a.settings, stride, img(in), img(a.normals), out, a.albedo, a.direct, a.tiled);   \
-    else                                                                                                                                           \
-        hipLaunchKernelGGL((k_blur<UV, F, false>), grid, block, 0, stream, a.settings, stride, img(in), img(a.normals), out, nullptr, nullptr, 0u)
-            if (use_var) { CAP_BLUR(true, false); }
-            else { CAP_BLUR(false, false); }
-#undef CAP_BLUR
+            const uint32_t ptx = (W + kPhaseW - 1) / kPhaseW, ptp = phase_tiles_per_phase(H, stride);
+            const dim3     pgrid(xcd_grid(ptx * ptp * stride)), pblock(kPhaseW * kPhaseH);
+#define CAP_PHASE_S(S)                                                     \
+    {                                                                      \
+        if (last) CAP_MODES(CAP_PHASE, S, true, img(in), out)              \
+        else CAP_MODES(CAP_PHASE, S, false, img(in), out)                  \
+    }
+            if (stride == 3u) CAP_PHASE_S(3)
+            else if (stride == 5u) CAP_PHASE_S(5)
+            else CAP_PHASE_S(7)
+#undef CAP_PHASE_S
         };
-#define CAP_DISOCC(UV, F)                                                                                                                     \
-    hipLaunchKernelGGL((k_blur_disocclusion<UV, F>), grid, block, 0, stream, a.settings, img(a.indirect_history[dst]), img(a.normals),        \
-                       img(a.moments_history[dst]), a.temp[0])
-        if (fast && use_var)
-            hipLaunchKernelGGL((k_stencil_fast_lds<kFastDisocclusion, 3, true, false>), xgrid, block, 0, stream, a.settings, img(a.indirect_history[dst]),
-                               img(a.normals), img(a.moments_history[dst]), a.temp[0], nullptr, nullptr);
-        else if (fast)
-            hipLaunchKernelGGL((k_stencil_fast_lds<kFastDisocclusion, 3, false, false>), xgrid, block, 0, stream, a.settings, img(a.indirect_history[dst]),
-                               img(a.normals), img(a.moments_history[dst]), a.temp[0], nullptr, nullptr);
-        else if (use_var) { CAP_DISOCC(true, false); }
-        else { CAP_DISOCC(false, false); }
-#undef CAP_DISOCC
+        CAP_MODES(CAP_STENCIL, kDisocclusion, 3, img(a.indirect_history[dst]), img(a.moments_history[dst]), a.temp[0]);
         blur(1u, a.temp[0], a.temp[1], false);
         blur(3u, a.temp[1], a.temp[0], !a.settings.eaw5);
         if (a.settings.eaw5)
@@ -1049,6 +846,9 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
             blur(5u, a.temp[0], a.temp[1], false);
             blur(7u, a.temp[1], a.temp[0], true);
         }
+#undef CAP_PHASE
+#undef CAP_STENCIL
+#undef CAP_MODES
         mark(3);
         if (!fuse_combine) hipLaunchKernelGGL(k_combine, dim3(cg), block, 0, stream, a.temp[0], a.albedo, a.direct, W * H, W, a.tiled, a.settings.output);
     }

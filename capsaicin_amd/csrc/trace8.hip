@@ -78,9 +78,6 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
 #ifdef CAP_W8_COUNT
     unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-#ifdef CAP_W8_PREFETCH
-    uint32_t pf = 0u, sink = 0u;
-#endif
     while (true)
     {
         W8_COUNT(5, lane == 0 ? 1 : 0);
@@ -145,29 +142,14 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
             W8_COUNT(6, rest ? 1 : 0);
             W8_COUNT(7, (rest && st.sp >= kW8Lds) ? 1 : 0);
             W8_COUNT(3, node < kWideTopNodes ? 1 : 0);
-            if (rest)
-            {
-                st.push(c.g_base, c.g_mask);
-#ifdef CAP_W8_PREFETCH  // experiment (59): touch the first line of the node the pushed group will give when it is popped
-                const uint32_t pbit  = 31u - (uint32_t)__clz((int)c.g_mask);
-                const uint32_t pslot = (pbit - 24u) ^ w.octinv;
-                const uint32_t pnode = c.g_base + (uint32_t)__popc(c.g_mask & 0xffu & ((1u << pslot) - 1u));
-                pf = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(bvh.nodes8 + (kWideNodeStride / 4u) * (size_t)pnode));
-#endif
-            }
+            if (rest) st.push(c.g_base, c.g_mask);
             src = bvh.nodes8 + (kWideNodeStride / 4u) * (size_t)node;
         }
         W8_COUNT(2, lane == 0 ? 1 : 0);
         WideNode nd;
         nd.h0 = nd.h1 = nd.q2 = nd.q3 = nd.q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef CAP_W8_SETPRIO  // experiment (60): a wave that is about to issue its loads goes first
-        __builtin_amdgcn_s_setprio(CAP_W8_SETPRIO);
-#endif
         if (alive) nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2], nd.q3 = src[3];
         if (node_lane) nd.q4 = src[4];
-#ifdef CAP_W8_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (tri_lane)
         {
             float t, u, v;
@@ -178,9 +160,6 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
             }
         }
         if (node_lane) wide_node_test(nd, w, r.tmin, best_t, c);
-#ifdef CAP_W8_PREFETCH
-        sink ^= pf;
-#endif
         // a lane with nothing due takes the next node group off its stack, or retires
         if (alive && c.t_hits == 0u && (c.g_mask >> 24) == 0u)
         {
@@ -193,9 +172,6 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
                 st.pop(c);
         }
     }
-#ifdef CAP_W8_PREFETCH
-    if (sink == 0x9e3779b9u && n_class == 0xffffffffu) hits[0].x = 1.0f;  // keeps the prefetched words alive; never true
-#endif
 #ifdef CAP_W8_COUNT
     for (int i = 0; i < 8; ++i)
     {
