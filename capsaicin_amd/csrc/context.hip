@@ -1659,6 +1659,7 @@ static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t fram
                                  s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback, s->lowres_indirect,
                                  s->disable_variance ? 0 : 1, s->fast_weights, s->output};
     a.width = c->screen.width, a.height = c->screen.height, a.frame_count = frame_count;
+    a.cu_count = (uint32_t)std::max(c->cu_count, 0);
     a.camera = camera_dev(c->camera), a.prev_camera = camera_dev(*prev_camera);
     a.indirect = c->post_in[0].p, a.direct = c->post_in[1].p, a.albedo = c->post_in[2].p, a.normal_depth = c->post_in[3].p;
     if (tiled)

@@ -294,8 +294,27 @@ __device__ __forceinline__ float closest_depth(const Img& g, f2 xy)
     return closest;
 }
 
+// One bilinear tap with the hardware's arithmetic for the FAST variants below: the reference's footprint and weights (utils.h:20-35),
+// no IEEE division.  (uv -> pixel coordinates as the reference does it, so the four texels are the ones the exact code blends.)
+__device__ __forceinline__ v3 sample_bilinear_fast(const Img& t, f2 uv)
+{
+    const f2       xy = uv_to_xy(uv, t.w, t.h);
+    const float    fx = xy.x - 0.5f, fy = xy.y - 0.5f;
+    const float    flx = floorf(fx), fly = floorf(fy);
+    const uint32_t ux = sat_uint(flx), uy = sat_uint(fly);
+    const float    wx = fx - flx, wy = fy - fly;
+    const v3 v00 = xyz(ld(t, ux, uy)), v01 = xyz(ld(t, ux, uy + 1)), v10 = xyz(ld(t, ux + 1, uy)), v11 = xyz(ld(t, ux + 1, uy + 1));
+    return lerp3(lerp3(v00, v10, wx), lerp3(v01, v11, wx), wy);
+}
+
 // temporal_accumulation.hlsl:213-325.  With UPSCALE2X (s.lowres_indirect) `color` is the half-resolution image (SampleColor uses its
 // size, :228-235) and a pixel that got no new sample this frame keeps its history (:307-313).
+// FAST (CapPostSettings::fast_weights): everything that DECIDES -- the reprojection, the disocclusion test, the history length -- is
+// the exact code on the same G-buffer and cameras, so the fast chain resets and blends exactly where the exact one does; only the
+// values are cheaper: the colour sample at a pixel centre is the texel (the reference's bilinear tap there has fractional weights of
+// 0 or one rounding error), and the bicubic history resample is its centre tap (the other eight sit where the Mitchell weight is
+// exactly 0 unless (c + 1) - c rounds: see resample_bicubic), without the weight that cancels in filtered / total.
+template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32_t frame_count, CameraDev cam, CameraDev prev_cam, Img color,
                                                        Img nd, Img color_history, Img moments_history, Img prev_nd, float4* out_color,
                                                        float4* out_moments)
@@ -306,6 +325,53 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32
     const f2     uv = f2{((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H};
     const float4 g  = ld(nd, x, y);
     const size_t o  = (size_t)y * W + x;
+    if (FAST && color.w == W && color.h == H)
+    {
+        // The same decisions as below, but every load of the pixel -- the 3 x 3 depths around the reprojected position, the history
+        // length, the two histories' bilinear footprints, the colour -- is issued in ONE batch behind the reprojection, with clamped
+        // coordinates where the exact code would not load at all, and the branches become selects at the end: the exact code's four
+        // dependent round trips (G-buffer -> previous depths -> history length -> histories) were what this kernel waited for.
+        const bool  bg  = g.w < 1e-5f;
+        const v3    hit = reconstruct_world_position(cam, uv, bg ? 1.0f : g.w);
+        const f2    puv = image_plane_uv(prev_cam, hit);
+        const bool  off = puv.x < 0.0f || puv.y < 0.0f || puv.x > 1.0f || puv.y > 1.0f || frame_count == 0;
+        const f2    sp  = (bg || off) ? f2{0.5f, 0.5f} : puv;  // where nothing is reprojected: any in-image position, result unused
+        const f2    pxy = uv_to_xy(sp, W, H);
+        const int   cx = (int)pxy.x, cy = (int)pxy.y;
+        float       dn[9];
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+            {
+                const int  tx = cx + dx, ty = cy + dy;
+                const bool in = tx >= 0 && ty >= 0 && tx < (int)W && ty < (int)H;
+                const float d = prev_nd.p[(size_t)min(max(ty, 0), (int)H - 1) * W + min(max(tx, 0), (int)W - 1)].w;
+                dn[(dx + 1) * 3 + dy + 1] = in ? d : 0.0f;  // (a depth of 0 is skipped by the minimum below, like an out-of-bounds tap)
+            }
+        const float hl  = ld(moments_history, sat_uint(floorf(pxy.x)), sat_uint(floorf(pxy.y))).w;
+        const f2    c0  = uv_to_xy(sp, W, H);
+        const f2    cuv = f2{fminf(fmaxf(c0.x * fast_rcp((float)W), 0.0f), 1.0f), fminf(fmaxf(c0.y * fast_rcp((float)H), 0.0f), 1.0f)};
+        const v3    history = sample_bilinear_fast(color_history, cuv), mh = sample_bilinear_fast(moments_history, cuv);
+        // (the last row and column are NOT the texel: UVtoXY clamps to dim - 1, utils.h:6-10, so the reference's tap there is a two-texel blend)
+        const v3    c = (x + 1u < W && y + 1u < H) ? xyz(color.p[o]) : sample_bilinear(color, uv);
+        const float l = luminance(c);
+        // closest_depth (:179-205): the centre texel, then the minimum over the non-zero depths of the 3 x 3
+        float closest = dn[4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            if (dn[k] != 0.0f && dn[k] < closest) closest = dn[k];
+        const float cur_depth = length3(hit - mk3(prev_cam.position[0], prev_cam.position[1], prev_cam.position[2]));
+        const bool  reset     = bg || off || fabsf(closest - cur_depth) / cur_depth > 0.05f;
+        float       alpha     = s.temporal_upscale_feedback;
+        uint32_t    hist_len  = sat_uint(hl);
+        if (hist_len < 256u) alpha = fminf(alpha, 1.0f - 1.0f / (float)(hist_len + 1));
+        const float m0 = lerp1(l, mh.x, alpha), m1 = lerp1(l * l, mh.y, alpha);
+        const v3    blended = lerp3(c, history, alpha);
+        out_moments[o] = reset ? make_float4(l, l * l, 0.0f, 1.0f) : make_float4(m0, m1, 0.0f, (float)(hist_len + 1));
+        out_color[o]   = reset ? make_float4(c.x, c.y, c.z, 0.0f) : make_float4(blended.x, blended.y, blended.z, fabsf(m1 - m0 * m0));
+        return;
+    }
     bool         reset = g.w < 1e-5f;
     f2           puv = f2{0.f, 0.f}, pxy = f2{0.f, 0.f};
     if (!reset)
@@ -329,10 +395,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32
         out_moments[o] = make_float4(l, l * l, 0.0f, 1.0f);
         return;
     }
-    float          alpha    = s.temporal_upscale_feedback;
-    const BicubicTaps taps  = bicubic_taps(puv, color_history.w, color_history.h);  // both histories are W x H images
-    const v3       history  = resample_bicubic(color_history, taps);
-    uint32_t       hist_len = sat_uint(ld(moments_history, sat_uint(floorf(pxy.x)), sat_uint(floorf(pxy.y))).w);
+    float    alpha    = s.temporal_upscale_feedback;
+    uint32_t hist_len = sat_uint(ld(moments_history, sat_uint(floorf(pxy.x)), sat_uint(floorf(pxy.y))).w);
     if (hist_len < 256u)
     {
         const float t = 1.0f / (float)(hist_len + 1);
@@ -343,7 +407,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PostSettingsDev s, uint32
         alpha = 1.0f;
         hist_len -= 1u;  // uint: a length of 0 wraps and the + 1 below brings it back to 0
     }
-    const v3    mh = resample_bicubic(moments_history, taps);
+    const BicubicTaps taps    = bicubic_taps(puv, color_history.w, color_history.h);  // both histories are W x H images
+    const v3          history = resample_bicubic(color_history, taps), mh = resample_bicubic(moments_history, taps);
     const float m0 = lerp1(l, mh.x, alpha), m1 = lerp1(l * l, mh.y, alpha);
     const float variance = fabsf(m1 - m0 * m0);
     out_moments[o]   = make_float4(m0, m1, 0.0f, (float)(hist_len + 1));
@@ -436,12 +501,32 @@ __device__ __forceinline__ void tap_weights(const TapCenter& k, float4 g, v3 c, 
 // One texel of a stencil footprint for the LDS tiles: outside the image -> depth 0 (= background, never taken) and colour 0; a
 // background texel inside the image keeps its (normal | depth) and gets colour 0 -- a tap of weight 0 still multiplies what it
 // reads, so EVERY plane of an entry that can be a skipped tap is a defined, finite 0.
-template <bool CLAMP, bool MOMENTS>
-__device__ __forceinline__ void stage_texel(const Img& color, const Img& nd, const Img& moments, int sx, int sy, float4& c, float4& g, float2& mm)
+// TILED (Gather on an unsharded context): `color` and `nd` are the render's tile-ordered planes, `nd` still octahedral-encoded -- the
+// texel is untiled and its normal decoded here, with the operations of k_untile_decode (the same bits), so that pass and its image
+// round trip are not needed.
+// DUAL (the first a-trous pass): `color` is IntegrateTemporally's output and `alt` BlurDisocclusion's, which is only written where a
+// pixel needed its 7 x 7 filter; a pixel that BlurDisocclusion passes through (background, or a history of eight frames: most of
+// the image most of the time) is taken from `color` as that pass would have written it -- its fireflies clamped, which CLAMP does
+// here anyway, and its variance kept -- so in the steady state BlurDisocclusion neither reads nor writes an image.
+template <bool CLAMP, bool MOMENTS, bool TILED = false, bool DUAL = false>
+__device__ __forceinline__ void stage_texel(const Img& color, const Img& nd, const Img& moments, int sx, int sy, float4& c, float4& g, float2& mm,
+                                            uint32_t tiles_x = 0, const float4* alt = nullptr)
 {
     const bool   in = sx >= 0 && sy >= 0 && sx < (int)color.w && sy < (int)color.h;
-    const size_t o  = in ? (size_t)sy * color.w + sx : 0;  // (clamped address: the loads are unconditional, their values selected)
-    const float4 gv = nd.p[o], v = color.p[o];
+    // (clamped address: the loads are unconditional, their values selected)
+    const size_t o  = !in ? 0 : (TILED ? aux_index((uint32_t)sx, (uint32_t)sy, color.w, tiles_x) : (size_t)sy * color.w + sx);
+    float4       gv = nd.p[o];
+    float4       v  = color.p[o];
+    if (DUAL)
+    {
+        const float hist = moments.p[o].w;
+        if (!(gv.w < 1e-5f || hist >= 8.0f)) v = alt[o];
+    }
+    if (TILED)
+    {
+        const v3 d = oct_decode(gv.x, gv.y);
+        gv         = make_float4(d.x, d.y, d.z, gv.w);
+    }
     float        m0 = 0.f, m1 = 0.f;
     if (MOMENTS)
     {
@@ -457,9 +542,15 @@ __device__ __forceinline__ void stage_texel(const Img& color, const Img& nd, con
 
 // Stride-1 stencils on a 32 x 8 pixel tile + halo R: Gather (R = 3), BlurDisocclusion (R = 3), the first a-trous pass (R = 2).
 // USE_VAR = the USE_VARIANCE define of eaw_blur.hlsl (:68, :114, :127, :162-165).
-template <int KIND, int R, bool USE_VAR, bool FAST>
-__global__ __launch_bounds__(kBlock) void k_stencil_lds(PostSettingsDev s, Img color, Img nd, Img moments, float4* out)
+// TILED (Gather only): see stage_texel; the decoded (normal | depth) of the workgroup's own pixels goes to `normals_out` row-major --
+// the image every later pass reads the G-buffer through.
+// DUAL (the first a-trous pass only): see stage_texel; `alt` = BlurDisocclusion's output, `moments` = the history lengths.
+template <int KIND, int R, bool USE_VAR, bool FAST, bool TILED = false, bool DUAL = false>
+__global__ __launch_bounds__(kBlock) void k_stencil_lds(PostSettingsDev s, Img color, Img nd, Img moments, float4* out, uint32_t tiles_x = 0,
+                                                        float4* normals_out = nullptr, const float4* alt = nullptr)
 {
+    static_assert(!TILED || KIND == kGather, "only Gather reads the render's planes");
+    static_assert(!DUAL || KIND == kBlur, "only the first a-trous pass reads BlurDisocclusion's sparse output");
     constexpr int TW = 32 + 2 * R, TH = 8 + 2 * R;
     __shared__ float4 t_col[TW * TH], t_nd[TW * TH];
     __shared__ float2 t_mom[KIND == kDisocclusion ? TW * TH : 1];
@@ -475,20 +566,35 @@ __global__ __launch_bounds__(kBlock) void k_stencil_lds(PostSettingsDev s, Img c
     float  hist = 0.0f;
     if (in_image)
     {
-        cv = color.p[o], cg = nd.p[o];
+        if (TILED)
+        {
+            const size_t ot = aux_index(x, y, color.w, tiles_x);
+            cv = color.p[ot], cg = nd.p[ot];
+            const v3 d = oct_decode(cg.x, cg.y);
+            cg         = make_float4(d.x, d.y, d.z, cg.w);
+            normals_out[o] = cg;
+        }
+        else
+            cv = color.p[o], cg = nd.p[o];
         if (KIND == kDisocclusion) hist = moments.p[o].w;
+        if (DUAL)
+            if (!(cg.w < 1e-5f || moments.p[o].w >= 8.0f)) cv = alt[o];
     }
     const bool pass = cg.w < 1e-5f || (KIND == kDisocclusion && hist >= 8.0f);
     // BlurDisocclusion passes most pixels through once the history is eight frames long: a workgroup of such pixels stages nothing
     bool needs_taps = true;
-    if (KIND == kDisocclusion) needs_taps = __syncthreads_or((in_image && !pass) ? 1 : 0) != 0;
+    if (KIND == kDisocclusion)
+    {
+        needs_taps = __syncthreads_or((in_image && !pass) ? 1 : 0) != 0;
+        if (!needs_taps) return;  // every pixel of the tile passes through: the first a-trous pass reads them where they are (DUAL)
+    }
     if (needs_taps)
     {
         for (int e = (int)threadIdx.x; e < TW * TH; e += (int)kBlock)
         {
             float4 c, g;
             float2 mm;
-            stage_texel<KIND != kGather, KIND == kDisocclusion>(color, nd, moments, x0 + e % TW, y0 + e / TW, c, g, mm);
+            stage_texel<KIND != kGather, KIND == kDisocclusion, TILED, DUAL>(color, nd, moments, x0 + e % TW, y0 + e / TW, c, g, mm, tiles_x, alt);
             t_col[e] = c, t_nd[e] = g;
             if (KIND == kDisocclusion) t_mom[e] = mm;
         }
@@ -673,12 +779,30 @@ __device__ __forceinline__ v3 clip_to_aabb(v3 pmin, v3 pmax, v3 p)
 }
 
 // temporal_accumulation.hlsl:362-447
+// FAST (CapPostSettings::fast_weights): as in k_accumulate, what DECIDES (reprojection, velocity, the plain path) is the exact code;
+// the values use v_rcp_f32 / v_sqrt_f32, the bilinear tap at a whole-pixel position is the mean of its 2 x 2 texels (its fractional
+// weights are 0.5 up to one rounding error), the current colour at the pixel centre is the texel, and the history resample is the
+// bicubic's centre tap.
 constexpr uint32_t kTaaTileW = 32 + 4, kTaaTileH = 8 + 4;  // the workgroup's 32 x 8 pixels + the 5 x 5 window's halo
+__device__ __forceinline__ v3 simple_tonemap_fast(v3 v) { return v * fast_rcp(1.0f + luminance(v)); }
+__device__ __forceinline__ v3 rgb2ycocg_fast(v3 c) { return mk3(0.25f * c.x + 0.5f * c.y + 0.25f * c.z, 0.5f * c.x - 0.5f * c.z, -0.25f * c.x + 0.5f * c.y - 0.25f * c.z); }
+template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_taa(PostSettingsDev s, CameraDev cam, CameraDev prev_cam, Img color, Img nd, Img history_img,
                                                 float4* out)
 {
     const uint32_t W = color.w, H = color.h;
     __shared__ v3  lds_tap[kTaaTileW * kTaaTileH];
+    // FAST: the pixel's own G-buffer texel and colour are requested before the tile is staged, the history's footprint right behind
+    // the reprojection, and the plain path is a select at the end: one batch of loads per dependency level instead of one per branch
+    uint32_t   x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    const bool in_image = x < W && y < H;
+    float4     g_early = make_float4(0.f, 0.f, 0.f, 0.f);
+    v3         cur_early = mk3(0.f, 0.f, 0.f);
+    if (FAST && in_image)
+    {
+        g_early   = nd.p[(size_t)y * W + x];
+        cur_early = xyz(color.p[(size_t)y * W + x]);
+    }
     {
         const int x0 = (int)(blockIdx.x * 32u) - 2, y0 = (int)(blockIdx.y * 8u) - 2;
         for (uint32_t e = threadIdx.x; e < kTaaTileW * kTaaTileH; e += kBlock)
@@ -686,30 +810,47 @@ __global__ __launch_bounds__(kBlock) void k_taa(PostSettingsDev s, CameraDev cam
             int sx = x0 + (int)(e % kTaaTileW), sy = y0 + (int)(e / kTaaTileW);
             sx = sx < 0 ? 0 : (sx > (int)W - 1 ? (int)W - 1 : sx);
             sy = sy < 0 ? 0 : (sy > (int)H - 1 ? (int)H - 1 : sy);
-            lds_tap[e] = rgb2ycocg(simple_tonemap(sample_bilinear(color, xy_to_uv(f2{(float)sx, (float)sy}, W, H))));
+            if (FAST)
+            {
+                // SampleBilinear at uv = (sx, sy) / dim: footprint (sx - 1 .. sx, sy - 1 .. sy) with weights 0.5; at the left / top
+                // edge uint(floor(-0.5)) saturates to 0, so the footprint is (0 .. 1) there (utils.h:24-27)
+                const uint32_t ux = sx > 0 ? (uint32_t)sx - 1u : 0u, uy = sy > 0 ? (uint32_t)sy - 1u : 0u;
+                const v3 v00 = xyz(ld(color, ux, uy)), v01 = xyz(ld(color, ux, uy + 1)), v10 = xyz(ld(color, ux + 1, uy)), v11 = xyz(ld(color, ux + 1, uy + 1));
+                lds_tap[e] = rgb2ycocg_fast(simple_tonemap_fast(((v00 + v10) + (v01 + v11)) * 0.25f));
+            }
+            else
+                lds_tap[e] = rgb2ycocg(simple_tonemap(sample_bilinear(color, xy_to_uv(f2{(float)sx, (float)sy}, W, H))));
         }
         __syncthreads();
     }
-    uint32_t x, y;
-    if (!pixel_of_thread(W, H, x, y)) return;
+    if (!in_image) return;
     const uint32_t lx = threadIdx.x & 31u, ly = threadIdx.x >> 5;
     const v3       tap_of_thread = lds_tap[(ly + 2) * kTaaTileW + (lx + 2)];
     const f2     uv = f2{((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H};
-    const float4 g  = ld(nd, x, y);
+    const float4 g  = FAST ? g_early : ld(nd, x, y);
     const size_t o  = (size_t)y * W + x;
     bool         plain = g.w < 1e-5f;
-    f2           puv = f2{0.f, 0.f};
+    f2           puv = f2{0.5f, 0.5f};
     float        velocity = 0.0f;
-    if (!plain)
+    if (FAST || !plain)
     {
-        const v3 hit = reconstruct_world_position(cam, uv, g.w);
-        puv          = image_plane_uv(prev_cam, hit);
-        const float vx = (puv.x - uv.x) * (float)W, vy = (puv.y - uv.y) * (float)H;
+        const v3 hit = reconstruct_world_position(cam, uv, (FAST && plain) ? 1.0f : g.w);
+        const f2 p   = image_plane_uv(prev_cam, hit);
+        const float vx = (p.x - uv.x) * (float)W, vy = (p.y - uv.y) * (float)H;
         velocity     = sqrtf(fmaf(vy, vy, vx * vx));
-        plain        = puv.x < 0.0f || puv.y < 0.0f || puv.x > 1.0f || puv.y > 1.0f;
+        plain        = plain || p.x < 0.0f || p.y < 0.0f || p.x > 1.0f || p.y > 1.0f;
+        puv          = (FAST && plain) ? puv : p;  // (FAST: a position nothing is read for keeps an in-image dummy)
     }
-    const v3 cur = sample_bilinear(color, uv);
-    if (plain)
+    v3 history_rgb = mk3(0.f, 0.f, 0.f);
+    if (FAST)
+    {
+        const f2 c0  = uv_to_xy(puv, W, H);
+        const f2 cuv = f2{fminf(fmaxf(c0.x * fast_rcp((float)W), 0.0f), 1.0f), fminf(fmaxf(c0.y * fast_rcp((float)H), 0.0f), 1.0f)};
+        history_rgb  = sample_bilinear_fast(history_img, cuv);
+    }
+    // (the last row and column are NOT the texel: UVtoXY clamps to dim - 1, utils.h:6-10, so the reference's tap there is a two-texel blend)
+    const v3 cur = (FAST && x + 1u < W && y + 1u < H) ? cur_early : sample_bilinear(color, uv);
+    if (!FAST && plain)
     {
         out[o] = make_float4(cur.x, cur.y, cur.z, 1.0f);
         return;
@@ -718,8 +859,17 @@ __global__ __launch_bounds__(kBlock) void k_taa(PostSettingsDev s, CameraDev cam
     float       alpha = is_static ? 0.98f : 0.6f;
     const float scale = is_static ? 5.0f : 0.75f;
     alpha             = fminf(s.taa_feedback, alpha);
-    v3       history = rgb2ycocg(simple_tonemap(resample_bicubic(history_img, puv)));
-    const v3 c       = rgb2ycocg(simple_tonemap(cur));
+    v3 history, c;
+    if (FAST)
+    {
+        history = rgb2ycocg_fast(simple_tonemap_fast(history_rgb));
+        c       = rgb2ycocg_fast(simple_tonemap_fast(cur));
+    }
+    else
+    {
+        history = rgb2ycocg(simple_tonemap(resample_bicubic(history_img, puv)));
+        c       = rgb2ycocg(simple_tonemap(cur));
+    }
     // CalculateNeighbourhoodColorAABB(gidx, dim, scale), :98-137.  The 25 tonemapped bilinear taps of a pixel sit at whole-pixel
     // positions (clamped to the image), so a tap's value depends on that position only and neighbouring pixels share 20 of their
     // 25: the workgroup evaluates each position of its 36 x 12 footprint once into LDS (the same operations on the same
@@ -740,9 +890,23 @@ __global__ __launch_bounds__(kBlock) void k_taa(PostSettingsDev s, CameraDev cam
     const v3 lo = m1 - dev, hi = m1 + dev;
     const v3 pmin = mk3(fminf(lo.x, center.x), fminf(lo.y, center.y), fminf(lo.z, center.z));
     const v3 pmax = mk3(fmaxf(hi.x, center.x), fmaxf(hi.y, center.y), fmaxf(hi.z, center.z));
-    history       = clip_to_aabb(pmin, pmax, history);
-    const v3 r    = invert_simple_tonemap(ycocg2rgb(lerp3(c, history, alpha)));
-    out[o]        = make_float4(r.x, r.y, r.z, 1.0f);
+    if (FAST)
+    {
+        // aabb.h:24-34 and the inverse tonemap with v_rcp_f32
+        const v3    cc = (pmin + pmax) * 0.5f, radius = (pmax - pmin) * 0.5f, dc = history - cc;
+        const v3    clip = mk3(dc.x * fast_rcp(radius.x + 1e-5f), dc.y * fast_rcp(radius.y + 1e-5f), dc.z * fast_rcp(radius.z + 1e-5f));
+        const float m    = fmaxf(fmaxf(fabsf(clip.x), fabsf(clip.y)), fabsf(clip.z));
+        history          = m > 1.0f ? cc + dc * fast_rcp(m) : history;
+        const v3 rr      = ycocg2rgb(lerp3(c, history, alpha));
+        const v3 r       = rr * fast_rcp(1.0f - luminance(rr));
+        out[o]           = plain ? make_float4(cur.x, cur.y, cur.z, 1.0f) : make_float4(r.x, r.y, r.z, 1.0f);
+    }
+    else
+    {
+        history    = clip_to_aabb(pmin, pmax, history);
+        const v3 r = invert_simple_tonemap(ycocg2rgb(lerp3(c, history, alpha)));
+        out[o]     = make_float4(r.x, r.y, r.z, 1.0f);
+    }
 }
 }  // namespace
 
@@ -765,7 +929,14 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     // decoded (normal.xyz, depth) image of the frame: every later pass reads the G-buffer through it (the depth in .w is the raw
     // texel's), and it is what the next frame keeps as its previous normal/depth image
     const float4* indirect = a.indirect;
-    if (a.tiled)
+    const bool     up = a.settings.lowres_indirect != 0;
+    const bool     fast = a.settings.fast_weights != 0, use_var = a.settings.use_variance != 0;
+    // Gather straight from the render's tile-ordered planes (full-resolution indirect pass): untiling and normal decoding happen in
+    // its staging, the decoded image is its second output
+    const bool gather_tiled = a.tiled && a.tiled_indirect && a.settings.gather && !up;
+    if (gather_tiled)
+        ;
+    else if (a.tiled)
     {
         hipLaunchKernelGGL(k_untile_decode, dim3(cg), block, 0, stream, a.screen, a.tiled_indirect, a.tiled_normal_depth, a.indirect_rowmajor, a.normals);
         if (a.tiled_indirect) indirect = a.indirect_rowmajor;
@@ -773,12 +944,18 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     else
         hipLaunchKernelGGL(k_decode_normals, dim3(cg), block, 0, stream, a.normal_depth, a.normals, W * H);
     // SpatialGather (cpp:1541-1604); with lowres_indirect the input, the grid and indirect_temp are (W/2, H/2)
-    const bool     up = a.settings.lowres_indirect != 0;
     const uint32_t IW = up ? W >> 1 : W, IH = up ? H >> 1 : H;
     const Img      indirect_in{indirect, IW, IH};
     const int      ox = (int)((a.frame_count % 4u) / 2u), oy = (int)((a.frame_count % 4u) % 2u);
-    const bool fast = a.settings.fast_weights != 0, use_var = a.settings.use_variance != 0;
-    if (a.settings.gather && up)
+    if (gather_tiled)
+    {
+        const Img tc{a.tiled_indirect, W, H}, tn{a.tiled_normal_depth, W, H};
+        if (fast)
+            hipLaunchKernelGGL((k_stencil_lds<kGather, 3, true, true, true>), xgrid, block, 0, stream, a.settings, tc, tn, none, a.indirect_temp, a.tiled, a.normals);
+        else
+            hipLaunchKernelGGL((k_stencil_lds<kGather, 3, true, false, true>), xgrid, block, 0, stream, a.settings, tc, tn, none, a.indirect_temp, a.tiled, a.normals);
+    }
+    else if (a.settings.gather && up)
     {
         if (fast)
             hipLaunchKernelGGL((k_gather<true, true>), dim3((IW + 31) / 32, (IH + 7) / 8), block, 0, stream, a.settings, indirect_in, img(a.normals),
@@ -798,9 +975,14 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
         (void)hipMemcpyAsync(a.indirect_temp, indirect, sizeof(float4) * (size_t)IW * IH, hipMemcpyDeviceToDevice, stream);
     // IntegrateTemporally (cpp:1283-1342)
     mark(1);
-    hipLaunchKernelGGL(k_accumulate, grid, block, 0, stream, a.settings, a.frame_count, a.camera, a.prev_camera,
-                       Img{a.indirect_temp, IW, IH}, img(a.normals), img(a.indirect_history[src]), img(a.moments_history[src]), img(a.prev_normal_depth),
-                       a.indirect_history[dst], a.moments_history[dst]);
+    if (fast)
+        hipLaunchKernelGGL(k_accumulate<true>, grid, block, 0, stream, a.settings, a.frame_count, a.camera, a.prev_camera,
+                           Img{a.indirect_temp, IW, IH}, img(a.normals), img(a.indirect_history[src]), img(a.moments_history[src]), img(a.prev_normal_depth),
+                           a.indirect_history[dst], a.moments_history[dst]);
+    else
+        hipLaunchKernelGGL(k_accumulate<false>, grid, block, 0, stream, a.settings, a.frame_count, a.camera, a.prev_camera,
+                           Img{a.indirect_temp, IW, IH}, img(a.normals), img(a.indirect_history[src]), img(a.moments_history[src]), img(a.prev_normal_depth),
+                           a.indirect_history[dst], a.moments_history[dst]);
     // Denoise (cpp:1437-1538)
     mark(2);
     if (a.settings.denoise)
@@ -816,6 +998,8 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
         else { KERNEL_UV_F(false, false, __VA_ARGS__); }                              \
     }
 #define CAP_STENCIL(UV, F, KIND, R, IN, MOM, OUT) hipLaunchKernelGGL((k_stencil_lds<KIND, R, UV, F>), xgrid, block, 0, stream, a.settings, IN, img(a.normals), MOM, OUT)
+#define CAP_STENCIL_DUAL(UV, F, IN, MOM, OUT, ALT) \
+    hipLaunchKernelGGL((k_stencil_lds<kBlur, 2, UV, F, false, true>), xgrid, block, 0, stream, a.settings, IN, img(a.normals), MOM, OUT, 0u, nullptr, ALT)
 #define CAP_PHASE(UV, F, S, CB, IN, OUT)                                                                                                        \
     hipLaunchKernelGGL((k_blur_phase<S, UV, F, CB>), pgrid, pblock, 0, stream, a.settings, IN, img(a.normals), OUT, (CB) ? a.albedo : nullptr,   \
                        (CB) ? a.direct : nullptr, a.tiled, ptx, ptp)
@@ -823,7 +1007,8 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
             const bool last = last_pass && fuse_combine;
             if (stride == 1u)
             {
-                CAP_MODES(CAP_STENCIL, kBlur, 2, img(in), none, out);
+                // (`in` = BlurDisocclusion's sparse output: see stage_texel DUAL)
+                CAP_MODES(CAP_STENCIL_DUAL, img(a.indirect_history[dst]), img(a.moments_history[dst]), out, in);
                 return;
             }
             const uint32_t ptx = (W + kPhaseW - 1) / kPhaseW, ptp = phase_tiles_per_phase(H, stride);
@@ -847,6 +1032,7 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
             blur(7u, a.temp[1], a.temp[0], true);
         }
 #undef CAP_PHASE
+#undef CAP_STENCIL_DUAL
 #undef CAP_STENCIL
 #undef CAP_MODES
         mark(3);
@@ -861,8 +1047,12 @@ void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
     }
     // ApplyTAA (cpp:1344-1398)
     mark(4);
-    hipLaunchKernelGGL(k_taa, grid, block, 0, stream, a.settings, a.camera, a.prev_camera, img(a.temp[0]), img(a.normals),
-                       img(a.combined_history[src]), a.combined_history[dst]);
+    if (a.settings.fast_weights)
+        hipLaunchKernelGGL(k_taa<true>, grid, block, 0, stream, a.settings, a.camera, a.prev_camera, img(a.temp[0]), img(a.normals),
+                           img(a.combined_history[src]), a.combined_history[dst]);
+    else
+        hipLaunchKernelGGL(k_taa<false>, grid, block, 0, stream, a.settings, a.camera, a.prev_camera, img(a.temp[0]), img(a.normals),
+                           img(a.combined_history[src]), a.combined_history[dst]);
     // CopyGBuffer of the next frame (cpp:955-1009): the caller makes `normals` the next call's `prev_normal_depth` (two buffers
     // changing roles; copying the image cost 7 us per 1080p frame)
     mark(5);
