@@ -177,6 +177,7 @@ struct CapContext
     // memory: cap_render does not try that size or a larger one again (every call repeated ~28 GB of hipMalloc / hipFree).
     uint64_t      lane1_failed_paths = 0;
     uint32_t      lanes_last_render = 0;       // cap_debug_get(CAP_DEBUG_LANES_USED)
+    uint32_t      last_class_capacity = 0;     // sub-queue capacity of the last cap_render batch (CAP_DEBUG_QUEUE_CANARY_*)
     uint32_t      traversal_mode  = CAP_TRAVERSAL_AUTO;
     uint32_t      bvh_build_mode  = CAP_BVH_BUILD_AUTO;
 
@@ -1024,6 +1025,42 @@ int cap_set_batch_paths(CapContext* c, uint64_t max_paths)
     return CAP_OK;
 }
 
+// Canary for the append-guard test (tests/test_append_guard_gpu.py): the extension queues' six planes of lane 0 are filled with one
+// word; after a render with undersized sub-queues every entry BEHIND the last class's sub-queue must still hold it.
+constexpr uint32_t kCanaryWord = 0x7fc0da7au;  // (a quiet NaN nobody computes)
+__global__ __launch_bounds__(256) void k_canary_count(const uint4* p, size_t begin, size_t end, unsigned long long* out)
+{
+    unsigned long long n = 0;
+    for (size_t i = begin + blockIdx.x * (size_t)256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256)
+    {
+        const uint4 v = p[i];
+        n += (v.x != kCanaryWord || v.y != kCanaryWord || v.z != kCanaryWord || v.w != kCanaryWord) ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(out, n);
+}
+static int canary_count(CapContext* c, bool behind, uint64_t* value)
+{
+    if (!c->q_org[0].p || !c->last_class_capacity) return fail(CAP_ERR_STATE, "cap_debug_get: no render yet");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(*d)));
+    HIP_TRY(hipMemsetAsync(d, 0, sizeof(*d), c->stream));
+    const size_t used = std::min((size_t)kQueueClasses * c->last_class_capacity, c->q_org[0].n);
+    for (int k = 0; k < 2; ++k)
+        for (DevBuf<float4>* b : {&c->q_org[k], &c->q_dir[k], &c->q_thr[k]})
+        {
+            const size_t lo = behind ? used : 0, hi = behind ? b->n : used;
+            if (hi > lo) hipLaunchKernelGGL(k_canary_count, dim3(512), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(b->p), lo, hi, d);
+        }
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(d);
+    *value = h;
+    return CAP_OK;
+}
+
 int cap_debug_set(CapContext* c, uint32_t key, uint64_t value)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_debug_set: ctx is NULL");
@@ -1035,6 +1072,13 @@ int cap_debug_set(CapContext* c, uint32_t key, uint64_t value)
         return CAP_OK;
     case CAP_DEBUG_WIDE_DEPTH_LIMIT:
         c->debug_wide_depth_limit = (uint32_t)value;
+        return CAP_OK;
+    case CAP_DEBUG_QUEUE_CANARY_FILL:
+        if (!c->q_org[0].p) return fail(CAP_ERR_STATE, "cap_debug_set: the queues are allocated by the first cap_render");
+        HIP_TRY(hipSetDevice(c->device));
+        for (int k = 0; k < 2; ++k)
+            for (DevBuf<float4>* b : {&c->q_org[k], &c->q_dir[k], &c->q_thr[k]})
+                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)b->p, (int)kCanaryWord, b->n * 4, c->stream));
         return CAP_OK;
     case CAP_DEBUG_FAIL_LANE1:
         c->debug_fail_lane1 = value != 0;
@@ -1053,6 +1097,8 @@ int cap_debug_get(CapContext* c, uint32_t key, uint64_t* value)
     case CAP_DEBUG_WIDE_DEPTH_LIMIT: *value = c->debug_wide_depth_limit; return CAP_OK;
     case CAP_DEBUG_FAIL_LANE1: *value = c->debug_fail_lane1 ? 1u : 0u; return CAP_OK;
     case CAP_DEBUG_LANES_USED: *value = c->lanes_last_render; return CAP_OK;
+    case CAP_DEBUG_QUEUE_CANARY_BEHIND: return canary_count(c, true, value);
+    case CAP_DEBUG_QUEUE_CANARY_USED: return canary_count(c, false, value);
     case CAP_DEBUG_WIDE_IN_USE:
         if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_debug_get: BVH not built");
         *value = bvh_dev(c).wide8_ok;
@@ -1319,6 +1365,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         uint32_t       class_capacity = ((total_chunks + kQueueClasses - 1) / kQueueClasses) * 64u;
         // (tests of the append guard: sub-queues deliberately too small -- the appends beyond them must be dropped and counted)
         if (c->debug_capacity_div > 1) class_capacity = std::max(64u, (class_capacity / c->debug_capacity_div) & ~63u);
+        c->last_class_capacity = class_capacity;
         const bool     last_batch = done + ns >= n_frames;
         const uint32_t aov_slot   = ((flags & CAP_RENDER_AOV) && last_batch) ? ns - 1 : ~0u;
         const uint32_t max_count  = ns * Ppad;

@@ -233,7 +233,14 @@ enum
     /* FAIL_LANE1 (0 / 1): the allocation of cap_render's second batch lane fails (what running out of HBM does), so that the one-lane
      * fallback and CapStats::lane1_dropped can be tested; LANES_USED (read-only): the lanes the last cap_render ran on (1 or 2). */
     CAP_DEBUG_FAIL_LANE1         = 4,
-    CAP_DEBUG_LANES_USED         = 5
+    CAP_DEBUG_LANES_USED         = 5,
+    /* Canary behind the last queue class (the append guard's direct proof).  CANARY_FILL (set, after a first cap_render has allocated
+     * them): every entry of the context's extension-queue planes takes one marker word.  CANARY_BEHIND (get): entries BEHIND the 64
+     * sub-queues of the last render (index >= 64 x its sub-queue capacity) that no longer hold the marker -- 0 unless something wrote
+     * past the last class; CANARY_USED (get): the same count inside the sub-queues (> 0 after any render: the check can see writes). */
+    CAP_DEBUG_QUEUE_CANARY_FILL   = 6,
+    CAP_DEBUG_QUEUE_CANARY_BEHIND = 7,
+    CAP_DEBUG_QUEUE_CANARY_USED   = 8
 };
 int cap_debug_set(CapContext* ctx, uint32_t key, uint64_t value);
 int cap_debug_get(CapContext* ctx, uint32_t key, uint64_t* value);

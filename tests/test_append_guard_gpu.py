@@ -49,12 +49,20 @@ def test_guard_fires_and_nothing_is_written_out_of_bounds(native_lib, cornell_pa
     ref_stats = ref_r.stats()
     assert ref_stats.guard_append == 0 and ref_stats.guard_shade == 0 and ref_stats.guard_trace_any == 0
 
-    # sub-queues at a quarter of what the classes need: most of bounce 0's appends run past them
+    # sub-queues at a quarter of what the classes need: most of bounce 0's appends run past them.  Three quarters of every queue
+    # plane then lie BEHIND the last class's sub-queue: a canary word there proves directly that no append left its sub-queue
+    # (a first render of the same shape allocates the queues at their final size; the marker goes in after it)
+    r.render(0, spp, depth, flags)
+    r.accum_reset()
+    r.stats_reset()
     r.debug_set(capi.Renderer.DEBUG_QUEUE_CAPACITY_DIV, 4)
+    r.debug_set(capi.Renderer.DEBUG_QUEUE_CANARY_FILL, 1)
     r.render(0, spp, depth, flags)
     got = r.readback(capi.BUF_ACCUM_SUM)
     s = r.stats()
     assert s.guard_append > 0, "the append guard did not fire on undersized sub-queues"
+    assert r.debug_get(capi.Renderer.DEBUG_QUEUE_CANARY_USED) > 0  # the check sees writes ...
+    assert r.debug_get(capi.Renderer.DEBUG_QUEUE_CANARY_BEHIND) == 0, "an append was stored behind the last queue class"
     assert s.guard_shade == 0 and s.guard_trace_any == 0  # no malformed entry was READ either: consumers clamp to the capacity
     assert np.isfinite(got).all() and (got[..., 3] == spp).all()
     # dropped paths lose their indirect light, nothing else: the image is not the reference one ...
