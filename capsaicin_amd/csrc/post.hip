@@ -478,6 +478,14 @@ struct TapCenter
     float f_depth, f_luma;            // fast mode: -log2(e) / sigma (0 where the reference's sigma is 0: weight 1)
 };
 
+// filtered += c * k.  Exact mode: a product and a sum, as the oracle rounds them (-ffp-contract=off).  Fast mode: three fused multiply-adds
+// (the compiler may not contract, so the toleranced mode writes them out: 4 of a tap's ~27 instructions less).
+template <bool FAST>
+__device__ __forceinline__ v3 acc3(v3 f, v3 c, float k)
+{
+    return FAST ? mk3(fmaf(c.x, k, f.x), fmaf(c.y, k, f.y), fmaf(c.z, k, f.z)) : f + c * k;
+}
+
 // Weights of one tap.  Exact: wgt = normal * depth (the reference's first two factors, in its order) and lw = the luminance weight
 // (1 when the pass has none).  Fast: wgt = the whole product from one exponential, lw = 1.
 // len / inv_len: length(float2(dx, dy)) of the tap and its reciprocal (0 for the centre: the reference's sigma * 0 gives weight 1).
@@ -638,19 +646,22 @@ __global__ __launch_bounds__(kBlock) void k_stencil_lds(PostSettingsDev s, Img c
                 {
                     const float hw = USE_VAR ? atrous_kernel(dx) * atrous_kernel(dy) : 1.0f;
                     const float kk = FAST ? wgt * hw : wgt * hw * lw;
-                    filtered = filtered + c * kk;
+                    filtered = acc3<FAST>(filtered, c, kk);
                     total += kk;
-                    if (USE_VAR) a0 += FAST ? (kk * kk) * v.w : hw * hw * wgt * wgt * lw * lw * v.w;
+                    if (USE_VAR) a0 = FAST ? fmaf(kk * kk, v.w, a0) : a0 + hw * hw * wgt * wgt * lw * lw * v.w;
                 }
                 else
                 {
                     const float w = FAST ? wgt : wgt * lw;
-                    filtered = filtered + c * w;
+                    filtered = acc3<FAST>(filtered, c, w);
                     total += w;
                     if (KIND == kDisocclusion)
                     {
                         const float2 m = t_mom[e];
-                        a0 += w * m.x, a1 += w * m.y;
+                        if (FAST)
+                            a0 = fmaf(w, m.x, a0), a1 = fmaf(w, m.y, a1);
+                        else
+                            a0 += w * m.x, a1 += w * m.y;
                     }
                 }
             }
@@ -692,7 +703,11 @@ __global__ __launch_bounds__(kPhaseW * kPhaseH) void k_blur_phase(PostSettingsDe
         const int ty = e / TW, txx = e - ty * TW;
         float4    c, g;
         float2    mm;
+#if defined(CAP_POST_DIAG) && CAP_POST_DIAG == 1  // diagnostic: no staging loads
+        c = make_float4(0.5f, 0.4f, 0.3f, 0.1f), g = make_float4(0.f, 0.f, 1.f, 1.f + 0.001f * (float)txx);
+#else
         stage_texel<true, false>(color, nd, nd, x0 + txx, (int)py + STRIDE * (j0 + ty), c, g, mm);
+#endif
         t_col[e] = c, t_nd[e] = g;
     }
     __syncthreads();
@@ -705,7 +720,11 @@ __global__ __launch_bounds__(kPhaseW * kPhaseH) void k_blur_phase(PostSettingsDe
     k.cn = xyz(cg), k.cd = cg.w, k.cc = remove_fireflies(cv), k.lcc = luminance(k.cc);
     const float cvar = USE_VAR ? cv.w : 0.0f;
     float4      res  = make_float4(k.cc.x, k.cc.y, k.cc.z, cvar);
+#if defined(CAP_POST_DIAG) && CAP_POST_DIAG == 2  // diagnostic: no taps
+    if (k.cd < -1.0f)
+#else
     if (!(k.cd < 1e-5f))
+#endif
     {
         k.s_normal = s.eaw_normal_sigma;
         k.s_depth  = k.cd * (float)STRIDE * s.eaw_depth_sigma;
@@ -728,9 +747,9 @@ __global__ __launch_bounds__(kPhaseW * kPhaseH) void k_blur_phase(PostSettingsDe
                 wgt = (g.w < 1e-5f) ? 0.0f : wgt;
                 const float hw = USE_VAR ? atrous_kernel(dx) * atrous_kernel(dy) : 1.0f;
                 const float kk = FAST ? wgt * hw : wgt * hw * lw;
-                filtered = filtered + c * kk;
+                filtered = acc3<FAST>(filtered, c, kk);
                 total += kk;
-                if (USE_VAR) fvar += FAST ? (kk * kk) * v.w : hw * hw * wgt * wgt * lw * lw * v.w;
+                if (USE_VAR) fvar = FAST ? fmaf(kk * kk, v.w, fvar) : fvar + hw * hw * wgt * wgt * lw * lw * v.w;
             }
         const bool  empty = total < kEpsPost;
         const float rt    = FAST ? fast_rcp(total) : 0.f;
@@ -881,7 +900,7 @@ __global__ __launch_bounds__(kBlock) void k_taa(PostSettingsDev s, CameraDev cam
         {
             const v3 v = lds_tap[(ly + 2 + j) * kTaaTileW + (lx + 2 + i)];
             m1 = m1 + v;
-            m2 = m2 + v * v;
+            m2 = FAST ? mk3(fmaf(v.x, v.x, m2.x), fmaf(v.y, v.y, m2.y), fmaf(v.z, v.z, m2.z)) : m2 + v * v;
         }
     const float inv_n = 1.0f / 25.0f;
     m1 = m1 * inv_n, m2 = m2 * inv_n;
