@@ -147,7 +147,15 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
         }
         W8_COUNT(2, lane == 0 ? 1 : 0);
         WideNode nd;
-        nd.h0 = nd.h1 = nd.q2 = nd.q3 = nd.q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // "defined, whatever it holds": a lane that does not load never reads these, so no instruction is spent on a value for it
+        // (zero-initialising the 20 registers was 20 moves per iteration; leaving the struct uninitialised made the allocator spill)
+#define CAP_DEF4(v) asm volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
+        CAP_DEF4(nd.h0);
+        CAP_DEF4(nd.h1);
+        CAP_DEF4(nd.q2);
+        CAP_DEF4(nd.q3);
+        CAP_DEF4(nd.q4);
+#undef CAP_DEF4
         if (alive) nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2], nd.q3 = src[3];
         if (node_lane) nd.q4 = src[4];
         if (tri_lane)
@@ -289,7 +297,13 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_any8_refill(Bvh
             src = bvh.nodes8 + (kWideNodeStride / 4u) * (size_t)node;
         }
         WideNode nd;
-        nd.h0 = nd.h1 = nd.q2 = nd.q3 = nd.q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define CAP_DEF4(v) asm volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))  // (see k_trace_closest8)
+        CAP_DEF4(nd.h0);
+        CAP_DEF4(nd.h1);
+        CAP_DEF4(nd.q2);
+        CAP_DEF4(nd.q3);
+        CAP_DEF4(nd.q4);
+#undef CAP_DEF4
         if (alive) nd.h0 = src[0], nd.h1 = src[1], nd.q2 = src[2];
         if (node_lane) nd.q3 = src[3], nd.q4 = src[4];  // (a triangle lane needs 48 of its record's 64 bytes: no id for an occlusion test)
         bool occluded = false;
