@@ -334,7 +334,10 @@ typedef struct CapPostSettings
                                           no luma edge-stopping and no a-trous kernel weights in Blur, variance channel 0 */
     int32_t fast_weights;              /* false.  Not a reference option: evaluates the edge-stopping weights with the hardware's
                                           v_exp_f32 / v_log_f32 / v_rcp_f32 instead of the arithmetic contract's polynomials and IEEE
-                                          divisions.  The exact mode (0) is bit-identical to the oracle; this one is held to a stated
+                                          divisions, and (round 5) the VALUES of IntegrateTemporally and TAA with the same instructions
+                                          and the centre tap of their bicubic resamples -- what those two passes DECIDE (reprojection,
+                                          disocclusion test, static / moving) stays the exact arithmetic on the same G-buffer, so both
+                                          modes reset and blend at the same pixels.  The exact mode (0) is bit-identical to the oracle; this one is held to a stated
                                           tolerance against it over a multi-frame sequence (tests/test_post_gpu.py), per colour channel
                                           with e = |fast - exact| / (|exact| + 1e-3): median e <= 2e-5, 99 % of the channels
                                           e <= 4e-3, every channel e <= 3e-2 (TAA's variance clipping amplifies in flat regions) */
