@@ -206,6 +206,9 @@ struct PostChainArgs
 };
 // The frame's output is combined_history[frame_count % 2] (raytracing_system.cpp:320-324).
 void launch_post_chain(hipStream_t stream, const PostChainArgs& a);
+// post.hip's unscaled IEEE division against the compiler's, on the device: out[0] mismatches of log2 over every normal float,
+// out[1] over 2^30 operand pairs of the range it is used on (both must be 0; cap_debug_get(CAP_DEBUG_SELFTEST_DIV))
+void launch_div_selftest(hipStream_t stream, unsigned long long* out_device);
 // out[(y, x)] = full[(2y + oy, 2x + ox)]: the half-resolution indirect image of LOWRES_INDIRECT (rt_indirect.hlsl:53-59, :176)
 void launch_decimate2x(hipStream_t stream, const float4* full, uint32_t width, uint32_t height, uint32_t ox, uint32_t oy, float4* out);
 }  // namespace cap

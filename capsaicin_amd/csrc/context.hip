@@ -1097,6 +1097,20 @@ int cap_debug_get(CapContext* c, uint32_t key, uint64_t* value)
     case CAP_DEBUG_WIDE_DEPTH_LIMIT: *value = c->debug_wide_depth_limit; return CAP_OK;
     case CAP_DEBUG_FAIL_LANE1: *value = c->debug_fail_lane1 ? 1u : 0u; return CAP_OK;
     case CAP_DEBUG_LANES_USED: *value = c->lanes_last_render; return CAP_OK;
+    case CAP_DEBUG_SELFTEST_DIV:
+    {
+        HIP_TRY(hipSetDevice(c->device));
+        unsigned long long* d = nullptr;
+        unsigned long long  h[2] = {0, 0};
+        HIP_TRY(hipMalloc(&d, sizeof(h)));
+        HIP_TRY(hipMemsetAsync(d, 0, sizeof(h), c->stream));
+        launch_div_selftest(c->stream, d);
+        HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(d);
+        *value = h[0] + h[1];
+        return CAP_OK;
+    }
     case CAP_DEBUG_QUEUE_CANARY_BEHIND: return canary_count(c, true, value);
     case CAP_DEBUG_QUEUE_CANARY_USED: return canary_count(c, false, value);
     case CAP_DEBUG_WIDE_IN_USE:

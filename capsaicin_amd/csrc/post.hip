@@ -8,6 +8,8 @@
 #include "cap_kernels.h"
 #include "cap_reproject.h"
 
+#include <type_traits>
+
 namespace cap
 {
 namespace
@@ -42,21 +44,13 @@ __device__ __forceinline__ float    lerp1(float a, float b, float t) { return a 
 __device__ __forceinline__ v3       div3(v3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 __device__ __forceinline__ float    luminance(v3 c) { return dot3(c, mk3(0.299f, 0.587f, 0.114f)); }
 
-// exp(x), x <= 0, and pow(x, s), x in [0,1]: the exp2/log2 polynomials of the arithmetic contract (cap_math.h)
+// exp(x), x <= 0 (pow(x, s), x in [0, 1]: pow01_t below): the exp2 / log2 polynomials of the arithmetic contract (cap_math.h)
 __device__ __forceinline__ float exp_neg(float x)
 {
     const float y = x * 1.44269504088896341f;
     if (!(y >= -125.0f)) return 0.0f;
     return exp2_c(y);
 }
-__device__ __forceinline__ float pow01(float x, float s)
-{
-    if (!(x >= 1.17549435e-38f)) return 0.0f;
-    const float y = s * log2_c(x);
-    if (!(y >= -125.0f)) return 0.0f;
-    return exp2_c(y);
-}
-
 // math_functions.h:60-77
 __device__ __forceinline__ float cubic(float x, float b, float c)
 {
@@ -123,14 +117,75 @@ __device__ __forceinline__ v3 oct_decode(float fx, float fy)
     n.y += n.y >= 0.0f ? -t : t;
     return normalize3(n);
 }
-// eaw_edge_stopping.h
-__device__ __forceinline__ float normal_weight(v3 n0, v3 n1, float s) { return pow01(fmaxf(dot3(n0, n1), 0.0f), s); }
-__device__ __forceinline__ float depth_weight(float dc, float dp, float s)
+// ---- IEEE division without its scaling steps (exact mode, round 5) ----
+// hipcc expands a / b into v_div_scale x 2, v_rcp, seven FMAs, v_div_fmas and v_div_fixup: ~47 SIMD cycles, four times per tap of
+// the exact stencils.  The two v_div_scale only act when an exponent is extreme -- a denormal or huge denominator, a numerator below
+// 2^-103, a quotient that would be denormal or whose exponents differ by 96 or more (CDNA ISA, V_DIV_SCALE_F32) --, and
+// v_div_fixup only on zeros, infinities and NaNs; everywhere else they pass their operands through and what remains is the
+// sequence below: the same instructions on the same operands, so the same bits (29 cycles).  `div_unscaled` is therefore ONLY called
+// where the operands are known to be in range -- |a| = 0 or in [2^-80, 2^41], b in [2^-40, 2^40] -- which the stencil kernels
+// establish per tile while staging (depths in [1e-5, 2^40], luminances 0 or in [2^-50, 2^30], the pixel's sigmas in [2^-38, 2^38];
+// a tile or wave that fails takes the IEEE form: the same result by definition).  cap_debug_get(CAP_DEBUG_SELFTEST_DIV) compares both
+// forms on the device: every float for log2's (m - 1) / (m + 1), 2^30 pseudo-random pairs over the whole stated range for the rest.
+__device__ __forceinline__ float div_unscaled(float a, float b)
 {
-    const float t = s == 0.0f ? 0.0f : (fabsf(dc - dp) / s);
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = fmaf(-b, r0, 1.0f);
+    const float r  = fmaf(e0, r0, r0);
+    const float q0 = a * r;
+    const float e1 = fmaf(-b, q0, a);
+    const float q1 = fmaf(e1, r, q0);
+    const float e2 = fmaf(-b, q1, a);
+    return fmaf(e2, r, q1);
+}
+template <bool NS>
+__device__ __forceinline__ float div_c(float a, float b)
+{
+    return NS ? div_unscaled(a, b) : a / b;
+}
+constexpr float kDivHi = 1.0995116e12f /* 2^40 */;
+__device__ __forceinline__ bool div_sigma_ok(float s) { return s == 0.0f || (s >= 3.637979e-12f /* 2^-38 */ && s <= 2.7487791e11f /* 2^38 */); }
+__device__ __forceinline__ bool div_depth_ok(float d) { return d < 1e-5f || d <= kDivHi; }  // (NaN: both compares false)
+__device__ __forceinline__ bool div_luma_ok(float l) { return l == 0.0f || (l >= 8.8817842e-16f /* 2^-50 */ && l <= 1.0737418e9f /* 2^30 */); }
+
+// cap_math.h log2_c with the unscaled division: m in (0.7071, 1.4143], so (m - 1) in [-0.293, 0.415] is 0 or at least 2^-24 in
+// magnitude and (m + 1) in [1.7, 2.42] -- never scaled, whatever x (compared for every float by the self-test)
+__device__ __forceinline__ float log2_c_ns(float x)
+{
+    const uint32_t b = f2u(x);
+    int            e = (int)((b >> 23) & 0xffu) - 127;
+    float          m = u2f((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f)
+    {
+        m *= 0.5f;
+        e += 1;
+    }
+    const float s = div_unscaled(m - 1.0f, m + 1.0f);
+    const float z = s * s;
+    const float p = fmaf(z, fmaf(z, fmaf(z, fmaf(z, 0.111111111111f, 0.142857142857f), 0.2f), 0.333333333333f), 1.0f);
+    return fmaf((2.0f * s) * p, 1.44269504088896341f, (float)e);
+}
+template <bool NS>
+__device__ __forceinline__ float pow01_t(float x, float s)
+{
+    if (!(x >= 1.17549435e-38f)) return 0.0f;
+    const float y = s * (NS ? log2_c_ns(x) : log2_c(x));
+    if (!(y >= -125.0f)) return 0.0f;
+    return exp2_c(y);
+}
+
+// eaw_edge_stopping.h (NS: divisions in the unscaled form, see div_unscaled)
+template <bool NS = false>
+__device__ __forceinline__ float normal_weight(v3 n0, v3 n1, float s) { return pow01_t<NS>(fmaxf(dot3(n0, n1), 0.0f), s); }
+// (NS: the caller has established s_depth > 0, so sigma = s_depth * length(tap) is 0 exactly at the centre tap)
+template <bool NS = false>
+__device__ __forceinline__ float depth_weight(float dc, float dp, float s, bool centre = false)
+{
+    const float t = NS ? (centre ? 0.0f : div_unscaled(fabsf(dc - dp), s)) : (s == 0.0f ? 0.0f : fabsf(dc - dp) / s);
     return exp_neg(-t);
 }
-__device__ __forceinline__ float luma_weight(float lc, float lp, float s) { return exp_neg(-(fabsf(lc - lp) / s)); }
+template <bool NS = false>
+__device__ __forceinline__ float luma_weight(float lc, float lp, float s) { return exp_neg(-div_c<NS>(fabsf(lc - lp), s)); }
 
 // CapPostSettings::fast_weights: the same three weights through the hardware's transcendental instructions -- v_log_f32 / v_exp_f32
 // (base 2, 1 ulp) and v_rcp_f32 instead of the contract's polynomials and IEEE divisions: ~12 instructions where the exact forms
@@ -489,8 +544,8 @@ __device__ __forceinline__ v3 acc3(v3 f, v3 c, float k)
 // Weights of one tap.  Exact: wgt = normal * depth (the reference's first two factors, in its order) and lw = the luminance weight
 // (1 when the pass has none).  Fast: wgt = the whole product from one exponential, lw = 1.
 // len / inv_len: length(float2(dx, dy)) of the tap and its reciprocal (0 for the centre: the reference's sigma * 0 gives weight 1).
-template <bool FAST, bool LUMA>
-__device__ __forceinline__ void tap_weights(const TapCenter& k, float4 g, v3 c, float len, float inv_len, float& wgt, float& lw)
+template <bool FAST, bool LUMA, bool NS = false>
+__device__ __forceinline__ void tap_weights(const TapCenter& k, float4 g, v3 c, float len, float inv_len, float& wgt, float& lw, bool centre = false)
 {
     if (FAST)
     {
@@ -501,8 +556,8 @@ __device__ __forceinline__ void tap_weights(const TapCenter& k, float4 g, v3 c, 
     }
     else
     {
-        wgt = normal_weight(k.cn, xyz(g), k.s_normal) * depth_weight(k.cd, g.w, k.s_depth * len);
-        lw  = LUMA ? luma_weight(k.lcc, luminance(c), k.s_luma) : 1.0f;
+        wgt = normal_weight<NS>(k.cn, xyz(g), k.s_normal) * depth_weight<NS>(k.cd, g.w, k.s_depth * len, centre);
+        lw  = LUMA ? luma_weight<NS>(k.lcc, luminance(c), k.s_luma) : 1.0f;
     }
 }
 
@@ -516,9 +571,10 @@ __device__ __forceinline__ void tap_weights(const TapCenter& k, float4 g, v3 c, 
 // pixel needed its 7 x 7 filter; a pixel that BlurDisocclusion passes through (background, or a history of eight frames: most of
 // the image most of the time) is taken from `color` as that pass would have written it -- its fireflies clamped, which CLAMP does
 // here anyway, and its variance kept -- so in the steady state BlurDisocclusion neither reads nor writes an image.
+// `ok` (exact mode): the texel's depth and luminance are in the range div_unscaled is used on.
 template <bool CLAMP, bool MOMENTS, bool TILED = false, bool DUAL = false>
 __device__ __forceinline__ void stage_texel(const Img& color, const Img& nd, const Img& moments, int sx, int sy, float4& c, float4& g, float2& mm,
-                                            uint32_t tiles_x = 0, const float4* alt = nullptr)
+                                            uint32_t tiles_x = 0, const float4* alt = nullptr, bool* ok = nullptr)
 {
     const bool   in = sx >= 0 && sy >= 0 && sx < (int)color.w && sy < (int)color.h;
     // (clamped address: the loads are unconditional, their values selected)
@@ -546,6 +602,7 @@ __device__ __forceinline__ void stage_texel(const Img& color, const Img& nd, con
     c  = make_float4(take ? cx : 0.f, take ? cy : 0.f, take ? cz : 0.f, take ? v.w : 0.f);
     g  = make_float4(in ? gv.x : 0.f, in ? gv.y : 0.f, in ? gv.z : 0.f, in ? gv.w : 0.f);
     mm = make_float2(take ? m0 : 0.f, take ? m1 : 0.f);
+    if (ok) *ok = div_depth_ok(g.w) && div_luma_ok(luminance(xyz(c)));
 }
 
 // Stride-1 stencils on a 32 x 8 pixel tile + halo R: Gather (R = 3), BlurDisocclusion (R = 3), the first a-trous pass (R = 2).
@@ -596,17 +653,25 @@ __global__ __launch_bounds__(kBlock) void k_stencil_lds(PostSettingsDev s, Img c
         needs_taps = __syncthreads_or((in_image && !pass) ? 1 : 0) != 0;
         if (!needs_taps) return;  // every pixel of the tile passes through: the first a-trous pass reads them where they are (DUAL)
     }
+    bool tile_ok = true;  // exact mode: every staged depth and luminance is in div_unscaled's range (workgroup-uniform)
     if (needs_taps)
     {
+        bool bad = false;
         for (int e = (int)threadIdx.x; e < TW * TH; e += (int)kBlock)
         {
             float4 c, g;
             float2 mm;
-            stage_texel<KIND != kGather, KIND == kDisocclusion, TILED, DUAL>(color, nd, moments, x0 + e % TW, y0 + e / TW, c, g, mm, tiles_x, alt);
+            bool   ok = true;
+            stage_texel<KIND != kGather, KIND == kDisocclusion, TILED, DUAL>(color, nd, moments, x0 + e % TW, y0 + e / TW, c, g, mm, tiles_x, alt,
+                                                                             FAST ? nullptr : &ok);
+            bad |= !ok;
             t_col[e] = c, t_nd[e] = g;
             if (KIND == kDisocclusion) t_mom[e] = mm;
         }
-        __syncthreads();
+        if (FAST)
+            __syncthreads();
+        else
+            tile_ok = __syncthreads_or(bad ? 1 : 0) == 0;
     }
     if (!in_image) return;
     TapCenter k;
@@ -627,6 +692,11 @@ __global__ __launch_bounds__(kBlock) void k_stencil_lds(PostSettingsDev s, Img c
         v3             filtered = mk3(0.f, 0.f, 0.f);
         float          total = 0.0f, a0 = 0.0f, a1 = 0.0f;  // a0: variance sum (Blur) or first moment (Disocclusion); a1: second moment
         const int      lc = ((int)(threadIdx.x >> 5) + R) * TW + (int)(threadIdx.x & 31u) + R;
+        // exact mode: the divisions of the three weights in their unscaled form where the tile's texels and this wave's sigmas allow it
+        // (div_unscaled); the IEEE form otherwise -- the same bits either way
+        const bool wave_ok = !FAST && tile_ok && __ballot(!(div_sigma_ok(k.s_depth) && k.s_depth != 0.0f && div_sigma_ok(k.s_luma) && k.s_luma != 0.0f && div_depth_ok(k.cd) && k.cd >= 1e-5f)) == 0ull;
+        auto taps = [&](auto ns_tag) {
+            constexpr bool NS = decltype(ns_tag)::value;
         // fast mode: fully unrolled (offsets, tap lengths and kernel weights fold into immediates; ~25 instructions per tap).  Exact
         // mode: one row of taps per iteration -- at ~150 instructions per tap a fully unrolled 7 x 7 body would be 50 KB of code that
         // every wave streams through once, against a 64-KB instruction cache shared by two CUs
@@ -640,7 +710,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil_lds(PostSettingsDev s, Img c
                 const float4 v = t_col[e], g = t_nd[e];
                 const v3     c = xyz(v);
                 float        wgt, lw;
-                tap_weights<FAST, LUMA>(k, g, c, kLen7.v[dy + 3][dx + 3], kInv7.v[dy + 3][dx + 3], wgt, lw);
+                tap_weights<FAST, LUMA, NS>(k, g, c, kLen7.v[dy + 3][dx + 3], kInv7.v[dy + 3][dx + 3], wgt, lw, dx == 0 && dy == 0);
                 wgt = (g.w < 1e-5f) ? 0.0f : wgt;
                 if (KIND == kBlur)
                 {
@@ -665,6 +735,11 @@ __global__ __launch_bounds__(kBlock) void k_stencil_lds(PostSettingsDev s, Img c
                     }
                 }
             }
+        };
+        if (wave_ok)
+            taps(std::true_type{});
+        else
+            taps(std::false_type{});
         const bool  empty = total < kEpsPost;
         const float rt    = FAST ? fast_rcp(total) : 0.f;
         const v3    r     = empty ? k.cc : (FAST ? filtered * rt : div3(filtered, total));
@@ -698,19 +773,26 @@ __global__ __launch_bounds__(kPhaseW * kPhaseH) void k_blur_phase(PostSettingsDe
     // linear tile index: columns fastest, then the 8-row groups of a phase (neighbours share 4 of their 12 staged rows), then the phase
     const uint32_t tx = t % tiles_x, rest = t / tiles_x, jt = rest % tiles_per_phase, py = rest / tiles_per_phase;
     const int      x0 = (int)tx * kPhaseW - HX, j0 = (int)jt * kPhaseH - 2;
+    bool           bad = false;
     for (int e = (int)threadIdx.x; e < TW * TH; e += kPhaseW * kPhaseH)
     {
         const int ty = e / TW, txx = e - ty * TW;
         float4    c, g;
         float2    mm;
+        bool      ok = true;
 #if defined(CAP_POST_DIAG) && CAP_POST_DIAG == 1  // diagnostic: no staging loads
         c = make_float4(0.5f, 0.4f, 0.3f, 0.1f), g = make_float4(0.f, 0.f, 1.f, 1.f + 0.001f * (float)txx);
 #else
-        stage_texel<true, false>(color, nd, nd, x0 + txx, (int)py + STRIDE * (j0 + ty), c, g, mm);
+        stage_texel<true, false>(color, nd, nd, x0 + txx, (int)py + STRIDE * (j0 + ty), c, g, mm, 0, nullptr, FAST ? nullptr : &ok);
 #endif
+        bad |= !ok;
         t_col[e] = c, t_nd[e] = g;
     }
-    __syncthreads();
+    bool tile_ok = true;  // (see k_stencil_lds)
+    if (FAST)
+        __syncthreads();
+    else
+        tile_ok = __syncthreads_or(bad ? 1 : 0) == 0;
     const int lx = (int)(threadIdx.x % kPhaseW), ly = (int)(threadIdx.x / kPhaseW);
     const int x = (int)tx * kPhaseW + lx, y = (int)py + STRIDE * ((int)jt * kPhaseH + ly);
     if (x >= W || y >= H) return;
@@ -733,6 +815,9 @@ __global__ __launch_bounds__(kPhaseW * kPhaseH) void k_blur_phase(PostSettingsDe
         v3          filtered = mk3(0.f, 0.f, 0.f);
         float       total = 0.0f, fvar = 0.0f;
         const int   lc = (ly + 2) * TW + lx + HX;
+        const bool wave_ok = !FAST && tile_ok && __ballot(!(div_sigma_ok(k.s_depth) && k.s_depth != 0.0f && div_sigma_ok(k.s_luma) && k.s_luma != 0.0f && div_depth_ok(k.cd))) == 0ull;
+        auto taps = [&](auto ns_tag) {
+            constexpr bool NS = decltype(ns_tag)::value;
         constexpr int UNROLL_Y = FAST ? 5 : 1;  // (see k_stencil_lds)
 #pragma unroll UNROLL_Y
         for (int dy = -2; dy <= 2; ++dy)
@@ -743,7 +828,7 @@ __global__ __launch_bounds__(kPhaseW * kPhaseH) void k_blur_phase(PostSettingsDe
                 const float4 v = t_col[e], g = t_nd[e];
                 const v3     c = xyz(v);
                 float        wgt, lw;
-                tap_weights<FAST, USE_VAR>(k, g, c, kLen7.v[dy + 3][dx + 3], kInv7.v[dy + 3][dx + 3], wgt, lw);
+                tap_weights<FAST, USE_VAR, NS>(k, g, c, kLen7.v[dy + 3][dx + 3], kInv7.v[dy + 3][dx + 3], wgt, lw, dx == 0 && dy == 0);
                 wgt = (g.w < 1e-5f) ? 0.0f : wgt;
                 const float hw = USE_VAR ? atrous_kernel(dx) * atrous_kernel(dy) : 1.0f;
                 const float kk = FAST ? wgt * hw : wgt * hw * lw;
@@ -751,6 +836,11 @@ __global__ __launch_bounds__(kPhaseW * kPhaseH) void k_blur_phase(PostSettingsDe
                 total += kk;
                 if (USE_VAR) fvar = FAST ? fmaf(kk * kk, v.w, fvar) : fvar + hw * hw * wgt * wgt * lw * lw * v.w;
             }
+        };
+        if (wave_ok)
+            taps(std::true_type{});
+        else
+            taps(std::false_type{});
         const bool  empty = total < kEpsPost;
         const float rt    = FAST ? fast_rcp(total) : 0.f;
         const v3    r     = empty ? k.cc : (FAST ? filtered * rt : div3(filtered, total));
@@ -927,7 +1017,40 @@ __global__ __launch_bounds__(kBlock) void k_taa(PostSettingsDev s, CameraDev cam
         out[o]     = make_float4(r.x, r.y, r.z, 1.0f);
     }
 }
+// cap_debug_get(CAP_DEBUG_SELFTEST_DIV): div_unscaled against the compiler's IEEE division, bit for bit, on the device.
+//   out[0]: log2_c_ns(x) != log2_c(x) over EVERY positive normal float x (the only division inside is (m - 1) / (m + 1));
+//   out[1]: div_unscaled(a, b) != a / b over 2^30 pseudo-random pairs that cover the range it is used on: a = 0 or in [2^-80, 2^42),
+//           b in [2^-40, 2^41), exponents and mantissas drawn independently.
+__device__ __forceinline__ uint32_t selftest_hash(uint32_t x)
+{
+    x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(kBlock) void k_div_selftest(unsigned long long* out)
+{
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x, total = gridDim.x * kBlock;
+    unsigned long long bad0 = 0, bad1 = 0;
+    for (uint64_t b = 0x00800000ull + tid; b <= 0x7f7fffffull; b += total)
+    {
+        const float x = u2f((uint32_t)b);
+        bad0 += f2u(log2_c_ns(x)) != f2u(log2_c(x)) ? 1u : 0u;
+    }
+    for (uint32_t i = tid; i < (1u << 30); i += total)
+    {
+        const uint32_t h0 = selftest_hash(i), h1 = selftest_hash(i ^ 0x9e3779b9u), h2 = selftest_hash(h0 + h1);
+        const uint32_t ea = 47u + h2 % 122u, eb = 87u + (h2 >> 8) % 81u;  // exponent fields: 2^-80 .. 2^41, 2^-40 .. 2^40
+        const float    a = (h2 >> 26) == 0u ? 0.0f : u2f((ea << 23) | (h0 & 0x007fffffu)), bb = u2f((eb << 23) | (h1 & 0x007fffffu));
+        bad1 += f2u(div_unscaled(a, bb)) != f2u(a / bb) ? 1u : 0u;
+    }
+    if (bad0) atomicAdd(&out[0], bad0);
+    if (bad1) atomicAdd(&out[1], bad1);
+}
 }  // namespace
+
+void launch_div_selftest(hipStream_t stream, unsigned long long* out_device)
+{
+    hipLaunchKernelGGL(k_div_selftest, dim3(4096), dim3(kBlock), 0, stream, out_device);
+}
 
 void launch_post_chain(hipStream_t stream, const PostChainArgs& a)
 {

@@ -240,7 +240,12 @@ enum
      * past the last class; CANARY_USED (get): the same count inside the sub-queues (> 0 after any render: the check can see writes). */
     CAP_DEBUG_QUEUE_CANARY_FILL   = 6,
     CAP_DEBUG_QUEUE_CANARY_BEHIND = 7,
-    CAP_DEBUG_QUEUE_CANARY_USED   = 8
+    CAP_DEBUG_QUEUE_CANARY_USED   = 8,
+    /* SELFTEST_DIV (get, ~0.5 s): the reconstruction chain's exact mode evaluates its per-tap divisions without the scaling steps of
+     * the compiler's IEEE expansion where the operands are in a range that never triggers them (post.hip div_unscaled); this runs both
+     * forms on the device -- every normal float through log2, 2^30 operand pairs over the whole range -- and returns the number of
+     * results that differ in any bit: 0. */
+    CAP_DEBUG_SELFTEST_DIV        = 9
 };
 int cap_debug_set(CapContext* ctx, uint32_t key, uint64_t value);
 int cap_debug_get(CapContext* ctx, uint32_t key, uint64_t* value);

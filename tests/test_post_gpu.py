@@ -64,6 +64,15 @@ def test_post_chain_parity_cornell(native_lib, bluenoise, cornell_path, settings
     r.close()
 
 
+def test_unscaled_division_is_the_ieee_division(native_lib):
+    """The exact mode's per-tap divisions skip the scaling steps of hipcc's IEEE expansion where the operands cannot trigger them
+    (post.hip div_unscaled; the stencil kernels establish the range per tile while staging and take the IEEE form otherwise).  Both forms
+    on the device, bit for bit: every positive normal float through the contract's log2, 2^30 operand pairs over the whole stated range."""
+    r = capi.Renderer(0)
+    assert r.debug_get(capi.Renderer.DEBUG_SELFTEST_DIV) == 0
+    r.close()
+
+
 @pytest.mark.parametrize("settings", [dict(), dict(use_variance=0), dict(eaw5=0, gather_luma_sigma=1.0)])
 def test_fast_weights_within_stated_tolerance(native_lib, bluenoise, cornell_path, settings):
     """CapPostSettings::fast_weights (hardware exp2 / log2 / rcp in the edge-stopping weights; not a reference option) against the
