@@ -83,8 +83,8 @@ def test_fast_weights_within_stated_tolerance(native_lib, bluenoise, cornell_pat
     Why a distribution and not one number: the weights themselves agree to ~1e-5 (the exact mode's polynomials are the LESS accurate
     side), but TAA clips the history to mean +- scale * sqrt(|m2 - m1^2|) of a 5x5 neighbourhood (temporal_accumulation.hlsl:98-137):
     in a flat region the variance is a cancellation residue, its square root turns a 1e-5 input difference into a 1e-2 box
-    difference, and the static branch feeds 98 % of it back.  Measured (tools/fast_err.py): median 5e-6, 99th percentile 2e-3,
-    maximum 1.3e-2.  The reference's own RGBA16F storage perturbs the same inputs by 5e-4.  The exact mode is held to 0 above."""
+    difference, and the static branch feeds 98 % of it back.  Measured (tools/fast_err.py; round 5, with the fast IntegrateTemporally and
+    TAA values): median 8e-6, 99th percentile 2.4e-3, maximum 1.6e-2.  The reference's own RGBA16F storage perturbs the same inputs by 5e-4.  The exact mode is held to 0 above."""
     from oracle import cap_oracle as O
     w, h, D = 150, 101, 2
     geo = capi.Geometry(cornell_path)
