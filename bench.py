@@ -81,7 +81,10 @@ def roofline_object(kernel_name, counters_key, kernel_bytes, launches, kernel_ms
     valu = None
     if pmc and pmc.get("valu_insts_per_launch"):
         valu = {"wave_insts_per_launch": pmc["valu_insts_per_launch"], "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
-                "issue_frac": pmc["valu_insts_per_launch"] / (avg_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S}
+                "issue_frac": pmc["valu_insts_per_launch"] / (avg_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S,
+                "note": "issue_frac is against one wave64 instruction per 2 cycles and SIMD, a rate no real mix reaches: measured at six "
+                        "waves per SIMD (profiles/r05_micro/valu_cost.txt) FMA / mul / add / mov issue at ~3 cycles, conversions, min / "
+                        "max, selects by SGPR mask and bit operations at ~4, transcendentals at ~8"}
     o = {"bound": "valu", "bound_note": "vector-instruction issue (+ exposed latency), not HBM: see `valu` and DESIGN.md 5; "
                                         "achieved / peak / frac are the contract's algorithmic HBM bytes against the 8 TB/s peak",
          "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

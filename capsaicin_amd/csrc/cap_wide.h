@@ -1,8 +1,9 @@
 // cap_wide.h — the compressed 8-wide view of the traversal tree: layout shared by the host-side collapse (wide_builder.cpp) and
 // the gfx950 kernels (trace8.hip).
 //
-// Why: the per-lane traversal of incoherent rays is bound by the bytes each lane pulls through the CU's texture-address path
-// (64 B per clock and CU; profiles/r01_tree_path.txt: TA busy 64 % of the closest-hit launch, vector ALU 38 %).  The binary
+// Why: in round 1 the per-lane traversal of incoherent rays was bound by what each lane pulls through the CU's texture-address
+// path (profiles/r01_tree_path.txt: TA busy 64 % of the closest-hit launch, vector ALU 38 %; with this view the vector ALU is the
+// first limiter and that path the second: docs/experiments.md (60)).  The binary
 // tree costs 64 B per two child boxes, its 4-wide view 112 B per four; this node holds EIGHT child boxes in 80 B — child planes
 // quantised to 8 bits on a per-node power-of-two grid (Ylitie, Karras, Laine 2017, "Efficient incoherent ray traversal on GPUs
 // through compressed wide BVHs": the idea; layout, child indexing and traversal order code below are this build's own).

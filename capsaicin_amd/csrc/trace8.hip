@@ -123,10 +123,12 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
         }
         // invariant: an alive lane has a triangle or a node due.  ONE load sequence serves both kinds of lane: a divergent 16-B
         // load costs the CU's texture-address path the same ~29 cycles whether 10 or 64 lanes take part (it works in quads of
-        // lanes, and the lanes of either kind are scattered over all quads), and those cycles are what bounds this kernel
-        // (measured: three extra 16-B loads per node step cost 1.8 ms; serving 45 % of the node steps from an LDS copy of the
-        // top levels, lane by lane, saved nothing).  So a lane with a triangle due fetches its 64-B record with the first four
-        // of the five loads a node lane needs, and both tests run on what arrived.
+        // lanes, and the lanes of either kind are scattered over all quads) (measured: three extra 16-B loads per node step
+        // cost 1.8 ms; serving 45 % of the node steps from an LDS copy of the top levels, lane by lane, saved nothing).  So a
+        // lane with a triangle due fetches its 64-B record with the first four of the five loads a node lane needs, and both
+        // tests run on what arrived.  (Round 5, docs/experiments.md (59)(60): that path is the SECOND limiter; the first is the
+        // vector ALU at the real cost of this loop's instruction classes, ~1 260 SIMD cycles per iteration, and the memory
+        // system behind both delivers twice what the kernel asks of it.)
         const bool     tri_lane = alive && c.t_hits != 0u, node_lane = alive && c.t_hits == 0u;
         const float4*  src      = bvh.nodes8;
         if (tri_lane)
