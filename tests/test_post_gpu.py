@@ -29,7 +29,11 @@ def moved(cam, dx, dy, dz):
                                       dict(use_variance=0), dict(use_variance=0, eaw5=0),  # RaytracingOptions::use_variance, raytracing_system.h:25
                                       # SettingsComponent::output -> CombineIllumination's `type` (combine_illumination.hlsl:26-40,
                                       # raytracing_system.cpp:1415): direct, indirect, variance (.www after the last blur / without one)
-                                      dict(output=1), dict(output=2), dict(output=3), dict(output=3, denoise=0), dict(output=2, eaw5=0)])
+                                      dict(output=1), dict(output=2), dict(output=3), dict(output=3, denoise=0), dict(output=2, eaw5=0),
+                                      # sigmas outside the range post.hip's unscaled division is used on: every tile takes the IEEE form
+                                      # (the fallback of docs/experiments.md (68)); a depth sigma of 0 is the reference's "weight 1"
+                                      dict(eaw_depth_sigma=1e-13, gather_depth_sigma=1e-13), dict(eaw_luma_sigma=1e13, gather_luma_sigma=1e-14),
+                                      dict(eaw_depth_sigma=0.0, gather_depth_sigma=0.0)])
 def test_post_chain_parity_cornell(native_lib, bluenoise, cornell_path, settings):
     from oracle import cap_oracle as O
     w, h, D = 150, 101, 2  # not multiples of the 32x8 workgroup footprint or the 8x8 render tiles
