@@ -7,6 +7,7 @@
 // Pure stencil / streaming work: HBM- and L2-bound, no MFMA.
 #include "cap_kernels.h"
 #include "cap_reproject.h"
+#include "cap_unscaled.h"
 
 #include <type_traits>
 
@@ -127,17 +128,6 @@ __device__ __forceinline__ v3 oct_decode(float fx, float fy)
 // establish per tile while staging (depths in [1e-5, 2^40], luminances 0 or in [2^-50, 2^30], the pixel's sigmas in [2^-38, 2^38];
 // a tile or wave that fails takes the IEEE form: the same result by definition).  cap_debug_get(CAP_DEBUG_SELFTEST_DIV) compares both
 // forms on the device: every float for log2's (m - 1) / (m + 1), 2^30 pseudo-random pairs over the whole stated range for the rest.
-__device__ __forceinline__ float div_unscaled(float a, float b)
-{
-    const float r0 = __builtin_amdgcn_rcpf(b);
-    const float e0 = fmaf(-b, r0, 1.0f);
-    const float r  = fmaf(e0, r0, r0);
-    const float q0 = a * r;
-    const float e1 = fmaf(-b, q0, a);
-    const float q1 = fmaf(e1, r, q0);
-    const float e2 = fmaf(-b, q1, a);
-    return fmaf(e2, r, q1);
-}
 template <bool NS>
 __device__ __forceinline__ float div_c(float a, float b)
 {
