@@ -648,6 +648,7 @@ int cap_scene_upload(CapContext* c, const float* positions, const float* normals
     c->vertex_count = vertex_count, c->index_count = index_count, c->mesh_count = mesh_count, c->tri_count = (uint32_t)tri_ids.size();
     c->scene_ready = true;
     c->bvh_ready   = false;
+    c->lane1_failed_paths = 0;  // another scene, other buffers: a second batch lane that did not fit before may fit now
     return CAP_OK;
 }
 
