@@ -836,7 +836,11 @@ def main():
         if extras and not args.no_tree_variant:
             shard_costs = guarded(lambda: {"what": "ms per step of shard 0 of N on ONE MI355X (no exchange): the compute side of the 1 -> N curve",
                                            "cornell_64spp": shard_cost(lambda: make_cornell(device_index, s_h), SPP, DEPTH),
-                                           "sponza_class_32spp": shard_cost(lambda: make_hall(device_index, s_h)[0], TREE_SPP, DEPTH, reps=2)})
+                                           "sponza_class_32spp": shard_cost(lambda: make_hall(device_index, s_h)[0], TREE_SPP, DEPTH, reps=2),
+                                           # BASELINE configs[3] at its own sample count: a rank's 128 frame slots are ONE batch of four times
+                                           # the 32-spp line's launches, so the traversal launches' drain (their longest rays, ~60 us whatever
+                                           # the launch holds) weighs a quarter as much
+                                           "sponza_class_128spp": shard_cost(lambda: make_hall(device_index, s_h)[0], TREE_FULL_SPP, DEPTH, reps=2)})
         post_chain = guarded(post_chain_variant, device_index, s_h) if extras else None
         realtime = guarded(realtime_frame_variant, device_index, s_h) if extras else None
 
