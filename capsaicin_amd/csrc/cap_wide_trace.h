@@ -87,7 +87,14 @@ __device__ __forceinline__ WideNode wide_node_load(const float4* __restrict__ N)
 }
 
 // Box tests of the eight children of a node; replaces the cursor's groups by the node's.
-__device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay& r, float tmin, float tfar, WideCursor& c)
+#ifdef CAP_W8_COUNT  // diagnostic build: the children's entry distances, by slot
+#define CAP_W8_TN_ARG , float* tn_out = nullptr
+#define CAP_W8_TN_OUT(slot, tn) if (tn_out) tn_out[slot] = tn;
+#else
+#define CAP_W8_TN_ARG
+#define CAP_W8_TN_OUT(slot, tn)
+#endif
+__device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay& r, float tmin, float tfar, WideCursor& c CAP_W8_TN_ARG)
 {
     const float4   h0 = n.h0, h1 = n.h1, q2 = n.q2, q3 = n.q3, q4 = n.q4;
     const uint32_t syz = f2u(h1.w);  // the y and z steps' upper halves (powers of two: the lower halves are zero)
@@ -108,6 +115,7 @@ __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay&
                     tfz = fmaf((float)(((fzw) >> (sh)) & 0xffu), az, bz);                                                                \
         const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin)), tf = fminf(fminf(tfx, tfy), fminf(tfz, tfar));                        \
         h8 |= (tn <= tf) ? (1u << (slot)) : 0u;                                                                                          \
+        CAP_W8_TN_OUT(slot, tn)                                                                                                          \
     }
     CAP_W8_CHILD(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
     CAP_W8_CHILD(1, nx0, ny0, nz0, fx0, fy0, fz0, 8)

@@ -34,9 +34,12 @@ constexpr uint32_t kW8StackPairs = (uint32_t)kW8Lds + kSpillEntries / 2u;
 
 // Diagnostic build only (make EXTRA=-DCAP_W8_COUNT): lane- and wave-level step counts of the closest-hit kernel, read by
 // tools/w8_counts.py: [0] node steps (lanes), [1] triangle tests (lanes), [2] load sequences (wave iterations with live lanes),
-// [3] node steps on the first kWideTopNodes nodes, [4] rays, [5] loop iterations (waves), [6] stack pushes, [7] spilled pushes
+// [3] node steps on the first kWideTopNodes nodes, [4] rays, [5] loop iterations (waves), [6] stack pushes, [7] spilled pushes,
+// [8] node steps whose node's own entry distance (as its parent's test computed it) was already beyond best_t when it was picked (what a
+// per-child cull would skip), [9] of those, the ones a per-GROUP bound (minimum over the children still in the group) would skip,
+// [10] node steps that hit no child at all
 #ifdef CAP_W8_COUNT
-__device__ unsigned long long g_w8_counts[8];
+__device__ unsigned long long g_w8_counts[16];
 #define W8_COUNT(i, v) (cnt[i] += (v))
 #else
 #define W8_COUNT(i, v) ((void)0)
@@ -76,7 +79,9 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
     float    best_t = 0.f, best_u = 0.f, best_v = 0.f;
     uint32_t best_gid = kInvalidId, out = 0;
 #ifdef CAP_W8_COUNT
-    unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cnt[16] = {};
+    float cur_tn[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // entry distances of the current node group's children, by slot
+    float tn_stack[24][8];
 #endif
     while (true)
     {
@@ -110,6 +115,9 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
                     wide_cursor_root(c);
                     st.sp = 0, alive = true;
                     W8_COUNT(4, 1);
+#ifdef CAP_W8_COUNT
+                    for (int k = 0; k < 8; ++k) cur_tn[k] = 0.f;
+#endif
                 }
                 buf_pos += take;
                 m_alive = __ballot(alive);
@@ -139,11 +147,25 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
         else if (node_lane)
         {
             bool           rest;
+#ifdef CAP_W8_COUNT
+            {
+                const uint32_t bit = 31u - (uint32_t)__clz((int)c.g_mask), slot = (bit - 24u) ^ w.octinv;
+                float          gmin = 3e38f;
+                for (uint32_t b = 24u; b < 32u; ++b)
+                    if ((c.g_mask >> b) & 1u) gmin = fminf(gmin, cur_tn[(b - 24u) ^ w.octinv]);
+                if (cur_tn[slot] > best_t) cnt[8] += 1;
+                if (gmin > best_t) cnt[9] += 1;
+            }
+#endif
             const uint32_t node = wide_pick_child(c, w.octinv, rest);
             W8_COUNT(0, 1);
             W8_COUNT(6, rest ? 1 : 0);
             W8_COUNT(7, (rest && st.sp >= kW8Lds) ? 1 : 0);
             W8_COUNT(3, node < kWideTopNodes ? 1 : 0);
+#ifdef CAP_W8_COUNT
+            if (rest && st.sp < 24)
+                for (int k = 0; k < 8; ++k) tn_stack[st.sp][k] = cur_tn[k];
+#endif
             if (rest) st.push(c.g_base, c.g_mask);
             src = bvh.nodes8 + (kWideNodeStride / 4u) * (size_t)node;
         }
@@ -169,7 +191,15 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
                 if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
             }
         }
+#ifdef CAP_W8_COUNT
+        if (node_lane)
+        {
+            wide_node_test(nd, w, r.tmin, best_t, c, cur_tn);
+            if (c.t_hits == 0u && (c.g_mask >> 24) == 0u) cnt[10] += 1;
+        }
+#else
         if (node_lane) wide_node_test(nd, w, r.tmin, best_t, c);
+#endif
         // a lane with nothing due takes the next node group off its stack, or retires
         if (alive && c.t_hits == 0u && (c.g_mask >> 24) == 0u)
         {
@@ -179,11 +209,17 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
                 alive     = false;
             }
             else
+            {
                 st.pop(c);
+#ifdef CAP_W8_COUNT
+                if (st.sp < 24)
+                    for (int k = 0; k < 8; ++k) cur_tn[k] = tn_stack[st.sp][k];
+#endif
+            }
         }
     }
 #ifdef CAP_W8_COUNT
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 16; ++i)
     {
         unsigned long long v = cnt[i];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -358,7 +394,7 @@ extern "C" int cap_debug_w8_counts(unsigned long long* out, int reset)
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w8_counts), sizeof(g_w8_counts));
     if (e == hipSuccess && reset)
     {
-        unsigned long long z[8] = {};
+        unsigned long long z[16] = {};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_w8_counts), z, sizeof(z));
     }
     return (int)e;

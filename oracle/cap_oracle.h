@@ -159,6 +159,8 @@ typedef struct OraclePostSettings
 
 void* oracle_post_create(uint32_t width, uint32_t height);
 void  oracle_post_destroy(void* chain);
+/* Host threads the chain's passes split their rows over (default 1); the images do not depend on it. */
+void  oracle_post_set_threads(int n);
 /* One frame of Gather -> Accumulate -> BlurDisocclusion -> Blur x2|x4 -> Combine -> TAA on this frame's ray-pass outputs
  * (all W*H*4 floats); writes current_frame_output() (raytracing_system.cpp:320-324) to out and keeps the histories. */
 int oracle_post_frame(void* chain, const OraclePostSettings* settings, uint32_t frame_count, const OracleCamera* camera,

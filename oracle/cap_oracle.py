@@ -70,6 +70,8 @@ def lib():
         L.oracle_post_create.restype = C.c_void_p
         L.oracle_post_create.argtypes = [C.c_uint32, C.c_uint32]
         L.oracle_post_destroy.argtypes = [C.c_void_p]
+        L.oracle_post_set_threads.argtypes = [C.c_int]
+        L.oracle_post_set_threads.restype = None
         L.oracle_post_pass.argtypes = [C.c_int, C.POINTER(PostSettings), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Camera), C.POINTER(Camera)] + [C.c_void_p] * 7
         L.oracle_post_frame.argtypes = [C.c_void_p, C.POINTER(PostSettings), C.c_uint32, C.POINTER(Camera), C.POINTER(Camera)] + [C.c_void_p] * 5
         L.oracle_wang_hash.restype = C.c_uint32
@@ -178,8 +180,9 @@ class Scene:
 class PostChain:
     """History-carrying reconstruction chain (Gather .. TAA) of the oracle."""
 
-    def __init__(self, width, height):
+    def __init__(self, width, height, threads=1):
         self.w, self.h = width, height
+        self.threads = threads
         self.handle = lib().oracle_post_create(width, height)
 
     def __del__(self):
@@ -191,6 +194,7 @@ class PostChain:
         a = [np.ascontiguousarray(planes[k], np.float32)
              for k in ("indirect_lowres" if settings.lowres_indirect else "indirect", "direct", "albedo", "normal_depth")]
         out = np.zeros((self.h, self.w, 4), np.float32)
+        lib().oracle_post_set_threads(self.threads)
         rc = lib().oracle_post_frame(self.handle, C.byref(settings), frame_count, C.byref(cam), C.byref(prev_cam), _p(a[0]), _p(a[1]),
                                      _p(a[2]), _p(a[3]), _p(out))
         if rc:

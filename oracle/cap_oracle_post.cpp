@@ -16,6 +16,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "cap_oracle.h"
@@ -228,6 +230,33 @@ f3 reconstruct_world_position(const OracleCamera& cam, f2 uv, float depth)
     return mk(cam.position[0], cam.position[1], cam.position[2]) + d * depth;
 }
 
+
+// Rows of a pass on `g_post_threads` host threads (oracle_post_set_threads; default 1).  Every pass writes images it does not read and a
+// pixel's value depends on no other output pixel, so the result does not depend on the thread count.
+static int g_post_threads = 1;
+template <class F>
+static void post_rows(uint32_t H, F&& body)
+{
+    const int nt = g_post_threads < 1 ? 1 : g_post_threads;
+    if (nt == 1 || H < 64u)
+    {
+        for (uint32_t y = 0; y < H; ++y) body(y);
+        return;
+    }
+    std::vector<std::thread> pool;
+    std::atomic<uint32_t>    next{0};
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([&]() {
+            for (;;)
+            {
+                const uint32_t y0 = next.fetch_add(8u);
+                if (y0 >= H) return;
+                for (uint32_t y = y0; y < y0 + 8u && y < H; ++y) body(y);
+            }
+        });
+    for (auto& th : pool) th.join();
+}
+
 struct Chain
 {
     uint32_t w, h;
@@ -238,7 +267,7 @@ struct Chain
 // spatial_gather.hlsl:28-109
 void gather(const OraclePostSettings& s, const Image& color, const Image& nd, Image& out)
 {
-    for (uint32_t y = 0; y < out.h; ++y)
+    post_rows(out.h, [&](uint32_t y) {
         for (uint32_t x = 0; x < out.w; ++x)
         {
             f4    cg = nd.load(x, y);
@@ -270,6 +299,7 @@ void gather(const OraclePostSettings& s, const Image& color, const Image& nd, Im
             f3 r = (total < kEps) ? cc : filtered / total;
             out.store(x, y, f4{r.x, r.y, r.z, 1.0f});
         }
+    });
 }
 
 // spatial_gather.hlsl:28-109 with UPSCALE2X (:36-46, :83-87): the grid and `color` are half resolution, the G-buffer is read at
@@ -280,7 +310,7 @@ void gather_lowres(const OraclePostSettings& s, uint32_t frame_count, uint32_t f
                    Image& out)
 {
     const int ox = (int)((frame_count % 4) / 2), oy = (int)((frame_count % 4) % 2);
-    for (uint32_t y = 0; y < out.h; ++y)
+    post_rows(out.h, [&](uint32_t y) {
         for (uint32_t x = 0; x < out.w; ++x)
         {
             f4    cg = nd.loadi(((int)x << 1) + ox, ((int)y << 1) + oy);
@@ -312,6 +342,7 @@ void gather_lowres(const OraclePostSettings& s, uint32_t frame_count, uint32_t f
             f3 r = (total < kEps) ? cc : filtered / total;
             out.store(x, y, f4{r.x, r.y, r.z, 1.0f});
         }
+    });
 }
 
 float closest_depth(const Image& g, f2 xy)  // temporal_accumulation.hlsl:179-205
@@ -335,7 +366,7 @@ void accumulate(const OraclePostSettings& s, uint32_t frame_count, const OracleC
                 Image& out_color, Image& out_moments)
 {
     const uint32_t W = out_color.w, H = out_color.h;
-    for (uint32_t y = 0; y < H; ++y)
+    post_rows(H, [&](uint32_t y) {
         for (uint32_t x = 0; x < W; ++x)
         {
             f2 uv = f2{((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H};
@@ -389,6 +420,7 @@ void accumulate(const OraclePostSettings& s, uint32_t frame_count, const OracleC
             f3 blended = lerp3(c, history, alpha);
             out_color.store(x, y, f4{blended.x, blended.y, blended.z, variance});
         }
+    });
 }
 
 f3 remove_fireflies(f4 v) { return mk(fminf(v.x, 10.0f), fminf(v.y, 10.0f), fminf(v.z, 10.0f)); }  // eaw_blur.hlsl:30-33
@@ -396,7 +428,7 @@ f3 remove_fireflies(f4 v) { return mk(fminf(v.x, 10.0f), fminf(v.y, 10.0f), fmin
 // eaw_blur.hlsl:142-223
 void blur_disocclusion(const OraclePostSettings& s, const Image& color, const Image& nd, const Image& moments, Image& out)
 {
-    for (uint32_t y = 0; y < out.h; ++y)
+    post_rows(out.h, [&](uint32_t y) {
         for (uint32_t x = 0; x < out.w; ++x)
         {
             float hist = moments.load(x, y).w;
@@ -435,13 +467,14 @@ void blur_disocclusion(const OraclePostSettings& s, const Image& color, const Im
             float boost = 8.0f / hist;
             out.store(x, y, f4{r.x, r.y, r.z, boost * fabsf(m1 - m0 * m0)});
         }
+    });
 }
 
 // eaw_blur.hlsl:48-137
 void blur(const OraclePostSettings& s, uint32_t stride, const Image& color, const Image& nd, Image& out)
 {
     const float kw[3] = {1.0f, 2.0f / 3.0f, 1.0f / 6.0f};
-    for (uint32_t y = 0; y < out.h; ++y)
+    post_rows(out.h, [&](uint32_t y) {
         for (uint32_t x = 0; x < out.w; ++x)
         {
             f4    cg   = nd.load(x, y);
@@ -483,6 +516,7 @@ void blur(const OraclePostSettings& s, uint32_t stride, const Image& color, cons
             float rv = (total < kEps) ? cvar : fvar / (total * total);
             out.store(x, y, f4{r.x, r.y, r.z, rv});
         }
+    });
 }
 
 // aabb.h:24-34
@@ -499,7 +533,7 @@ void taa(const OraclePostSettings& s, const OracleCamera& cam, const OracleCamer
          const Image& history_img, Image& out)
 {
     const uint32_t W = out.w, H = out.h;
-    for (uint32_t y = 0; y < H; ++y)
+    post_rows(H, [&](uint32_t y) {
         for (uint32_t x = 0; x < W; ++x)
         {
             f2 uv = f2{((float)x + 0.5f) / (float)W, ((float)y + 0.5f) / (float)H};
@@ -550,6 +584,7 @@ void taa(const OraclePostSettings& s, const OracleCamera& cam, const OracleCamer
             f3 r = invert_simple_tonemap(ycocg2rgb(lerp3(c, history, alpha)));
             out.store(x, y, f4{r.x, r.y, r.z, 1.0f});
         }
+    });
 }
 
 void from_floats(Image& img, const float* p)
@@ -571,6 +606,8 @@ void* oracle_post_create(uint32_t w, uint32_t h)
 }
 
 void oracle_post_destroy(void* h) { delete (Chain*)h; }
+
+void oracle_post_set_threads(int n) { g_post_threads = n; }
 
 int oracle_post_frame(void* handle, const OraclePostSettings* s, uint32_t frame_count, const OracleCamera* cam,
                       const OracleCamera* prev_cam, const float* indirect, const float* direct, const float* albedo,

@@ -427,3 +427,110 @@ def test_sharded_chain_error_paths(native_lib, bluenoise, cornell_path):
     with pytest.raises(capi.CapError, match="even width"):
         r.post_frame_gathered(s, 0, cam, buf.data_ptr(), 2)
     r.close()
+
+
+def _host_threads():
+    """The CPU share the test process really has (the GPU box reports 256 hardware threads and grants a cgroup quota of 16)."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError, AttributeError):
+        pass
+    return max(1, min(n, 32))
+
+
+def test_post_chain_parity_1080p(native_lib, bluenoise, cornell_path):
+    """The reconstruction chain at the size bench.py times it at (`realtime_frame`, `post_chain`: 1920 x 1080, the reference's window,
+    /root/reference/src/viewer/main.cpp:53-54; pipeline raytracing_system.cpp:294-317): depth 1, G-buffer feedback on, default settings,
+    two static frames and two moved ones.  At this size post.hip's tile grid is 60 x 135 in eight XCD bands, a stride-7 row-phase tile is a
+    fraction of a row, and BlurDisocclusion is sparse -- none of which the 150 x 101 tests reach.  Exact mode: every frame's ray-pass
+    planes and chain output bit for bit against the oracle running the same loop (its chain on the host's threads: the passes are
+    row-parallel, the images do not depend on the thread count).  `fast_weights`: the same loop on a context of its own inside the
+    stated distribution.  Then two frames on three shards through cap_post_frame_gathered, bit-identical to the unsharded chain."""
+    import torch
+    from oracle import cap_oracle as O
+    w, h, D = 1920, 1080, 1
+    nt = _host_threads()
+    geo = capi.Geometry(cornell_path)
+
+    def make():
+        r = capi.Renderer(0)
+        r.upload_geometry(geo)
+        r.upload_bluenoise(bluenoise)
+        r.build_bvh()
+        r.set_resolution(w, h)
+        return r
+
+    r, rf = make(), make()
+    sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes)
+    chain = O.PostChain(w, h, threads=nt)
+    base = capi.cornell_camera(w, h)
+    cams = [base, base, moved(base, 0.02, 0.01, -0.03), moved(base, 0.04, 0.02, -0.06)]
+    gs, gf, os_ = capi.PostSettings(), capi.PostSettings(fast_weights=1), O.PostSettings()
+    flags = capi.RENDER_AOV | capi.RENDER_GBUFFER_FEEDBACK
+    prev, prev_nd, hist = cams[0], np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    for f, cam in enumerate(cams):
+        for ctx in (r, rf):
+            ctx.set_camera(cam)
+            ctx.set_prev_camera(prev)
+            ctx.stats_reset()
+            ctx.render(f, 1, D, flags)
+        ref = sc.render_frame(ocam_of(O, cam), bluenoise, w, h, f, D, threads=nt, feedback=(ocam_of(O, prev), prev_nd, hist))
+        for name, kind in (("direct", capi.BUF_DIRECT), ("albedo", capi.BUF_ALBEDO), ("normal_depth", capi.BUF_NORMAL_DEPTH),
+                           ("indirect", capi.BUF_INDIRECT)):
+            got = r.readback(kind)
+            nbad = int((bits(got) != bits(ref[name])).any(-1).sum())
+            assert nbad == 0, "frame %d %s: %d pixels differ" % (f, name, nbad)
+        s = r.stats()
+        assert (s.rays_primary, s.rays_extension, s.rays_shadow) == ref["rays"]
+        r.post_frame(gs, f, prev)
+        got = r.post_readback()
+        want = chain.frame(os_, f, ocam_of(O, cam), ocam_of(O, prev), ref)
+        assert np.all(np.isfinite(got))
+        nbad = int((bits(got) != bits(want)).any(-1).sum())
+        assert nbad == 0, "frame %d chain output: %d pixels differ, max abs %g" % (f, nbad, float(np.abs(got - want).max()))
+        # the toleranced mode, carrying its own histories and its own feedback (tolerance: include/capsaicin_hip.h, CapPostSettings)
+        rf.post_frame(gf, f, prev)
+        fast = rf.post_readback()
+        assert np.all(np.isfinite(fast))
+        e = np.abs(fast.astype(np.float64) - want)[..., :3] / (np.abs(want[..., :3]) + 1e-3)
+        assert np.median(e) <= 2e-5 and np.percentile(e, 99) <= 4e-3 and e.max() <= 3e-2, \
+            "fast frame %d: median %.2e p99 %.2e max %.2e" % (f, np.median(e), np.percentile(e, 99), e.max())
+        prev, prev_nd, hist = cam, ref["normal_depth"], want
+    rf.close()
+
+    # three shards, one gather per frame, the chain on the root (SURVEY.md 8e): bit-identical to the unsharded chain at this size
+    def sequence(count):
+        out, prev = [], cams[1]
+        r.post_reset()
+        for f, cam in enumerate(cams[1:3]):
+            r.set_camera(cam)
+            if count == 1:
+                r.set_shard(0, 1)
+                r.render(f, 1, D, capi.RENDER_AOV)
+                r.post_frame(gs, f, prev)
+            else:
+                bufs = []
+                for idx in range(count):
+                    r.set_shard(idx, count)
+                    r.render(f, 1, D, capi.RENDER_AOV)
+                    t = torch.empty(r.aov_tile_buffer_floats(), dtype=torch.float32, device="cuda")
+                    torch.cuda.synchronize()
+                    r.resolve_aov_tiles(t.data_ptr())
+                    r.sync()
+                    bufs.append(t)
+                gathered = torch.cat(bufs)
+                torch.cuda.synchronize()
+                r.post_frame_gathered(gs, f, prev, gathered.data_ptr(), count)
+            out.append(r.post_readback())
+            prev = cam
+        return out
+
+    one, three = sequence(1), sequence(3)
+    for f, (a, b) in enumerate(zip(three, one)):
+        assert np.array_equal(bits(a), bits(b)), "sharded frame %d: %d pixels differ" % (f, int((bits(a) != bits(b)).any(-1).sum()))
+    r.close()

@@ -24,7 +24,7 @@ def main():
     r.build_bvh()
     r.set_resolution(bench.WIDTH, bench.HEIGHT)
     r.set_camera(cam)
-    out = (ctypes.c_ulonglong * 8)()
+    out = (ctypes.c_ulonglong * 16)()
     r.render(0, spp, bench.DEPTH, 0)
     r.sync()
     lib.cap_debug_w8_counts(out, 1)
@@ -34,11 +34,13 @@ def main():
     r.sync()
     s = r.stats()
     lib.cap_debug_w8_counts(out, 1)
-    nodes, tris, seqs, top, rays, iters, pushes, spills = (int(x) for x in out)
+    nodes, tris, seqs, top, rays, iters, pushes, spills, cull_child, cull_group, empty = (int(x) for x in list(out)[:11])
     res = {"scale": scale, "spp": spp, "triangles": int(r.bvh_info().triangle_count), "rays": rays, "rays_extension": int(s.rays_extension), "node_steps_per_ray": nodes / rays, "triangle_tests_per_ray": tris / rays,
            "lanes_per_load_sequence": (nodes + tris) / max(1, seqs), "load_sequences": seqs, "loop_iterations": iters,
            "node_steps_on_top_levels": top / max(1, nodes), "pushes_per_ray": pushes / rays,
            "spilled_push_fraction": spills / max(1, pushes),
+           "steps_a_per_child_cull_would_skip": cull_child / max(1, nodes), "steps_a_group_bound_would_skip": cull_group / max(1, nodes),
+           "steps_that_hit_no_child": empty / max(1, nodes),
            # nodes visited x node size + triangles tested x record size
            "traversal_bytes_per_ray": 80 * nodes / rays + 64 * tris / rays}
     print(json.dumps(res))
