@@ -368,10 +368,11 @@ class Renderer:
         m = np.ascontiguousarray(materials, np.float32).reshape(-1, 12)
         _check(lib().cap_materials_upload(self.ctx, _p(m), m.shape[0]), "cap_materials_upload")
 
-    BVH_BUILD_AUTO, BVH_BUILD_LBVH, BVH_BUILD_SAH, BVH_BUILD_PLOC = 0, 1, 2, 3  # CapBvhBuild
+    BVH_BUILD_AUTO, BVH_BUILD_LBVH, BVH_BUILD_SAH, BVH_BUILD_PLOC, BVH_BUILD_SAH_DEVICE = 0, 1, 2, 3, 4  # CapBvhBuild
 
     def set_bvh_build(self, mode):
-        """0 auto (clustering build on the device above 64 triangles), 1 Morton hierarchy on the device, 2 SAH on the host, 3 clustering."""
+        """0 auto (clustering build on the device above 64 triangles), 1 Morton hierarchy on the device, 2 SAH on the host, 3 clustering,
+        4 SAH on the device (surface-area splits down to small segments, clustering inside)."""
         _check(lib().cap_set_bvh_build(self.ctx, mode), "cap_set_bvh_build")
 
     def build_bvh(self):

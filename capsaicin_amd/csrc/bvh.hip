@@ -337,8 +337,8 @@ void launch_gather_wide(hipStream_t stream, const uint32_t* tri_src, const float
 // builder (wide_builder.cpp: open the largest inner child until eight, then multi-triangle leaf children; octant slots by greedy
 // assignment; planes quantised outwards in double precision after padding), one thread per wide node, level by level.  A level's
 // nodes are contiguous (breadth-first array, top levels first); a node's inner children are allocated as one block, so they
-// are contiguous in slot order, and its triangles likewise.  Within a level the order depends on the atomics' arrival: the layout
-// may differ from run to run, the traversal result never does.
+// are contiguous in slot order, and its triangles likewise.  The blocks are handed out by a prefix sum in the level's own order (round 6;
+// an atomic per node before): the same layout on every run and on every rank, siblings' children next to each other.
 // ------------------------------------------------------------------------------------------------
 namespace
 {
@@ -363,13 +363,10 @@ __device__ __forceinline__ double wide_half_area(const WideRef& r)
     return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ __launch_bounds__(kBlock) void k_wide_level(WideCollapseArgs a)
+// the children of the wide node that stands for binary node `root`: open the largest inner child until eight, then multi-triangle leaves
+__device__ __forceinline__ int wide_open(const WideCollapseArgs& a, uint32_t root, WideRef kids[8])
 {
-    const uint32_t w = a.begin + blockIdx.x * kBlock + threadIdx.x;
-    if (w >= a.end) return;
-    const uint32_t root = a.task[w];
-    WideRef        kids[8];
-    int            nk = 2;
+    int nk = 2;
     kids[0] = wide_ref(a.bnodes, a.count, root, 0), kids[1] = wide_ref(a.bnodes, a.count, root, 1);
     for (int pass = 0; pass < 2; ++pass)
         while (nk < 8)
@@ -388,6 +385,60 @@ __global__ __launch_bounds__(kBlock) void k_wide_level(WideCollapseArgs a)
             kids[best]  = wide_ref(a.bnodes, a.count, open, 0);
             kids[nk++]  = wide_ref(a.bnodes, a.count, open, 1);
         }
+    return nk;
+}
+
+// first half of a level: how many inner children and triangles every node of the level will allocate
+__global__ __launch_bounds__(kBlock) void k_wide_count(WideCollapseArgs a)
+{
+    const uint32_t w = a.begin + blockIdx.x * kBlock + threadIdx.x;
+    if (w >= a.end) return;
+    WideRef   kids[8];
+    const int nk = wide_open(a, a.task[w], kids);
+    uint32_t  n_inner = 0u, n_tris = 0u;
+    for (int i = 0; i < nk; ++i)
+        if (kids[i].count > kWideLeafMax)
+            ++n_inner;
+        else
+            n_tris += kids[i].count;
+    a.cnt[2 * (size_t)(w - a.begin)] = n_inner, a.cnt[2 * (size_t)(w - a.begin) + 1] = n_tris;
+}
+
+// exclusive scan of the level's (inner children, triangles) pairs on top of alloc[0..1], one workgroup; alloc takes the totals.  The
+// blocks a level's nodes get are in the level's own order: the layout is the same on every run and a node's children lie next to its
+// siblings' children.
+__global__ __launch_bounds__(1024) void k_wide_scan(WideCollapseArgs a)
+{
+    __shared__ uint32_t s_part[2][1024];
+    const uint32_t n = a.end - a.begin, t = threadIdx.x, per = (n + 1023u) / 1024u, b0 = min(n, t * per), b1 = min(n, b0 + per);
+    uint32_t       s0 = 0, s1 = 0;
+    for (uint32_t b = b0; b < b1; ++b) s0 += a.cnt[2 * (size_t)b], s1 += a.cnt[2 * (size_t)b + 1];
+    s_part[0][t] = s0, s_part[1][t] = s1;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1)
+    {
+        const uint32_t v0 = t >= off ? s_part[0][t - off] : 0u, v1 = t >= off ? s_part[1][t - off] : 0u;
+        __syncthreads();
+        s_part[0][t] += v0, s_part[1][t] += v1;
+        __syncthreads();
+    }
+    uint32_t e0 = a.alloc[0] + s_part[0][t] - s0, e1 = a.alloc[1] + s_part[1][t] - s1;
+    for (uint32_t b = b0; b < b1; ++b)
+    {
+        const uint32_t k0 = a.cnt[2 * (size_t)b], k1 = a.cnt[2 * (size_t)b + 1];
+        a.cnt[2 * (size_t)b] = e0, a.cnt[2 * (size_t)b + 1] = e1;
+        e0 += k0, e1 += k1;
+    }
+    __syncthreads();  // every read of alloc is done
+    if (t == 1023u) a.alloc[0] += s_part[0][t], a.alloc[1] += s_part[1][t];
+}
+
+__global__ __launch_bounds__(kBlock) void k_wide_level(WideCollapseArgs a)
+{
+    const uint32_t w = a.begin + blockIdx.x * kBlock + threadIdx.x;
+    if (w >= a.end) return;
+    WideRef   kids[8];
+    const int nk = wide_open(a, a.task[w], kids);
     // padded child boxes (double) and the node box
     double clo[8][3], chi[8][3], nlo[3] = {1e300, 1e300, 1e300}, nhi[3] = {-1e300, -1e300, -1e300};
     for (int i = 0; i < nk; ++i)
@@ -481,8 +532,8 @@ __global__ __launch_bounds__(kBlock) void k_wide_level(WideCollapseArgs a)
             word[wi + 6] |= (uint32_t)qhi << sh;
         }
     }
-    const uint32_t child_base = n_inner ? atomicAdd(&a.alloc[0], n_inner) : 0u;
-    const uint32_t tri_base   = n_tris ? atomicAdd(&a.alloc[1], n_tris) : 0u;
+    const uint32_t child_base = n_inner ? a.cnt[2 * (size_t)(w - a.begin)] : 0u;
+    const uint32_t tri_base   = n_tris ? a.cnt[2 * (size_t)(w - a.begin) + 1] : 0u;
     word[4] = child_base, word[5] = tri_base, word[6] = tvalid | (imask << 24);
     uint32_t rel = 0u, at = tri_base;
     for (int s = 0; s < 8; ++s)
@@ -507,6 +558,8 @@ int launch_wide_collapse(hipStream_t stream, WideCollapseArgs a, uint32_t* node_
         ++levels;
         if (levels <= 3) top = end < kWideTopNodes ? end : kWideTopNodes;
         a.begin = begin, a.end = end;
+        hipLaunchKernelGGL(k_wide_count, dim3((end - begin + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, stream, a);
         hipLaunchKernelGGL(k_wide_level, dim3((end - begin + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
         uint32_t allocated = 0u;
         if (hipMemcpyAsync(&allocated, a.alloc, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;

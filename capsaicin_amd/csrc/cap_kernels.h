@@ -146,6 +146,10 @@ struct PlocScratch
     uint32_t* ints;
 };
 int    launch_bvh_build_ploc(hipStream_t stream, const BvhBuildArgs& a, const PlocScratch& s, uint32_t radius);
+// Binned surface-area splits from the root down to segments of <= `leaf` triangles, the clustering inside those (ploc.hip,
+// "sah_device"); same outputs and the same PlocScratch, plus bvh_sah_device_scratch_words(n) words of its own.
+size_t bvh_sah_device_scratch_words(uint32_t n);
+int    launch_bvh_build_sah_device(hipStream_t stream, const BvhBuildArgs& a, const PlocScratch& s, uint32_t* scratch, uint32_t radius, uint32_t leaf);
 // Host-built tree (sah_builder.cpp): setup = triangle records, boxes and scene bounds only; finish = after `nodes` and
 // `leaf_tri` have been uploaded: intersection records into leaf order + the wide view.
 void launch_bvh_setup(hipStream_t stream, const BvhBuildArgs& a);
@@ -154,7 +158,7 @@ void launch_bvh_finish_host(hipStream_t stream, const BvhBuildArgs& a);
 // Compressed 8-wide view (wide_builder.cpp builds the nodes on the host): intersection records into its leaf order.
 void     launch_gather_wide(hipStream_t stream, const uint32_t* tri_src, const float4* tris_sorted, uint32_t n, float4* tris8);
 // Device-side collapse of the device-built binary tree (needs BvhBuildArgs::keys[1] = the subtree counts launch_bvh_build leaves
-// there).  task: capacity words of scratch; alloc: 2 words; nodes8: capacity * kWideNodeStride words; tri_src: n_tris words.
+// there).  task: capacity words of scratch; cnt: 2 * capacity; alloc: 2 words; nodes8: capacity * kWideNodeStride words; tri_src: n_tris words.
 struct WideCollapseArgs
 {
     const float4*   bnodes;
@@ -162,6 +166,7 @@ struct WideCollapseArgs
     uint32_t        n_tris, capacity;
     double          pad;
     uint32_t *      task, *alloc, *nodes8, *tri_src;
+    uint32_t*       cnt;  // 2 * capacity words: per node of the level being written, (inner children, triangles) -> their bases
     uint32_t        begin, end;
 };
 int      launch_wide_collapse(hipStream_t stream, WideCollapseArgs a, uint32_t* node_count, uint32_t* depth, uint32_t* top_nodes);

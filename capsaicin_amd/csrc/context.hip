@@ -87,6 +87,8 @@ struct DevBuf
 constexpr double kPrimaryWideTrianglesPerPixel = 1.0;
 // shadow rays take the lane-refill kernel from this many bytes of wide nodes + intersection records on (measured: cap_render)
 constexpr uint64_t kAnyRefillTreeBytes = 512ull << 20;
+// AUTO builds with surface-area splits (ploc.hip, sah_device) from this many triangles on, the clustering alone below (see cap_bvh_build)
+constexpr uint32_t kAutoSahTriangles = 4096;
 
 // guard block of a context (ShadeArgs::shaded_counter): {-, malformed path ids seen by shade, by trace_any, last offender, appends
 // beyond a class's capacity, -, -, -}
@@ -153,7 +155,7 @@ struct CapContext
     DevBuf<float4>   shade_tris, tris_sorted, nodes, tri_raw, tri_box;
     DevBuf<float4>   nodes8, tris8;           // compressed 8-wide view (cap_wide.h) and its intersection records
     DevBuf<uint32_t> wide_src;                // leaf-order index per wide-order record
-    DevBuf<uint32_t> wide_task, wide_alloc;   // device collapse: binary node per wide node, allocation counters
+    DevBuf<uint32_t> wide_task, wide_alloc, wide_cnt;   // device collapse: binary node per wide node, allocation counters, per-level bases
     uint32_t         wide8_depth = 0, wide8_top = 0, wide8_nodes = 0;
     float            wide8_ms = 0.f;
     DevBuf<uint32_t> stack_spill;             // traversal-stack entries beyond the LDS part, per thread of the persistent grid
@@ -162,6 +164,7 @@ struct CapContext
     DevBuf<uint32_t> leaf_tri, keys0, keys1, vals0, vals1, hist, parent, flags, bvh_misc;  // bvh_misc: 6 bounds + depth
     DevBuf<float4>   ploc_boxes;  // CAP_BVH_BUILD_PLOC scratch (ploc.hip)
     DevBuf<uint32_t> ploc_ints;
+    DevBuf<uint32_t> sahdev_words;  // CAP_BVH_BUILD_SAH_DEVICE scratch (ploc.hip)
     CapBvhInfo       bvh_info{};
     bool             bvh_ready = false;
 
@@ -792,7 +795,11 @@ int cap_bvh_build(CapContext* c)
     // build -- on the device like the driver build it replaces (blas_system.cpp:42-65), within 1 % of the host SAH tree's trace
     // times (builders table) at 1 / 40 of its build time.  The host SAH build stays available by name.
     const bool sah  = n >= 2 && c->bvh_build_mode == CAP_BVH_BUILD_SAH;
-    const bool ploc = n >= 2 && (c->bvh_build_mode == CAP_BVH_BUILD_PLOC || (c->bvh_build_mode == CAP_BVH_BUILD_AUTO && n > kExhaustiveMax));
+    // ... and from kAutoSahTriangles on the surface-area splits on top of it (round 6): host-SAH quality (expected node visits 44.6 against
+    // 44.4 and the clustering's 47.6 on the 262 k hall) for 10 ms at 262 k and 0.2 s at 16.8 M triangles, built once like the reference's
+    // PREFER_FAST_TRACE structures (blas_system.cpp:44); below, a build is a few dozen launches whatever it holds and the trees do not differ.
+    const bool sahdev = n >= 2 && (c->bvh_build_mode == CAP_BVH_BUILD_SAH_DEVICE || (c->bvh_build_mode == CAP_BVH_BUILD_AUTO && n >= kAutoSahTriangles));
+    const bool ploc = n >= 2 && !sahdev && (c->bvh_build_mode == CAP_BVH_BUILD_PLOC || (c->bvh_build_mode == CAP_BVH_BUILD_AUTO && n > kExhaustiveMax));
     const auto wall0 = std::chrono::steady_clock::now();
     uint32_t   host_depth = 0;
     std::vector<float> bnodes_host;  // the binary tree on the host, for the collapse into the compressed 8-wide view
@@ -810,6 +817,21 @@ int cap_bvh_build(CapContext* c)
         HIP_TRY(hipMemcpy(c->leaf_tri.p, tree.order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
         launch_bvh_finish_host(c->stream, a);
         bnodes_host.swap(tree.nodes);
+    }
+    else if (sahdev)
+    {
+        // surface-area splits from the root down, the clustering inside the finished segments: the PREFER_FAST_TRACE tree the reference
+        // asks its driver for (blas_system.cpp:44), built where the geometry is
+        HIP_TRY(c->ploc_boxes.ensure(4 * (size_t)n));
+        HIP_TRY(c->ploc_ints.ensure(3 * (size_t)n + 4));
+        HIP_TRY(c->sahdev_words.ensure(bvh_sah_device_scratch_words(n)));
+        static const int radius = getenv("CAP_PLOC_RADIUS") ? atoi(getenv("CAP_PLOC_RADIUS")) : 16;  // A/B switches
+        static const int leaf   = getenv("CAP_SAHDEV_LEAF") ? atoi(getenv("CAP_SAHDEV_LEAF")) : 32;
+        const int rc = launch_bvh_build_sah_device(c->stream, a, PlocScratch{c->ploc_boxes.p, c->ploc_ints.p}, c->sahdev_words.p, (uint32_t)radius,
+                                                   (uint32_t)(leaf < 1 ? 1 : leaf));
+        if (rc != 0) return fail(CAP_ERR_HIP, "cap_bvh_build: device surface-area build failed (%d)", rc);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->sahdev_words.release();  // 90 B per triangle, of no use after the build
     }
     else if (ploc)
     {
@@ -862,6 +884,7 @@ int cap_bvh_build(CapContext* c)
             const uint32_t cap = n / 2u + 16u;  // an inner child stands for >= 4 triangles
             HIP_TRY(c->nodes8.ensure((kWideNodeStride / 4) * std::max<size_t>((size_t)cap + 1, kWideTopNodes)));
             HIP_TRY(c->wide_task.ensure(cap));
+            HIP_TRY(c->wide_cnt.ensure(2 * (size_t)cap));
             HIP_TRY(c->wide_alloc.ensure(2));
             double m = 0.0;
             for (int k = 0; k < 3; ++k)
@@ -869,7 +892,7 @@ int cap_bvh_build(CapContext* c)
             WideCollapseArgs wa{};
             wa.bnodes = c->nodes.p, wa.count = c->keys1.p, wa.n_tris = n, wa.capacity = cap;
             wa.pad = (double)kWidePad * std::max(m, 1e-30);
-            wa.task = c->wide_task.p, wa.alloc = c->wide_alloc.p, wa.nodes8 = reinterpret_cast<uint32_t*>(c->nodes8.p), wa.tri_src = c->wide_src.p;
+            wa.task = c->wide_task.p, wa.cnt = c->wide_cnt.p, wa.alloc = c->wide_alloc.p, wa.nodes8 = reinterpret_cast<uint32_t*>(c->nodes8.p), wa.tri_src = c->wide_src.p;
             uint32_t count = 0;
             if (launch_wide_collapse(c->stream, wa, &count, &wdepth, &wtop) != 0) return fail(CAP_ERR_HIP, "cap_bvh_build: device collapse into the 8-wide view failed");
             wn = count;
@@ -1125,7 +1148,7 @@ int cap_debug_get(CapContext* c, uint32_t key, uint64_t* value)
 int cap_set_bvh_build(CapContext* c, uint32_t mode)
 {
     if (!c) return fail(CAP_ERR_INVALID_ARG, "cap_set_bvh_build: ctx is NULL");
-    if (mode > CAP_BVH_BUILD_PLOC) return fail(CAP_ERR_INVALID_ARG, "cap_set_bvh_build: unknown mode %u", mode);
+    if (mode > CAP_BVH_BUILD_SAH_DEVICE) return fail(CAP_ERR_INVALID_ARG, "cap_set_bvh_build: unknown mode %u", mode);
     c->bvh_build_mode = mode;
     return CAP_OK;
 }

@@ -195,7 +195,9 @@ typedef enum CapBvhBuild
     CAP_BVH_BUILD_AUTO = 0,
     CAP_BVH_BUILD_LBVH = 1,
     CAP_BVH_BUILD_SAH  = 2,
-    CAP_BVH_BUILD_PLOC = 3 /* on the device: agglomerative clustering over the Morton order with a surface-area distance */
+    CAP_BVH_BUILD_PLOC = 3, /* on the device: agglomerative clustering over the Morton order with a surface-area distance */
+    CAP_BVH_BUILD_SAH_DEVICE = 4 /* on the device: binned surface-area splits from the root down to small segments, the clustering
+                                  * inside those -- the tree quality the reference requests (PREFER_FAST_TRACE, blas_system.cpp:44) */
 } CapBvhBuild;
 int cap_set_bvh_build(CapContext* ctx, uint32_t mode);
 int cap_bvh_info(CapContext* ctx, CapBvhInfo* out);

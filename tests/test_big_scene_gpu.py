@@ -4,7 +4,7 @@ had been built, traced or checked here.  The procedural hall of tools/make_sponz
 (0.27 GB of intersection records + 0.06 GB of wide nodes + 0.54 GB of shading records: past the 256-MiB Infinity Cache); at
 scale 8 -- bench.py's `big_variant` -- 16.8 M.
 
-* 4.2 M triangles, 1920x1080, depth 8, the three builders (device clustering = AUTO, device Morton hierarchy, host SAH): one
+* 4.2 M triangles, 1920x1080, depth 8, the four builders (device clustering = AUTO, device Morton hierarchy, host SAH, device SAH): one
   WHOLE frame against the oracle for the AUTO tree (six planes and the three ray counters, tolerance 0), three 8-row crops
   (top, middle, bottom: `rows=`) for the other two with counters equal to the AUTO render's, structural invariants of every
   tree (each triangle in exactly one leaf, depth within the kernels' stacks, the 8-wide view in use), guards silent.
@@ -80,7 +80,7 @@ def _compare_crops(r, sc, O, ocam, bluenoise, frame, threads):
             assert nbad == 0, "rows %d..%d, %s: %d pixels differ" % (y0, y1, name, nbad)
 
 
-def test_4m_triangles_three_builders(native_lib, bluenoise):
+def test_4m_triangles_four_builders(native_lib, bluenoise):
     import make_sponza_class as gen
     arrays = gen.arrays(4.0, 256)
     ntri = arrays[3].size // 3
@@ -89,7 +89,7 @@ def test_4m_triangles_three_builders(native_lib, bluenoise):
     threads = min(64, os.cpu_count() or 8)
     frame = 3
     auto_rays = None
-    for build in (capi.Renderer.BVH_BUILD_AUTO, capi.Renderer.BVH_BUILD_LBVH, capi.Renderer.BVH_BUILD_SAH):
+    for build in (capi.Renderer.BVH_BUILD_AUTO, capi.Renderer.BVH_BUILD_LBVH, capi.Renderer.BVH_BUILD_SAH, capi.Renderer.BVH_BUILD_SAH_DEVICE):
         r, info = _renderer(arrays, bluenoise, build)
         _check_tree(r, info, ntri)
         r.render(frame, 1, D, capi.RENDER_AOV)
@@ -123,9 +123,14 @@ def test_16m_triangles(native_lib, bluenoise):
     O, sc, ocam = _oracle(arrays)
     _compare_crops(r, sc, O, ocam, bluenoise, frame, min(64, os.cpu_count() or 8))
     # the same frame through the binary tree's kernels, which take over when the wide view is deeper than the wide kernels' stacks
-    # (here: the bound lowered by hand): this tree is 36 deep, so these are the 64-entry instantiations nothing else reaches
-    assert info.max_depth > 32 and info.stack_entries == 64 and r.debug_get(capi.Renderer.DEBUG_WIDE_IN_USE) == 1
+    # (here: the bound lowered by hand), on the clustering tree: that one is 36 deep at this size (AUTO's surface-area tree: 31), so these
+    # are the 64-entry instantiations nothing else reaches
+    assert r.debug_get(capi.Renderer.DEBUG_WIDE_IN_USE) == 1
     rays_wide = (s.rays_primary, s.rays_extension, s.rays_shadow)
+    r.set_bvh_build(capi.Renderer.BVH_BUILD_PLOC)
+    info = r.build_bvh()
+    _check_tree(r, info, ntri)
+    assert info.max_depth > 32 and info.stack_entries == 64 and r.debug_get(capi.Renderer.DEBUG_WIDE_IN_USE) == 1
     r.debug_set(capi.Renderer.DEBUG_WIDE_DEPTH_LIMIT, 2)
     assert r.debug_get(capi.Renderer.DEBUG_WIDE_IN_USE) == 0
     r.stats_reset()

@@ -78,7 +78,7 @@ def check_tree(nodes, leaves, tri_lo, tri_hi):
     return max_depth
 
 
-@pytest.mark.parametrize("build", [1, 2, 3])  # on-device LBVH, host-side SAH, on-device clustering: same layout, same invariants
+@pytest.mark.parametrize("build", [1, 2, 3, 4])  # on-device LBVH, host-side SAH, on-device clustering, on-device SAH: same layout, same invariants
 @pytest.mark.parametrize("seed,ntri", [(1, 1), (2, 2), (3, 3), (4, 33), (5, 1000), (6, 20000)])
 def test_lbvh_invariants(native_lib, bluenoise, seed, ntri, build):
     pos, nrm, uv, idx, meshes = soup(seed, ntri)
@@ -96,7 +96,7 @@ def test_lbvh_invariants(native_lib, bluenoise, seed, ntri, build):
     r.close()
 
 
-@pytest.mark.parametrize("build", [1, 2, 3])
+@pytest.mark.parametrize("build", [1, 2, 3, 4])
 def test_identical_triangles(native_lib, bluenoise, build):
     # 3000 copies of one triangle: every Morton code, every box and every merge distance ties; the builders' index tie-breaks
     # must still produce a complete tree of bounded depth (the clustering build: mutual nearest neighbours exist in every round)
@@ -113,7 +113,7 @@ def test_identical_triangles(native_lib, bluenoise, build):
     r.close()
 
 
-@pytest.mark.parametrize("build", [0, 1, 3])
+@pytest.mark.parametrize("build", [0, 1, 3, 4])
 def test_duplicate_centroids_and_flat_scene(native_lib, bluenoise, build):
     # all triangles share one centroid / lie in one plane: Morton codes collide, the index tie-break must still give a tree
     base = np.float32([[-1, -1, 0], [1, -1, 0], [0, 2, 0]])
@@ -131,7 +131,7 @@ def test_duplicate_centroids_and_flat_scene(native_lib, bluenoise, build):
     r.close()
 
 
-@pytest.mark.parametrize("build", [1, 2, 3])
+@pytest.mark.parametrize("build", [1, 2, 3, 4])
 @pytest.mark.parametrize("seed,ntri,w,h,D", [(11, 1, 48, 48, 2), (12, 2, 48, 48, 2), (13, 300, 96, 96, 3), (14, 5000, 128, 96, 4),
                                             (15, 700, 61, 37, 3)])  # the last: partial tiles (idle lanes in the camera-ray packets)
 def test_triangle_soup_parity(native_lib, bluenoise, seed, ntri, w, h, D, build):
@@ -234,7 +234,7 @@ def test_fan_pairs_parity(native_lib, bluenoise, seed, nquads, nsingles, fold):
     r.close()
 
 
-@pytest.mark.parametrize("build", [1, 2, 3])
+@pytest.mark.parametrize("build", [1, 2, 3, 4])
 def test_geometric_progression_scene(native_lib, bluenoise, build):
     """Triangles whose size and distance grow geometrically: the SAH build wants to peel them off one by one (a tree as deep as
     the triangle count) and Morton codes collapse most of them into one cell.  Both builders must stay within the traversal
@@ -352,7 +352,7 @@ def test_textured_quad_parity(native_lib, bluenoise, shape):
     r.close()
 
 
-@pytest.mark.parametrize("n,build", [(2, 1), (7, 1), (500, 1), (20000, 1), (20000, 2), (2, 3), (7, 3), (1500, 3), (20000, 3)])
+@pytest.mark.parametrize("n,build", [(2, 1), (7, 1), (500, 1), (20000, 1), (20000, 2), (2, 3), (7, 3), (1500, 3), (20000, 3), (40, 4), (1500, 4), (20000, 4)])
 def test_wide_view_structure_on_device(native_lib, n, build):
     """The compressed 8-wide view as cap_bvh_build leaves it on the device -- collapsed on the device itself for the device-built
     LBVH (bvh.hip k_wide_level), on the host for the SAH tree -- satisfies the structural and conservativeness checks of the host
@@ -378,3 +378,22 @@ def test_wide_view_structure_on_device(native_lib, n, build):
     if n >= 20000:
         assert depth <= 14 and len(wide) < n // 3
     r.close()
+
+
+@pytest.mark.parametrize("ntri", [33, 2000, 50000])
+def test_sah_device_build_is_deterministic(native_lib, ntri):
+    """CAP_BVH_BUILD_SAH_DEVICE (ploc.hip): bins are integer atomics, positions and node numbers come from prefix sums -- two builds of one
+    scene give the same bytes, binary tree and 8-wide view alike (every rank of a multi-GPU job builds its own copy)."""
+    pos, nrm, uv, idx, meshes = soup(40 + ntri % 7, ntri)
+    out = []
+    for _ in range(2):
+        r = capi.Renderer(0)
+        r.upload_scene(pos, nrm, uv, idx, meshes)
+        r.set_bvh_build(capi.Renderer.BVH_BUILD_SAH_DEVICE)
+        r.build_bvh()
+        nodes, leaves = r.bvh_readback()
+        wn, wsrc, _, _ = r.bvh_wide_readback()
+        out.append((nodes.copy(), leaves.copy(), wn.copy(), wsrc.copy()))
+        r.close()
+    for a, b in zip(*out):
+        assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))

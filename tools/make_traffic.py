@@ -47,7 +47,17 @@ def total(pass_glob, counter, kernel):
         if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
             s += float(r["Counter_Value"])
             n += 1
+            DURATION_NS[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     return s, n
+
+
+DURATION_NS = [0.0]  # of the dispatches the last total() summed (the counter file carries every dispatch's start and end)
+
+
+def total_timed(pass_glob, counter, kernel):
+    DURATION_NS[0] = 0.0
+    s, n = total(pass_glob, counter, kernel)
+    return s, n, DURATION_NS[0]
 
 
 PASSES = listed_passes()
@@ -68,6 +78,17 @@ for key, (wl, name) in KERNELS.items():
          "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / n}
     if n3:
         k["valu_insts_per_launch"] = valu / n3
+    # the vector ALU's busy fraction from the counters alone.  SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader
+    # cycles) in which a wave has a vector instruction executing, summed over the chip's 1024 SIMDs; the clock the kernel really ran
+    # at is GRBM_GUI_ACTIVE / 8 XCDs / the dispatches' own duration in that pass (MI355X_MICROARCH.md "DVFS give-back"): nothing assumed.
+    act, n4, ns4 = total_timed("prof_%s_pmc_SQ_WAIT_ANY*" % wl, "SQ_ACTIVE_INST_VALU", name)
+    gui, n5, ns5 = total_timed("prof_%s_pmc_TA_TA_BUSY*" % wl, "GRBM_GUI_ACTIVE", name)
+    if n4 and n5 and ns4 > 0 and ns5 > 0:
+        clock_ghz = gui / 8.0 / ns5
+        k["valu_busy"] = {"SQ_ACTIVE_INST_VALU_quadcycles_per_launch": act / n4, "launch_ns_in_that_pass": ns4 / n4,
+                          "effective_clock_ghz": clock_ghz, "simds": 1024,
+                          "valu_busy_frac": act * 4.0 / (ns4 * clock_ghz * 1024.0),
+                          "valu_busy_frac_at_2p4_ghz": act * 4.0 / (ns4 * 2.4 * 1024.0)}
     out["kernels"][key] = k
 for wl in ("big", "tree"):
     fetch = sum(total("prof_%s_pmc_FETCH_SIZE" % wl, "FETCH_SIZE", k)[0] for k in STEP_KERNELS)

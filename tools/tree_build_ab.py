@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from capsaicin_amd import capi  # noqa: E402
 
-MODES = ((1, "LBVH (device)"), (2, "SAH (host)"), (3, "PLOC (device)"))
+MODES = ((1, "LBVH (device)"), (2, "SAH (host)"), (3, "PLOC (device)"), (4, "SAH (device)"))
 for mode, name in [mn for mn in MODES if len(sys.argv) < 2 or str(mn[0]) in sys.argv[1:]]:
     r = capi.Renderer(0)
     r.set_bvh_build(mode)

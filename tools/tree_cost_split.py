@@ -13,7 +13,7 @@ from capsaicin_amd import capi  # noqa: E402
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 EDGES = [1, 8, 64, 512, 4096, 32768, 262144, 1 << 30]
-for mode, name in ((3, "PLOC (device)"), (2, "SAH (host)")):
+for mode, name in ((3, "PLOC (device)"), (4, "SAH (device)"), (2, "SAH (host)")):
     r = capi.Renderer(0)
     r.set_bvh_build(mode)
     bench.load_sponza_class(r, scale=scale)
