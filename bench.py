@@ -82,9 +82,15 @@ def roofline_object(kernel_name, counters_key, kernel_bytes, launches, kernel_ms
     if pmc and pmc.get("valu_insts_per_launch"):
         valu = {"wave_insts_per_launch": pmc["valu_insts_per_launch"], "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
                 "issue_frac": pmc["valu_insts_per_launch"] / (avg_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S,
-                "note": "issue_frac is against one wave64 instruction per 2 cycles and SIMD, a rate no real mix reaches: measured at six "
-                        "waves per SIMD (profiles/r05_micro/valu_cost.txt) FMA / mul / add / mov issue at ~3 cycles, conversions, min / "
-                        "max, selects by SGPR mask and bit operations at ~4, transcendentals at ~8"}
+                "note": "issue_frac is against one wave64 instruction per 2 cycles and SIMD at an assumed 2.4 GHz -- the rate of the full-rate class "
+                        "only (profiles/r06_micro/valu_cost.txt, s_memtime-timed: FMA / mul / add / mov / bitop3 2.1 cycles per SIMD, conversions, "
+                        "min / max, selects, compares, shifts and bit-field operations 4.0, transcendentals 8.0; one wave alone: 4.2 / 8.2).  "
+                        "valu_busy_frac and issue_cycles_frac are the counter-derived figures at the clock the kernel really ran at"}
+        if pmc.get("valu_busy"):
+            vb = pmc["valu_busy"]
+            valu.update({"valu_busy_frac": vb["valu_busy_frac"], "issue_cycles_frac": vb.get("issue_cycles_frac"),
+                         "static_issue_cycles_per_inst": vb.get("static_issue_cycles_per_inst"), "effective_clock_ghz": vb["effective_clock_ghz"],
+                         "valu_busy_note": vb["note"]})
     o = {"bound": "valu", "bound_note": "vector-instruction issue (+ exposed latency), not HBM: see `valu` and DESIGN.md 5; "
                                         "achieved / peak / frac are the contract's algorithmic HBM bytes against the 8 TB/s peak",
          "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -362,7 +368,7 @@ def tree_variant(dev, stream):
     return {"workload": "sponza_class.obj (procedural, %d triangles, textured) %dx%d %dspp depth=%d, reference shading" %
                         (bi2.triangle_count, WIDTH, HEIGHT, TREE_FULL_SPP, DEPTH),
             "value": rays(ts) / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
-            "bvh": {"build": "device PLOC + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
+            "bvh": {"build": "device SAH splits + clustering + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
             "batch_32spp": {"value": rays(ts32) / 2 / dt32 / 1e6, "ms_per_step": dt32 * 1e3,
                             "stage_ms": {k: v / 2 for k, v in stage_ms(tp).items()}},
             "roofline": troof, "shade_roofline": sroof}
@@ -394,7 +400,7 @@ def big_variant(dev, stream):
     return {"workload": "sponza_class hall at scale %g (procedural, %d triangles, textured) %dx%d %dspp depth=%d, reference shading" %
                         (BIG_SCALE, n, WIDTH, HEIGHT, BIG_SPP, DEPTH),
             "value": rays / 2 / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
-            "bvh": {"build": "device PLOC + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi.max_depth), "build_ms": float(bi.build_ms),
+            "bvh": {"build": "device SAH splits + clustering + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi.max_depth), "build_ms": float(bi.build_ms),
                     "wide_nodes": winfo[0], "wide_depth": winfo[1], "triangles_per_s_build": n / (bi.build_ms * 1e-3),
                     "resident_bytes": {"wide_nodes": 80 * winfo[0], "intersection_records": 64 * n, "shading_records": 128 * n}},
             "scene_setup_s": setup_s, "roofline": troof, "shade_roofline": sroof, "stage_ms": {k: v / 2 for k, v in stage_ms(bp).items()},
@@ -553,8 +559,101 @@ def realtime_frame_variant(dev, stream):
         out[name] = {"ms_per_frame": total, "ray_passes_ms": st.ms_total / 20, "chain_ms": st.ms_post / 20,
                      "chain_passes_ms": dict(zip(("gather", "temporal", "eaw", "combine", "taa"), (x / 20 for x in st.ms_post_pass))),
                      "frames_per_s": 1e3 / total, "rays_per_frame": (st.rays_primary + st.rays_extension + st.rays_shadow) / 20}
+    # The viewer's real use is a fly camera (input_system.cpp:49-148), not a tripod (VERDICT r5 missing 4): the same loop with the camera
+    # moving every frame -- a dolly along the view with a strafe and a slow turn, the per-frame steps of a hand on W + A and the mouse --
+    # so that reprojection misses at the silhouettes, BlurDisocclusion has tiles to filter, and IntegrateTemporally / TAA take their
+    # moving branches from frame 8 on, where the static loop above stages nothing.
+    import math
+
+    def fly(f):
+        c = capi.CameraData.from_buffer_copy(bytes(cam))
+        yaw = math.radians(180.0 + 0.15 * f)
+        fwd = (math.sin(yaw), 0.0, math.cos(yaw))
+        c.forward[:] = fwd
+        c.right[:] = (-fwd[2], 0.0, fwd[0])  # normalize(-cross(forward, (0, 1, 0))), input_system.cpp:134-141
+        c.up[:] = (0.0, 1.0, 0.0)
+        c.position[0] = cam.position[0] + 0.004 * f
+        c.position[1] = cam.position[1] + 0.001 * f
+        c.position[2] = cam.position[2] - 0.012 * f
+        return c
+
+    out["moving"] = {"what": "the same loop, camera moving every frame: 12 mm dolly + 4 mm strafe + 0.15 degrees of yaw per frame, frames 3..22"}
+    for name, fast in (("exact", 0), ("fast_weights", 1)):
+        ps = capi.PostSettings(fast_weights=fast)
+        r.post_reset()
+
+        def mframe(f):
+            c, p = fly(f), fly(max(0, f - 1))
+            r.set_camera(c)
+            r.set_prev_camera(p)
+            r.render(f, 1, 1, fl)
+            r.post_frame(ps, f, p)
+
+        for f in range(3):
+            mframe(f)
+        r.sync()
+        r.stats_reset()
+        t0 = time.perf_counter()
+        for f in range(3, 23):
+            mframe(f)
+        r.sync()
+        total = (time.perf_counter() - t0) / 20 * 1e3
+        st = r.stats()
+        out["moving"][name] = {"ms_per_frame": total, "ray_passes_ms": st.ms_total / 20, "chain_ms": st.ms_post / 20,
+                               "chain_passes_ms": dict(zip(("gather", "temporal", "eaw", "combine", "taa"), (x / 20 for x in st.ms_post_pass))),
+                               "frames_per_s": 1e3 / total, "rays_per_frame": (st.rays_primary + st.rays_extension + st.rays_shadow) / 20}
     r.close()
     return out
+
+
+def ingest_variant(dev, stream):
+    """The step BEFORE the path (asset_load_system.cpp:43-255, texture_system.cpp:38-118): the 262 k-triangle textured
+    hall as an OBJ + MTL + twelve 1024 x 1024 texture files on disk (written by tools/make_sponza_class.py, not timed) through the
+    product's own ingestion -- cap_obj_load (parse, triangulate, MeshComponent table), cap_image_decode of the texture files on the
+    host's threads, cap_scene_upload_geometry + cap_texture_upload (bilinear footprints built on the device), cap_bvh_build."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from capsaicin_amd import capi
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_sponza_class as gen
+    tmp = tempfile.mkdtemp(prefix="cap_ingest_")
+    try:
+        ntri = gen.write(tmp, 1.0, 1024)
+        obj = os.path.join(tmp, "sponza_class.obj")
+        obj_bytes = os.path.getsize(obj)
+        t0 = time.perf_counter()
+        geo = capi.Geometry(obj)
+        t_parse = time.perf_counter() - t0
+        files = [os.path.join(tmp, "textures", os.path.basename(n)) if not os.path.exists(os.path.join(tmp, n)) else os.path.join(tmp, n)
+                 for n in geo.texture_names]
+        tex_bytes = sum(os.path.getsize(f) for f in files)
+        threads = max(1, min(len(files), host_cores()))
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL inside cap_image_decode
+            texs = list(ex.map(lambda f: capi.image_decode(open(f, "rb").read(), f), files))
+        t_decode = time.perf_counter() - t0
+        r = capi.Renderer(dev, stream)
+        t0 = time.perf_counter()
+        r.upload_geometry(geo)
+        for i, t in enumerate(texs):
+            r.upload_texture(i, t)
+        r.sync()
+        t_upload = time.perf_counter() - t0
+        r.upload_bluenoise(capi.load_bluenoise())
+        t0 = time.perf_counter()
+        bi = r.build_bvh()
+        t_build = time.perf_counter() - t0
+        r.close()
+        total = t_parse + t_decode + t_upload + t_build
+        return {"what": "sponza_class.obj (%d triangles, %.1f MB of OBJ text) + MTL + %d textures of 1024 x 1024 (%.1f MB of files): disk -> traceable scene"
+                        % (ntri, obj_bytes / 1e6, len(files), tex_bytes / 1e6),
+                "parse_ms": t_parse * 1e3, "parse_mb_per_s": obj_bytes / 1e6 / t_parse, "parse_mtriangles_per_s": ntri / 1e6 / t_parse,
+                "texture_decode_ms": t_decode * 1e3, "texture_decode_threads": threads, "texture_decode_mpixels_per_s": len(files) * 1024 * 1024 / 1e6 / t_decode,
+                "upload_ms": t_upload * 1e3, "build_ms": float(bi.build_ms), "build_wall_ms": t_build * 1e3,
+                "build_mtriangles_per_s": ntri / 1e6 / (bi.build_ms * 1e-3), "total_ms": total * 1e3, "mtriangles_per_s": ntri / 1e6 / total}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def guarded(fn, *a):
@@ -615,7 +714,7 @@ def main():
         stream = torch.cuda.Stream()
         with torch.cuda.stream(stream):
             fn = {"ext": lambda d, s: ext_variant(d, s, max(1, args.steps), spp), "tree": tree_variant, "big": big_variant, "config3": config3_variant,
-                  "config5": config5_share, "post": post_chain_variant, "realtime": realtime_frame_variant}[args.only]
+                  "config5": config5_share, "post": post_chain_variant, "realtime": realtime_frame_variant, "ingest": ingest_variant}[args.only]
             print(json.dumps({"only": args.only, "result": fn(device_index, stream.cuda_stream)}), flush=True)
         return
 
@@ -646,6 +745,13 @@ def main():
         if args.batch_paths:
             r.set_batch_paths(args.batch_paths)
         r.set_traversal(args.traversal)
+        # every rank builds its own copy of the tree: the builders are deterministic (prefix sums, integer atomics), so the copies are the
+        # same bytes -- shown per rank for the tree path's workload (tests/test_comm_gpu.py asserts it)
+        wide_sha = None
+        if sponza:
+            import hashlib
+            wn, wsrc, _, _ = r.bvh_wide_readback()
+            wide_sha = hashlib.sha1(np.ascontiguousarray(wn).tobytes() + np.ascontiguousarray(wsrc).tobytes()).hexdigest()
         tile_floats = r.tile_buffer_floats()
         tile_buf = torch.zeros(tile_floats, dtype=torch.float32, device="cuda")
         gathered = torch.zeros(tile_floats * world, dtype=torch.float32, device="cuda") if rank == 0 else None
@@ -784,6 +890,10 @@ def main():
         else:
             per_rank = [mine]
         stage_ms_per_rank = [dict(zip(("primary", "trace_closest", "trace_any", "shade", "resolve", "total"), m)) for m in per_rank]
+        wide_sha_per_rank = [wide_sha]
+        if world > 1:
+            wide_sha_per_rank = [None] * world
+            dist.all_gather_object(wide_sha_per_rank, wide_sha)
         roofline = None
         if rank == 0 and sp.launches_trace_closest:
             fused = sp.launches_shade == 0
@@ -843,6 +953,7 @@ def main():
                                            "sponza_class_128spp": shard_cost(lambda: make_hall(device_index, s_h)[0], TREE_FULL_SPP, DEPTH, reps=2)})
         post_chain = guarded(post_chain_variant, device_index, s_h) if extras else None
         realtime = guarded(realtime_frame_variant, device_index, s_h) if extras else None
+        ingest = guarded(ingest_variant, device_index, s_h) if extras else None
 
         if rank == 0:
             # sanity of the product of the timed region: finite image, every pixel accumulated spp frames
@@ -857,7 +968,7 @@ def main():
                                           "tile-sharded over %d GPU(s)" % (WIDTH, HEIGHT, spp, DEPTH, world),
                               "triangles": int(bvh.triangle_count), "bvh_depth": int(bvh.max_depth),
                               "rays_per_step": {"primary": rays_p / args.steps, "extension": rays_e / args.steps, "shadow": rays_s / args.steps},
-                              "parallelism": "tiles%d" % world, "exchange": exchange},
+                              "parallelism": "tiles%d" % world, "exchange": exchange, "wide_tree_sha1_per_rank": wide_sha_per_rank},
                    # BASELINE configs[1] reads "Lambert+GGX": that literal configuration is the EXT model's line below (ext_variant);
                    # `value` is the reference's own shading model on the same scene, camera, resolution, spp and depth
                    "value_literal_config": ext.get("value") if isinstance(ext, dict) else None,
@@ -866,7 +977,7 @@ def main():
                    "exchange": exchange, "stage_ms_per_rank": stage_ms_per_rank,
                    "roofline": roofline, "ext_variant": ext, "tree_variant": tree, "big_variant": big, "config3_variant": c3,
                    "config5_share": c5, "shard_cost": shard_costs, "post_chain": post_chain,
-                   "realtime_frame": realtime}
+                   "realtime_frame": realtime, "ingest": ingest}
             out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()  # rank 0, N = 1 only
             print(json.dumps(out), flush=True)
         r.close()

@@ -12,6 +12,9 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libcapsaicin_hip.so")
+# A/B and diagnostic builds made by tools/build_variant.sh (compile-time switches measured against the product build in one GPU call)
+if os.environ.get("CAP_LIB_VARIANT"):
+    LIB_PATH = os.path.join(_PKG, "variants", "libcapsaicin_hip_%s.so" % os.environ["CAP_LIB_VARIANT"])
 
 RENDER_AOV = 1
 RENDER_EXT_MATERIALS = 2

@@ -87,6 +87,71 @@ __device__ __forceinline__ WideNode wide_node_load(const float4* __restrict__ N)
 }
 
 // Box tests of the eight children of a node; replaces the cursor's groups by the node's.
+#ifndef CAP_W8_NODE_V1
+// Box tests of the eight children of a node; replaces the cursor's groups by the node's.
+// Round 6 form, written against the measured issue rates of docs/experiments.md (74) (tools/micro/valu_cost.hip): per SIMD a wave64
+// v_fma / v_sub / v_bitop3 costs 2 cycles, a select, a compare, a two-operand min / max, a byte conversion or a shift 4.  So
+//   * the near / far plane words are picked with bit selects (v_bitop3_b32) by the sign words of the ray's 1 / d instead of 24 selects
+//     by SGPR mask, and the octant permutation's three conditional swaps likewise;
+//   * a child's verdict is the sign of three differences -- exit - entry, tfar - entry, exit - tmin: the box interval is empty, starts
+//     behind the ray's end, or ends before its start -- OR-ed by one v_bitop3 and shifted into the mask by one v_alignbit, instead of
+//     clamping entry and exit with tmin / tfar (two min / max), a compare, a select and an OR;
+// 26 -> 20 instructions per child, 16 of the 24 that remain half-rate are the six byte conversions and the two three-operand min / max.
+// Same verdicts for every finite operand: max(entry, tmin) <= min(exit, tfar)  <=>  entry <= exit, entry <= tfar, tmin <= exit (tmin <=
+// tfar holds for a live ray); a NaN difference (inf - inf) reads as "hit", which only costs a visit.  The hit rule never looks at boxes.
+__device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay& r, float tmin, float tfar, WideCursor& c)
+{
+    const float4   h0 = n.h0, h1 = n.h1, q2 = n.q2, q3 = n.q3, q4 = n.q4;
+    const uint32_t syz = f2u(h1.w);  // the y and z steps' upper halves (powers of two: the lower halves are zero)
+    const float    ax = h0.w * r.inv.x, ay = u2f(syz & 0xffff0000u) * r.inv.y, az = u2f(syz << 16) * r.inv.z;
+    const float    bx = fmaf(h0.x, r.inv.x, r.noi.x), by = fmaf(h0.y, r.inv.y, r.noi.y), bz = fmaf(h0.z, r.inv.z, r.noi.z);
+    // all ones where the direction component is negative (1 / d is never +-0: |d| <= 1): such a ray enters through the high plane
+    const uint32_t mx = (uint32_t)((int32_t)f2u(r.inv.x) >> 31), my = (uint32_t)((int32_t)f2u(r.inv.y) >> 31), mz = (uint32_t)((int32_t)f2u(r.inv.z) >> 31);
+    const uint32_t lx0 = f2u(q2.x), lx1 = f2u(q2.y), ly0 = f2u(q2.z), ly1 = f2u(q2.w), lz0 = f2u(q3.x), lz1 = f2u(q3.y);
+    const uint32_t hx0 = f2u(q3.z), hx1 = f2u(q3.w), hy0 = f2u(q4.x), hy1 = f2u(q4.y), hz0 = f2u(q4.z), hz1 = f2u(q4.w);
+#define CAP_W8_SEL(m, a, b) __builtin_amdgcn_bitop3_b32((m), (a), (b), 0xca) /* m ? a : b, bit by bit: truth-table index = m * 4 + a * 2 + b */
+    const uint32_t nx0 = CAP_W8_SEL(mx, hx0, lx0), nx1 = CAP_W8_SEL(mx, hx1, lx1), fx0 = CAP_W8_SEL(mx, lx0, hx0), fx1 = CAP_W8_SEL(mx, lx1, hx1);
+    const uint32_t ny0 = CAP_W8_SEL(my, hy0, ly0), ny1 = CAP_W8_SEL(my, hy1, ly1), fy0 = CAP_W8_SEL(my, ly0, hy0), fy1 = CAP_W8_SEL(my, ly1, hy1);
+    const uint32_t nz0 = CAP_W8_SEL(mz, hz0, lz0), nz1 = CAP_W8_SEL(mz, hz1, lz1), fz0 = CAP_W8_SEL(mz, lz0, hz0), fz1 = CAP_W8_SEL(mz, lz1, hz1);
+    uint32_t       miss = 0u;  // children 7 .. 0 shifted in from the right: bit s = child s's box interval misses [tmin, tfar]
+#define CAP_W8_CHILD(nxw, nyw, nzw, fxw, fyw, fzw, sh)                                                                                    \
+    {                                                                                                                                    \
+        const float tnx = fmaf((float)(((nxw) >> (sh)) & 0xffu), ax, bx), tny = fmaf((float)(((nyw) >> (sh)) & 0xffu), ay, by),         \
+                    tnz = fmaf((float)(((nzw) >> (sh)) & 0xffu), az, bz);                                                                \
+        const float tfx = fmaf((float)(((fxw) >> (sh)) & 0xffu), ax, bx), tfy = fmaf((float)(((fyw) >> (sh)) & 0xffu), ay, by),         \
+                    tfz = fmaf((float)(((fzw) >> (sh)) & 0xffu), az, bz);                                                                \
+        const float tn = fmaxf(fmaxf(tnx, tny), tnz), tf = fminf(fminf(tfx, tfy), tfz);                                                  \
+        const uint32_t sg = __builtin_amdgcn_bitop3_b32(f2u(tf - tn), f2u(tfar - tn), f2u(tf - tmin), 0xfe);                             \
+        miss = __builtin_amdgcn_alignbit(miss, sg, 31);                                                                                  \
+    }
+    CAP_W8_CHILD(nx1, ny1, nz1, fx1, fy1, fz1, 24)
+    CAP_W8_CHILD(nx1, ny1, nz1, fx1, fy1, fz1, 16)
+    CAP_W8_CHILD(nx1, ny1, nz1, fx1, fy1, fz1, 8)
+    CAP_W8_CHILD(nx1, ny1, nz1, fx1, fy1, fz1, 0)
+    CAP_W8_CHILD(nx0, ny0, nz0, fx0, fy0, fz0, 24)
+    CAP_W8_CHILD(nx0, ny0, nz0, fx0, fy0, fz0, 16)
+    CAP_W8_CHILD(nx0, ny0, nz0, fx0, fy0, fz0, 8)
+    CAP_W8_CHILD(nx0, ny0, nz0, fx0, fy0, fz0, 0)
+#undef CAP_W8_CHILD
+    const uint32_t masks = f2u(h1.z), imask = masks >> 24, tvalid = masks & 0x00ffffffu;
+    const uint32_t h8 = ~miss & 0xffu;
+    // an unused slot is told by the masks, not by its planes (no plane content fails the conservative test reliably)
+    // the hit inner children in visiting priority: bit i <- bit i ^ octinv (octinv's bits are the negated signs: swap where the sign is +)
+    uint32_t m = h8 & imask;
+    uint32_t a = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    m          = CAP_W8_SEL(mx, m, a);
+    a          = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    m          = CAP_W8_SEL(my, m, a);
+    a          = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    m          = CAP_W8_SEL(mz, m, a);
+#undef CAP_W8_SEL
+    c.g_base  = f2u(h1.x);
+    c.g_mask  = (m << 24) | imask;
+    c.t_base  = f2u(h1.y);
+    c.t_valid = tvalid;
+    c.t_hits  = __builtin_amdgcn_perm(h8, h8, 0x0c000000u) & tvalid;  // h8 in the three low bytes (one v_perm_b32)
+}
+#else
 #ifdef CAP_W8_COUNT  // diagnostic build: the children's entry distances, by slot
 #define CAP_W8_TN_ARG , float* tn_out = nullptr
 #define CAP_W8_TN_OUT(slot, tn) if (tn_out) tn_out[slot] = tn;
@@ -134,6 +199,8 @@ __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay&
     c.t_valid = tvalid;
     c.t_hits  = __builtin_amdgcn_perm(h8, h8, 0x0c000000u) & tvalid;  // h8 in the three low bytes (one v_perm_b32)
 }
+
+#endif  // CAP_W8_NODE_V1
 
 // Takes the next due triangle out of the triangle group; returns its record index.
 __device__ __forceinline__ uint32_t wide_pick_triangle(WideCursor& c)

@@ -188,3 +188,6 @@ def test_bench_two_ranks_sponza_workload(native_lib):
     assert d["exchange"] == "torch.distributed.gather" and len(d["stage_ms_per_rank"]) == 2
     assert all(st["shade"] > 0 and st["trace_any"] > 0 for st in d["stage_ms_per_rank"])  # the tree path's stand-alone stages ran
     assert d["config"]["rays_per_step"]["primary"] == 2 * 1920 * 1080
+    # every rank built its own copy of the tree (device SAH splits + clustering + 8-wide collapse): the same bytes on both
+    sha = d["config"]["wide_tree_sha1_per_rank"]
+    assert len(sha) == 2 and sha[0] and sha[0] == sha[1]

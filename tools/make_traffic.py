@@ -60,7 +60,39 @@ def total_timed(pass_glob, counter, kernel):
     return s, n, DURATION_NS[0]
 
 
+def static_issue_costs():
+    """Average issue cycles per vector instruction of the priced kernels, from their device listings (hipcc -S here) at the measured class
+    costs (tools/isa_count.py): what turns a kernel's SQ_INSTS_VALU into SIMD issue cycles.  Static mix of the whole kernel -- its loop
+    dominates both the listing and the execution."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import isa_count
+    csrc = os.path.join(root, "capsaicin_amd", "csrc")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fno-vectorize", "-w",
+             "-I" + os.path.join(root, "include"), "--cuda-device-only", "-S"]
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for src, keys in (("trace8.hip", {"k_trace_closest8": "k_trace_closest8"}),
+                          ("kernels.hip", {"k_trace_shade<false, false, false, true>": "k_trace_shadeILb0ELb0ELb0ELb1E",
+                                           "k_trace_shade<false, true, false, true>": "k_trace_shadeILb0ELb1ELb0ELb1E", "k_shade<": "k_shadeILb0E",
+                                           "k_trace_any<": "k_trace_anyILi24E"})):
+            lst = os.path.join(tmp, src + ".s")
+            try:
+                subprocess.run(["/opt/rocm/bin/hipcc"] + flags + [os.path.join(csrc, src), "-o", lst], check=True, capture_output=True, timeout=900)
+            except Exception:
+                continue
+            for name, key in keys.items():
+                try:
+                    _, tot = isa_count.kernel_blocks(lst, key)
+                    out[name] = tot["cyc"] / max(1, tot["valu"])
+                except StopIteration:
+                    pass
+    return out
+
+
 PASSES = listed_passes()
+ISSUE = static_issue_costs()
 out = {"source_sha256": bench.kernel_source_sha(), "kernels": {},
        "method": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ block, each in its own run, no trace options), one workload per "
                  "run: `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` (headline), `bench.py --only ext`, and with "
@@ -88,7 +120,15 @@ for key, (wl, name) in KERNELS.items():
         k["valu_busy"] = {"SQ_ACTIVE_INST_VALU_quadcycles_per_launch": act / n4, "launch_ns_in_that_pass": ns4 / n4,
                           "effective_clock_ghz": clock_ghz, "simds": 1024,
                           "valu_busy_frac": act * 4.0 / (ns4 * clock_ghz * 1024.0),
-                          "valu_busy_frac_at_2p4_ghz": act * 4.0 / (ns4 * 2.4 * 1024.0)}
+                          "valu_busy_frac_at_2p4_ghz": act * 4.0 / (ns4 * 2.4 * 1024.0),
+                          "note": "SQ_ACTIVE_INST_VALU is summed per WAVE in quad-cycles: an instruction of the full-rate class holds its wave for one "
+                                  "quad-cycle but the SIMD for two cycles, so two waves' counts overlap and the sum can exceed the SIMD's time -- an upper "
+                                  "bound of the unit's occupancy.  issue_cycles_frac prices the same launches from SQ_INSTS_VALU and the measured class costs"}
+        cyc = ISSUE.get(name)
+        if cyc and n3:
+            vs, _, ns3 = total_timed("prof_%s_pmc_SQ_WAVES*" % wl, "SQ_INSTS_VALU", name)
+            k["valu_busy"]["static_issue_cycles_per_inst"] = cyc
+            k["valu_busy"]["issue_cycles_frac"] = vs * cyc / (ns3 * clock_ghz * 1024.0)
     out["kernels"][key] = k
 for wl in ("big", "tree"):
     fetch = sum(total("prof_%s_pmc_FETCH_SIZE" % wl, "FETCH_SIZE", k)[0] for k in STEP_KERNELS)
