@@ -114,6 +114,7 @@ SYMBOLS = {
     "cap_set_traversal": (_i, [_vp, _u32]),
     "cap_debug_set": (_i, [_vp, _u32, _u64]),
     "cap_debug_get": (_i, [_vp, _u32, C.POINTER(_u64)]),
+    "cap_debug_switch_index": (_i, [C.c_char_p]),
     "cap_render": (_i, [_vp, _u32, _u32, _u32, _u32]),
     "cap_accum_reset": (_i, [_vp]),
     "cap_accum_import": (_i, [_vp, _vp, _u64]),
@@ -432,6 +433,15 @@ class Renderer:
 
     def debug_set(self, key, value):
         _check(lib().cap_debug_set(self.ctx, key, value), "cap_debug_set")
+
+    DEBUG_SWITCH_BASE = 64
+
+    def debug_switch(self, name, value):
+        """Sets one of the A/B switches of the context's table by its (environment-variable) name; value None = the product's choice."""
+        i = lib().cap_debug_switch_index(name.encode())
+        if i < 0:
+            raise CapError("unknown switch %s" % name)
+        self.debug_set(self.DEBUG_SWITCH_BASE + i, 0xFFFFFFFFFFFFFFFF if value is None else int(value))
 
     def debug_get(self, key):
         v = _u64()

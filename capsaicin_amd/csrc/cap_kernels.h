@@ -5,6 +5,45 @@
 
 namespace cap
 {
+// A/B and diagnostic switches: ONE table per context (round 6; 26 getenv() calls with function-local statics before), filled from the
+// environment once at cap_ctx_create and settable per context with cap_debug_set(ctx, CAP_DEBUG_SWITCH_BASE + index, value), so that a
+// test or a tool flips a path without a child process.  -1 = not set: the product's own choice.  The names are the environment
+// variables' (kSwitchNames, context.hip); the launchers read the table through LaunchCfg.
+enum CapSwitch : uint32_t
+{
+    SW_NO_WIDE8 = 0,      // binary-tree kernels instead of the compressed 8-wide view
+    SW_LANE1_PRIORITY,    // stream priority of the second lane
+    SW_PLOC_RADIUS,       // clustering search window
+    SW_SAHDEV_LEAF,       // sah_device: segments of at most this many triangles go to the clustering
+    SW_WIDE_HOST_COLLAPSE,
+    SW_TRACE_LAUNCHES,    // name every launch on stderr and drain the stream after it
+    SW_NO_TWO_LANES,
+    SW_LANE_SPLIT_MIN,
+    SW_BLOCKS_PER_CU,
+    SW_NO_CAMERA_CULL,
+    SW_NO_ALBEDO_IN_W,
+    SW_NO_INLINE_NEE,
+    SW_NO_INLINE_PROBE,
+    SW_NO_WAVE_RING,
+    SW_ANY_REFILL,        // 0 never, 1 always: the lane-refill any-hit kernel
+    SW_PRIMARY_WIDE,      // 0 never, 1 whenever allowed: camera rays through k_trace_closest8
+    SW_NO_PACKET,
+    SW_NO_ANY_PROBE,
+    SW_ANY_PROBE,
+    SW_ANY_BLOCKS,
+    SW_NO_PRIMARY_FUSE,
+    SW_W8_REFILL,
+    SW_W8_GRID,
+    SW_AUTO_SAH_TRIANGLES,  // AUTO builds with surface-area splits from this many triangles on
+    SW_COUNT
+};
+struct SwitchTable
+{
+    int64_t v[SW_COUNT];
+    bool    on(CapSwitch k) const { return v[k] > 0; }              // presence flags: set and not 0
+    int64_t get(CapSwitch k, int64_t dflt) const { return v[k] >= 0 ? v[k] : dflt; }
+};
+
 struct LaunchCfg
 {
     hipStream_t stream;
@@ -13,6 +52,9 @@ struct LaunchCfg
     uint32_t    cu_count = 0;   // compute units (0: unknown) -- persistent kernels with a static chunk assignment clamp their grid
                                 // to what is resident at once, see resident_grid() in kernels.hip
     uint32_t    any_no_probe = 0;  // launch_trace_any: the producer already probed (ShadeArgs::inline_probe): plain per-chunk kernel
+    const SwitchTable* sw = nullptr;  // the context's A/B switches (null: every switch at the product's choice)
+    bool    sw_on(CapSwitch k) const { return sw && sw->on(k); }
+    int64_t sw_get(CapSwitch k, int64_t dflt) const { return sw ? sw->get(k, dflt) : dflt; }
 };
 
 // ---- trace ----

@@ -173,6 +173,7 @@ struct CapContext
     bool          camera_ready = false, prev_camera_ready = false;
     ScreenDev     screen{};
     uint64_t      max_batch_paths = 0;
+    SwitchTable   sw{};                    // A/B switches: environment at creation, then cap_debug_set(CAP_DEBUG_SWITCH_BASE + i)
     uint32_t      debug_capacity_div = 1;  // cap_debug_set(CAP_DEBUG_QUEUE_CAPACITY_DIV): tests of the append guard only
     uint32_t      debug_wide_depth_limit = 0;  // cap_debug_set(CAP_DEBUG_WIDE_DEPTH_LIMIT): pretend the wide kernels' stacks end here
     bool          debug_fail_lane1 = false;    // cap_debug_set(CAP_DEBUG_FAIL_LANE1): the second working set "cannot be allocated"
@@ -408,7 +409,7 @@ BvhDev bvh_dev(const CapContext* c)
     b.stack_spill   = c->stack_spill.p;
     b.spill_threads = (uint32_t)(c->stack_spill.n / kSpillEntries);
     // A/B switch: the binary-tree kernels (also what runs if the 8-wide view's depth ever exceeds the pair stacks)
-    static const bool no_wide8 = getenv("CAP_NO_WIDE8") != nullptr || getenv("CAP_BVH_BINARY") != nullptr;
+    const bool no_wide8 = c->sw.on(SW_NO_WIDE8);
     b.nodes8 = c->nodes8.p, b.tris8 = c->tris8.p;
     b.wide8_ok  = !no_wide8 && c->stack_spill.p && c->wide8_nodes != 0 && c->wide8_depth <= wide8_stack_pairs() + 1u &&
                  c->wide8_depth <= kWideLdsEntries / 2u + kSpillEntries / 2u + 1u &&
@@ -504,8 +505,8 @@ int ensure_lane1(CapContext* c, uint32_t slots, uint32_t bounces)
     if (!c->stream2)
     {
         // (A/B switch: the second lane's stream priority -- streams of different priority never share a hardware queue)
-        if (const char* e = getenv("CAP_LANE1_PRIORITY"))
-            HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, atoi(e)));
+        if (c->sw.v[SW_LANE1_PRIORITY] >= 0)
+            HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, (int)c->sw.v[SW_LANE1_PRIORITY]));
         else
             HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     }
@@ -538,6 +539,35 @@ int cap_device_count(void)
     return n;
 }
 
+// The switches' names: environment variables read ONCE, at cap_ctx_create (tools and profiling scripts set them around a whole process),
+// and the strings cap_debug_switch_index() resolves for cap_debug_set.  A presence flag counts as set unless its value is "0".
+static const char* const kSwitchNames[SW_COUNT] = {
+    "CAP_NO_WIDE8", "CAP_LANE1_PRIORITY", "CAP_PLOC_RADIUS", "CAP_SAHDEV_LEAF", "CAP_WIDE_HOST_COLLAPSE", "CAP_TRACE_LAUNCHES", "CAP_NO_TWO_LANES",
+    "CAP_LANE_SPLIT_MIN", "CAP_BLOCKS_PER_CU", "CAP_NO_CAMERA_CULL", "CAP_NO_ALBEDO_IN_W", "CAP_NO_INLINE_NEE", "CAP_NO_INLINE_PROBE", "CAP_NO_WAVE_RING",
+    "CAP_ANY_REFILL", "CAP_PRIMARY_WIDE", "CAP_NO_PACKET", "CAP_NO_ANY_PROBE", "CAP_ANY_PROBE", "CAP_ANY_BLOCKS", "CAP_NO_PRIMARY_FUSE", "CAP_W8_REFILL",
+    "CAP_W8_GRID", "CAP_AUTO_SAH_TRIANGLES"};
+
+static void switches_from_environment(SwitchTable& t)
+{
+    for (uint32_t k = 0; k < SW_COUNT; ++k)
+    {
+        const char* e = getenv(kSwitchNames[k]);
+        t.v[k]        = -1;
+        if (!e) continue;
+        char*           end = nullptr;
+        const long long v   = strtoll(e, &end, 10);
+        t.v[k]              = (end != e && v >= 0) ? v : 1;  // "CAP_NO_X=" / "=yes": a set flag
+    }
+    if (getenv("CAP_BVH_BINARY") && t.v[SW_NO_WIDE8] < 0) t.v[SW_NO_WIDE8] = 1;  // older name of the same switch
+}
+
+int cap_debug_switch_index(const char* name)
+{
+    for (uint32_t k = 0; name && k < SW_COUNT; ++k)
+        if (strcmp(name, kSwitchNames[k]) == 0) return (int)k;
+    return -1;
+}
+
 int cap_ctx_create(int device_id, void* hip_stream, CapContext** out_ctx)
 {
     if (!out_ctx) return fail(CAP_ERR_INVALID_ARG, "cap_ctx_create: out_ctx is NULL");
@@ -548,6 +578,7 @@ int cap_ctx_create(int device_id, void* hip_stream, CapContext** out_ctx)
     HIP_TRY(hipSetDevice(device_id));
     CapContext* c = new CapContext;
     c->device     = device_id;
+    switches_from_environment(c->sw);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->cu_count = prop.multiProcessorCount;
     if (hip_stream)
@@ -798,7 +829,7 @@ int cap_bvh_build(CapContext* c)
     // ... and from kAutoSahTriangles on the surface-area splits on top of it (round 6): host-SAH quality (expected node visits 44.6 against
     // 44.4 and the clustering's 47.6 on the 262 k hall) for 10 ms at 262 k and 0.2 s at 16.8 M triangles, built once like the reference's
     // PREFER_FAST_TRACE structures (blas_system.cpp:44); below, a build is a few dozen launches whatever it holds and the trees do not differ.
-    const bool sahdev = n >= 2 && (c->bvh_build_mode == CAP_BVH_BUILD_SAH_DEVICE || (c->bvh_build_mode == CAP_BVH_BUILD_AUTO && n >= kAutoSahTriangles));
+    const bool sahdev = n >= 2 && (c->bvh_build_mode == CAP_BVH_BUILD_SAH_DEVICE || (c->bvh_build_mode == CAP_BVH_BUILD_AUTO && n >= (uint32_t)c->sw.get(SW_AUTO_SAH_TRIANGLES, kAutoSahTriangles)));
     const bool ploc = n >= 2 && !sahdev && (c->bvh_build_mode == CAP_BVH_BUILD_PLOC || (c->bvh_build_mode == CAP_BVH_BUILD_AUTO && n > kExhaustiveMax));
     const auto wall0 = std::chrono::steady_clock::now();
     uint32_t   host_depth = 0;
@@ -825,8 +856,7 @@ int cap_bvh_build(CapContext* c)
         HIP_TRY(c->ploc_boxes.ensure(4 * (size_t)n));
         HIP_TRY(c->ploc_ints.ensure(3 * (size_t)n + 4));
         HIP_TRY(c->sahdev_words.ensure(bvh_sah_device_scratch_words(n)));
-        static const int radius = getenv("CAP_PLOC_RADIUS") ? atoi(getenv("CAP_PLOC_RADIUS")) : 16;  // A/B switches
-        static const int leaf   = getenv("CAP_SAHDEV_LEAF") ? atoi(getenv("CAP_SAHDEV_LEAF")) : 32;
+        const int radius = (int)c->sw.get(SW_PLOC_RADIUS, 16), leaf = (int)c->sw.get(SW_SAHDEV_LEAF, 32);  // A/B switches
         const int rc = launch_bvh_build_sah_device(c->stream, a, PlocScratch{c->ploc_boxes.p, c->ploc_ints.p}, c->sahdev_words.p, (uint32_t)radius,
                                                    (uint32_t)(leaf < 1 ? 1 : leaf));
         if (rc != 0) return fail(CAP_ERR_HIP, "cap_bvh_build: device surface-area build failed (%d)", rc);
@@ -837,7 +867,7 @@ int cap_bvh_build(CapContext* c)
     {
         HIP_TRY(c->ploc_boxes.ensure(4 * (size_t)n));
         HIP_TRY(c->ploc_ints.ensure(3 * (size_t)n + 4));
-        static const int radius = getenv("CAP_PLOC_RADIUS") ? atoi(getenv("CAP_PLOC_RADIUS")) : 16;  // A/B switch
+        const int radius = (int)c->sw.get(SW_PLOC_RADIUS, 16);  // A/B switch
         const int rc = launch_bvh_build_ploc(c->stream, a, PlocScratch{c->ploc_boxes.p, c->ploc_ints.p}, (uint32_t)radius);
         if (rc != 0) return fail(CAP_ERR_HIP, "cap_bvh_build: clustering build failed (%d)", rc);
     }
@@ -877,7 +907,7 @@ int cap_bvh_build(CapContext* c)
         HIP_TRY(c->wide_src.ensure(n));
         size_t   wn = 0;
         uint32_t wdepth = 0, wtop = 0;
-        static const bool host_collapse = getenv("CAP_WIDE_HOST_COLLAPSE") != nullptr;  // A/B switch
+        const bool host_collapse = c->sw.on(SW_WIDE_HOST_COLLAPSE);  // A/B switch
         if (!sah && n >= 2 && !host_collapse)
         {
             // the device built the binary tree: collapse it there too (bvh.hip k_wide_level), nothing leaves the GPU
@@ -918,7 +948,7 @@ int cap_bvh_build(CapContext* c)
         c->wide8_nodes = (uint32_t)wn, c->wide8_depth = wdepth, c->wide8_top = wtop;
         c->wide8_ms    = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
         bi.build_ms += c->wide8_ms;  // the collapse is part of the build
-        if (getenv("CAP_TRACE_LAUNCHES"))
+        if (c->sw.on(SW_TRACE_LAUNCHES))
             fprintf(stderr, "[cap] wide view: %zu nodes, depth %u, top %u, %.1f ms\n", wn, wdepth, wtop, c->wide8_ms);
     }
     // Exhaustive path (cap_set_traversal): triangles that come in fans (k, k + 1 share v0 and the edge v0->v2, as every
@@ -1108,7 +1138,15 @@ int cap_debug_set(CapContext* c, uint32_t key, uint64_t value)
         c->debug_fail_lane1 = value != 0;
         if (!value) c->lane1_failed_paths = 0;  // "memory has been released"
         return CAP_OK;
-    default: return fail(CAP_ERR_INVALID_ARG, "cap_debug_set: unknown key %u", key);
+    default:
+        if (key >= CAP_DEBUG_SWITCH_BASE && key < CAP_DEBUG_SWITCH_BASE + SW_COUNT)
+        {
+            // ~0 = back to the product's choice.  Read at the next build / render: a switch that selects buffers (second lane, rings)
+            // takes effect with the next call that sizes them.
+            c->sw.v[key - CAP_DEBUG_SWITCH_BASE] = value == ~0ull ? -1 : (int64_t)value;
+            return CAP_OK;
+        }
+        return fail(CAP_ERR_INVALID_ARG, "cap_debug_set: unknown key %u", key);
     }
 }
 
@@ -1141,7 +1179,13 @@ int cap_debug_get(CapContext* c, uint32_t key, uint64_t* value)
         if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_debug_get: BVH not built");
         *value = bvh_dev(c).wide8_ok;
         return CAP_OK;
-    default: return fail(CAP_ERR_INVALID_ARG, "cap_debug_get: unknown key %u", key);
+    default:
+        if (key >= CAP_DEBUG_SWITCH_BASE && key < CAP_DEBUG_SWITCH_BASE + SW_COUNT)
+        {
+            *value = (uint64_t)c->sw.v[key - CAP_DEBUG_SWITCH_BASE];
+            return CAP_OK;
+        }
+        return fail(CAP_ERR_INVALID_ARG, "cap_debug_get: unknown key %u", key);
     }
 }
 
@@ -1239,7 +1283,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     // next launch instead of waiting for the stream's next kernel (measured with two contexts side by side, tools/dual_test.py:
     // 21.0 -> 20.55 ms per step on the headline, 3.30 -> 3.05 ms for shard 0 of 8, 28.3 -> 27.1 ms on the 262 k scene).  A call
     // that fits one batch is cut in two halves when the halves are still large.  Per-stage timers need one stream.
-    static const bool no_two_lanes = getenv("CAP_NO_TWO_LANES") != nullptr;  // A/B switch
+    const bool no_two_lanes = c->sw.on(SW_NO_TWO_LANES);  // A/B switch
     // Only on the tree path: its bounces are three launches each, and from the third bounce on they are short (the 262 k scene: 27
     // launches per batch, the last 15 under 0.2 ms each) -- 28.3 -> 26.4 ms per 32 spp.  The small-scene path's nine long fused
     // launches gain nothing measurable (20.45 -> 20.25 ms with the context's own stream, 20.56 -> 20.9 beside a torch stream).
@@ -1249,7 +1293,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                      !(flags & CAP_RENDER_LOWRES_INDIRECT) && n_frames >= 2;
     if (two_lanes && slots >= n_frames)
     {
-        static const uint64_t split_min = getenv("CAP_LANE_SPLIT_MIN") ? (uint64_t)atoll(getenv("CAP_LANE_SPLIT_MIN")) : ((uint64_t)4 << 20);  // A/B switch (shard 0 of 8 of the 262 k scene: 4.55 -> 4.35 ms with halves of 4 Mi paths)
+        const uint64_t split_min = (uint64_t)c->sw.get(SW_LANE_SPLIT_MIN, (int64_t)4 << 20);  // A/B switch (shard 0 of 8 of the 262 k scene: 4.55 -> 4.35 ms with halves of 4 Mi paths)
         if ((uint64_t)n_frames * Ppad >= split_min)
             slots = (n_frames + 1) / 2;
         else
@@ -1268,7 +1312,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     }
     // (per-stage timers and launch tracing need one stream: the batches keep the size the two lanes gave them -- so that a stage-timed
     // render launches what the plain one does -- and run one after the other on lane 0)
-    if ((flags & CAP_RENDER_STAGE_TIMERS) || getenv("CAP_TRACE_LAUNCHES")) two_lanes = false;
+    if ((flags & CAP_RENDER_STAGE_TIMERS) || c->sw.on(SW_TRACE_LAUNCHES)) two_lanes = false;
     if (ensure_wavefront(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
     if (two_lanes && c->lane1_failed_paths && (uint64_t)slots * Ppad >= c->lane1_failed_paths)
     {
@@ -1335,8 +1379,9 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     // waves retire and doubles the kernel's tail.  blocks_per_cu is therefore the residency the kernels are built for
     // (launch bounds in kernels.hip), not the 8 a register-light kernel could reach.
     uint32_t blocks_per_cu = stack_entries == 0 ? 6u : (stack_entries <= 32 ? 5u : 2u);  // measured: 4..8 within 4 %, 6 best
-    if (const char* e = getenv("CAP_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)std::max(1, atoi(e));
+    if (c->sw.v[SW_BLOCKS_PER_CU] >= 0) blocks_per_cu = (uint32_t)std::max<int64_t>(1, c->sw.v[SW_BLOCKS_PER_CU]);
     LaunchCfg cfg{c->stream, (uint32_t)c->cu_count * blocks_per_cu, stack_entries, (uint32_t)c->cu_count};
+    cfg.sw = &c->sw;
     BvhDev          bvh   = bvh_dev(c);
     const SceneDev  scene = scene_dev(c);
     const CameraDev cam   = camera_dev(c->camera);
@@ -1414,7 +1459,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         sa.n_slots = ns, sa.num_bounces = D, sa.max_count = max_count, sa.aov_slot = aov_slot, sa.shaded_counter = c->shaded_counter.p;
         {
             // screen-space culling of bounce 0 inverts primary_dir (camera.h:39-63), which needs an orthonormal basis
-            static const bool no_cull = getenv("CAP_NO_CAMERA_CULL") != nullptr;  // A/B switch
+            const bool no_cull = c->sw.on(SW_NO_CAMERA_CULL);  // A/B switch
             auto dotf = [](const float* x, const float* y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
             const CapCameraData& cd = c->camera;
             const bool ortho = std::fabs(dotf(cd.right, cd.up)) < 1e-4f && std::fabs(dotf(cd.right, cd.forward)) < 1e-4f &&
@@ -1423,24 +1468,24 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             sa.cull_camera_pairs = (ortho && !no_cull) ? 1u : 0u;
         }
         // Nobody reads this batch's planes but the resolve (plane read-backs and the reconstruction chain need CAP_RENDER_AOV)
-        static const bool no_albedo_w = getenv("CAP_NO_ALBEDO_IN_W") != nullptr;  // A/B switch
+        const bool no_albedo_w = c->sw.on(SW_NO_ALBEDO_IN_W);  // A/B switch
         sa.albedo_in_w = (!no_albedo_w && !feedback && !lowres && !(flags & CAP_RENDER_AOV) && (ext || scene.texture_count == 0)) ? 1u : 0u;  // (the EXT model's first-vertex albedo is 1: it folds kd into the throughput)
         if (feedback)  // g_color_history = combined_history[(frame_count + 1) % 2], raytracing_system.cpp:1754-1759
             sa.fb = FeedbackDev{camera_dev(c->prev_camera), c->post_prev_nd.p, c->post_chist[(frame_begin + 1) % 2].p};
         const bool fused = cfg.stack_entries == 0;  // small-scene path: closest hit and shading in one kernel per bounce
-        static const bool no_inline_nee = getenv("CAP_NO_INLINE_NEE") != nullptr;  // A/B switch
+        const bool no_inline_nee = c->sw.on(SW_NO_INLINE_NEE);  // A/B switch
         sa.inline_nee = (ext && fused && !no_inline_nee) ? 1u : 0u;
-        static const bool no_inline_probe = getenv("CAP_NO_INLINE_PROBE") != nullptr;  // A/B switch
+        const bool no_inline_probe = c->sw.on(SW_NO_INLINE_PROBE);  // A/B switch
         sa.inline_probe = (!ext && !feedback && fused && !no_inline_probe && c->tri_count <= kExhaustiveMax && bvh.fan_pair_count >= 1 &&
                            bvh.fan_pair_count <= kExhaustiveMax / 2)
                               ? 1u
                               : 0u;
-        static const bool no_wave_ring = getenv("CAP_NO_WAVE_RING") != nullptr;  // A/B switch
+        const bool no_wave_ring = c->sw.on(SW_NO_WAVE_RING);  // A/B switch
         sa.wave_ring = (sa.inline_probe && !no_wave_ring && (size_t)cfg.grid_blocks * (kBlock / 64) * 128 <= L.ring_n) ? 1u : 0u;  // (a grid beyond what ensure_wavefront sized the rings for: CAP_BLOCKS_PER_CU)
         LaunchCfg cfg_any    = cfg;
         cfg_any.any_no_probe = sa.inline_probe;
         // CAP_TRACE_LAUNCHES=1: name every launch on stderr and drain the stream after it (fault localisation only)
-        static const bool trace_launches = getenv("CAP_TRACE_LAUNCHES") != nullptr;
+        const bool trace_launches = c->sw.on(SW_TRACE_LAUNCHES);
         auto              traced         = [&](const char* what, uint32_t b) -> int {
             if (!trace_launches) return CAP_OK;
             fprintf(stderr, "[cap] %s bounce %u batch %u ... ", what, b, done / slots);
@@ -1465,14 +1510,14 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
         bool any_refill = false;
         if (!fused && !ext && bvh.wide8_ok && c->tri_count > kExhaustiveMax)
         {
-            static const int force = getenv("CAP_ANY_REFILL") ? atoi(getenv("CAP_ANY_REFILL")) : -1;
+            const int force = (int)c->sw.v[SW_ANY_REFILL];
             const uint64_t tree_bytes = (uint64_t)c->wide8_nodes * kWideNodeStride * 4u + (uint64_t)c->tri_count * 64u;
             any_refill = force >= 0 ? force != 0 : tree_bytes >= kAnyRefillTreeBytes;
         }
         bool primary_wide = false;
         if (!fused && bvh.wide8_ok && c->tri_count > kExhaustiveMax)
         {
-            static const int force = getenv("CAP_PRIMARY_WIDE") ? atoi(getenv("CAP_PRIMARY_WIDE")) : -1;  // A/B switch: 0 never, 1 whenever allowed
+            const int force = (int)c->sw.v[SW_PRIMARY_WIDE];  // A/B switch: 0 never, 1 whenever allowed
             bool inside = true;
             for (int k = 0; k < 3; ++k)
                 inside = inside && c->camera.position[k] >= c->bvh_info.bounds_lo[k] && c->camera.position[k] <= c->bvh_info.bounds_hi[k];

@@ -1143,7 +1143,7 @@ static uint32_t resident_grid(const LaunchCfg& cfg, uint32_t want)
     {
         int n = 0;
         per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, K, (int)kBlock, 0) == hipSuccess && n > 0) ? n : 0;
-        if (getenv("CAP_TRACE_LAUNCHES")) fprintf(stderr, "[cap] resident workgroups per CU: %d\n", per_cu);
+        if (cfg.sw_on(SW_TRACE_LAUNCHES)) fprintf(stderr, "[cap] resident workgroups per CU: %d\n", per_cu);
     }
     if (!cfg.cu_count || !per_cu) return want;
     const uint32_t cap = cfg.cu_count * (uint32_t)per_cu;
@@ -1154,7 +1154,7 @@ void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraD
                           const FrameConst* frames, uint32_t n_slots, float4* hits, uint32_t* work)
 {
     const uint32_t chunks = screen.pixels_padded >> 6;
-    static const bool no_packet = getenv("CAP_NO_PACKET") != nullptr;  // A/B switch
+    const bool no_packet = cfg.sw_on(SW_NO_PACKET);  // A/B switch
     if (cfg.stack_entries != 0 && work && bvh.tri_count >= 2 && !no_packet)
     {
         // latency-bound on the dependent scalar node fetches and light on registers: as many waves as fit
@@ -1212,12 +1212,12 @@ void launch_trace_any(const LaunchCfg& cfg, const BvhDev& bvh, const ShadowQueue
     // shadow rays share one direction per frame and retire early: the plain per-chunk kernel beats the refill variant here
     // (8.3 vs 10.5 ms on the 262 k-triangle scene when it was tried)
     const uint32_t pre = (cfg.stack_entries == 0 && !mostly_unoccluded) ? pre_table_bytes(n_slots, bvh.fan_pair_count) : 0u;
-    static const bool     no_probe = getenv("CAP_NO_ANY_PROBE") != nullptr;  // A/B switch
-    static const uint32_t probe    = getenv("CAP_ANY_PROBE") ? (uint32_t)atoi(getenv("CAP_ANY_PROBE")) : (uint32_t)CAP_ANY_PROBE;
+    const bool     no_probe = cfg.sw_on(SW_NO_ANY_PROBE);  // A/B switch
+    const uint32_t probe    = (uint32_t)cfg.sw_get(SW_ANY_PROBE, CAP_ANY_PROBE);
     if (pre != 0u && work && !no_probe && !cfg.any_no_probe && bvh.fan_pair_count <= kExhaustiveMax / 2)
     {
         // (3 .. 8 workgroups per CU measure the same: what is left is the planes' scattered read-modify-write traffic)
-        static const uint32_t per_cu = getenv("CAP_ANY_BLOCKS") ? (uint32_t)atoi(getenv("CAP_ANY_BLOCKS")) : 6u;
+        const uint32_t per_cu = (uint32_t)cfg.sw_get(SW_ANY_BLOCKS, 6);
         uint32_t g = (max_count + kBlock - 1) / kBlock;
         const uint32_t cap = cfg.cu_count ? cfg.cu_count * per_cu : cfg.grid_blocks;
         g = g > cap ? cap : (g ? g : 1u);
@@ -2122,7 +2122,7 @@ __global__ __launch_bounds__(kBlock, CAP_PS_BLOCKS) void k_primary_shade(BvhDev 
 
 bool launch_primary_shade(const LaunchCfg& cfg, const BvhDev& bvh, const ShadeArgs& args, float4* hits, bool ext)
 {
-    static const bool off = getenv("CAP_NO_PRIMARY_FUSE") != nullptr || getenv("CAP_NO_PACKET") != nullptr;  // A/B switches
+    const bool off = cfg.sw_on(SW_NO_PRIMARY_FUSE) || cfg.sw_on(SW_NO_PACKET);  // A/B switches
     if (off || cfg.stack_entries == 0 || !args.work || bvh.tri_count < 2 || !cfg.cu_count) return false;
     const uint32_t chunks = (args.screen.pixels_padded >> 6) * args.n_slots;
     uint32_t       gx     = (chunks + 3) / 4;

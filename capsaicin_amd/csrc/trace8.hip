@@ -369,10 +369,9 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_any8_refill(Bvh
 
 // Idle lanes at which a wave refills (A/B switch CAP_W8_REFILL), clamped to 1..64: above 64 the refill condition is never true, no
 // lane ever gets a ray and the persistent loop would spin for ever.
-static uint32_t w8_refill_idle()
+static uint32_t w8_refill_idle(const LaunchCfg& cfg)
 {
-    const char* e = getenv("CAP_W8_REFILL");
-    const long  v = e ? atol(e) : (long)CAP_W8_REFILL;
+    const long v = (long)cfg.sw_get(SW_W8_REFILL, CAP_W8_REFILL);
     return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v);
 }
 
@@ -384,7 +383,7 @@ void launch_trace_any8_refill(const LaunchCfg& cfg, const BvhDev& bvh, const Sha
     if ((uint64_t)cap * kBlock > bvh.spill_threads) cap = bvh.spill_threads / kBlock;  // every thread owns a spill slice
     if (g > cap) g = cap;
     if (g == 0) g = 1;
-    static const uint32_t refill = w8_refill_idle();
+    const uint32_t refill = w8_refill_idle(cfg);
     hipLaunchKernelGGL(k_trace_any8_refill, dim3(g), dim3(kBlock), 0, cfg.stream, bvh, q, target, pixels_padded, n_slots, guard, work, frames, refill);
 }
 
@@ -417,7 +416,7 @@ uint32_t wide8_stack_pairs() { return kW8StackPairs; }
 void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work)
 {
     uint32_t g = (max_count + kBlock - 1) / kBlock;
-    static const uint32_t per_cu = getenv("CAP_W8_GRID") ? (uint32_t)atoi(getenv("CAP_W8_GRID")) : (uint32_t)CAP_W8_BLOCKS;  // A/B switch
+    const uint32_t per_cu = (uint32_t)cfg.sw_get(SW_W8_GRID, CAP_W8_BLOCKS);  // A/B switch
     uint32_t cap = cfg.cu_count ? cfg.cu_count * per_cu : cfg.grid_blocks;
     if ((uint64_t)cap * kBlock > bvh.spill_threads) cap = bvh.spill_threads / kBlock;  // every thread owns a spill slice
     if (g > cap) g = cap;
@@ -427,7 +426,7 @@ void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQue
         hipLaunchKernelGGL(k_trace_closest8_empty, dim3(g), dim3(kBlock), 0, cfg.stream, q, hits);
         return;
     }
-    static const uint32_t refill = w8_refill_idle();
+    const uint32_t refill = w8_refill_idle(cfg);
     hipLaunchKernelGGL(k_trace_closest8, dim3(g), dim3(kBlock), 0, cfg.stream, bvh, q, hits, work, refill);
 }
 }  // namespace cap

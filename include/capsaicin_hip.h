@@ -247,10 +247,19 @@ enum
      * the compiler's IEEE expansion where the operands are in a range that never triggers them (post.hip div_unscaled); this runs both
      * forms on the device -- every normal float through log2, 2^30 operand pairs over the whole range -- and returns the number of
      * results that differ in any bit: 0. */
-    CAP_DEBUG_SELFTEST_DIV        = 9
+    CAP_DEBUG_SELFTEST_DIV        = 9,
+    /* A/B and diagnostic switches of the build and render paths (which kernels trace the camera and the shadow rays, one or two batch
+     * lanes, the builders' parameters ...): ONE table per context, key = SWITCH_BASE + cap_debug_switch_index("CAP_..."), the names being
+     * the environment variables that fill the table once, at cap_ctx_create (tools set those around a whole process; nothing else in the
+     * library reads the environment except CAP_RCCL_LIBRARY).  value: the switch's number (flags: 1 / 0), ~0 = the product's own
+     * choice again.  A switch is read by the next cap_bvh_build / cap_render.  Every switch selects between paths that give the same
+     * image: they exist for measurements and for tests that exercise a path the product would not take on a small scene. */
+    CAP_DEBUG_SWITCH_BASE         = 64
 };
 int cap_debug_set(CapContext* ctx, uint32_t key, uint64_t value);
 int cap_debug_get(CapContext* ctx, uint32_t key, uint64_t* value);
+/* Index of a switch by its name ("CAP_NO_WIDE8", "CAP_PRIMARY_WIDE", ...; capsaicin_amd/csrc/cap_kernels.h CapSwitch), -1 if unknown. */
+int cap_debug_switch_index(const char* name);
 /* Traversal strategy of the trace kernels (same hits either way): AUTO picks EXHAUSTIVE for scenes of at most 64
  * triangles (wave-uniform test of every triangle, no stack) and STACK (LBVH + per-lane LDS stack) otherwise. */
 typedef enum CapTraversal

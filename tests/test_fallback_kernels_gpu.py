@@ -212,3 +212,46 @@ def test_dense_scene_kernels_forced_on_small_scenes(native_lib, bluenoise, tmp_p
             for i, pl in enumerate(planes):
                 assert np.array_equal(bits(pl), bits(child["%s_p%d" % (key, i)])), (key, i)
             r.close()
+
+
+def test_switch_table_flips_paths_in_one_process(native_lib, bluenoise):
+    """The A/B switches are one table per context (cap_debug_set(CAP_DEBUG_SWITCH_BASE + index); the environment only fills it at
+    cap_ctx_create): the paths the child-process tests above force through the environment, flipped here on ONE context between renders
+    -- binary-tree kernels instead of the 8-wide view, camera rays through k_trace_closest8, the lane-refill any-hit kernel, one batch
+    lane, the other builders' parameters -- every combination bit-identical, counters included."""
+    r, info = make("hall", bluenoise, 160, 96, capi.Renderer.BVH_BUILD_AUTO)
+    want = render_all(r, 2, 3, 4)
+    assert r.debug_get(capi.Renderer.DEBUG_WIDE_IN_USE) == 1
+    with pytest.raises(capi.CapError):
+        r.debug_switch("CAP_NO_SUCH_SWITCH", 1)
+
+    def same(what):
+        got = render_all(r, 2, 3, 4)
+        assert got[2] == want[2], what
+        assert np.array_equal(bits(got[1]), bits(want[1])), what
+        for a, b in zip(got[0], want[0]):
+            assert np.array_equal(bits(a), bits(b)), what
+
+    r.debug_switch("CAP_NO_WIDE8", 1)
+    assert r.debug_get(capi.Renderer.DEBUG_WIDE_IN_USE) == 0
+    same("binary-tree kernels")
+    r.debug_switch("CAP_NO_WIDE8", None)
+    assert r.debug_get(capi.Renderer.DEBUG_WIDE_IN_USE) == 1
+    r.debug_switch("CAP_PRIMARY_WIDE", 1)
+    r.debug_switch("CAP_ANY_REFILL", 1)
+    same("dense-scene kernels")
+    r.debug_switch("CAP_NO_TWO_LANES", 1)
+    same("dense-scene kernels, one lane")
+    assert r.debug_get(capi.Renderer.DEBUG_LANES_USED) == 1
+    r.debug_switch("CAP_PRIMARY_WIDE", 0)
+    r.debug_switch("CAP_ANY_REFILL", 0)
+    r.debug_switch("CAP_NO_PACKET", 1)
+    same("no packet walk")
+    for name in ("CAP_NO_TWO_LANES", "CAP_PRIMARY_WIDE", "CAP_ANY_REFILL", "CAP_NO_PACKET"):
+        r.debug_switch(name, None)
+    # the builders' switches: another leaf size and search window, the clustering alone -- other trees, the same image
+    for name, value in (("CAP_SAHDEV_LEAF", 64), ("CAP_PLOC_RADIUS", 8), ("CAP_AUTO_SAH_TRIANGLES", 1 << 30)):
+        r.debug_switch(name, value)
+        r.build_bvh()
+        same("%s = %d" % (name, value))
+    r.close()
