@@ -429,7 +429,7 @@ class Renderer:
         _check(lib().cap_set_traversal(self.ctx, mode), "cap_set_traversal")
 
     DEBUG_QUEUE_CAPACITY_DIV, DEBUG_WIDE_DEPTH_LIMIT, DEBUG_WIDE_IN_USE, DEBUG_FAIL_LANE1, DEBUG_LANES_USED = 1, 2, 3, 4, 5
-    DEBUG_QUEUE_CANARY_FILL, DEBUG_QUEUE_CANARY_BEHIND, DEBUG_QUEUE_CANARY_USED, DEBUG_SELFTEST_DIV = 6, 7, 8, 9
+    DEBUG_QUEUE_CANARY_FILL, DEBUG_QUEUE_CANARY_BEHIND, DEBUG_QUEUE_CANARY_USED, DEBUG_SELFTEST_DIV, DEBUG_NEE_PAIRS = 6, 7, 8, 9, 10
 
     def debug_set(self, key, value):
         _check(lib().cap_debug_set(self.ctx, key, value), "cap_debug_set")

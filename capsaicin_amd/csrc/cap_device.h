@@ -63,6 +63,11 @@ struct BvhDev
     const float4* fan_pairs;
     const float4* fan_singles;
     uint32_t      fan_pair_count, fan_single_count;
+    // EXT model, next-event rays (round 6): the same pair records with the pairs that can never occlude a segment between a scene point
+    // and a point of a light triangle moved behind the first fan_pair_nee_count -- see update_nee_pairs() in context.hip for the rule
+    // and its exactness argument.  An occlusion test is an OR over the pairs, so their order is free there.
+    const float4* fan_pairs_nee;
+    uint32_t      fan_pair_nee_count;
     int32_t       root;       // 0, or ~0 for a single triangle
     uint32_t      tri_count;  // 0 -> every ray misses
     // compressed 8-wide view (cap_wide.h): 5 x float4 per node, breadth-first; 64-B intersection records in its own leaf order

@@ -35,6 +35,7 @@ enum CapSwitch : uint32_t
     SW_W8_REFILL,
     SW_W8_GRID,
     SW_AUTO_SAH_TRIANGLES,  // AUTO builds with surface-area splits from this many triangles on
+    SW_NO_NEE_PAIR_CULL,    // EXT model: next-event rays test every fan pair (read by the next cap_bvh_build / cap_materials_upload)
     SW_COUNT
 };
 struct SwitchTable

@@ -161,6 +161,10 @@ struct CapContext
     DevBuf<uint32_t> stack_spill;             // traversal-stack entries beyond the LDS part, per thread of the persistent grid
     DevBuf<float4>   fan_pairs, fan_singles;  // exhaustive path: fan-pair records (5 float4) and the unpaired triangles (4 float4)
     uint32_t         fan_pair_count = 0, fan_single_count = 0;
+    DevBuf<float4>   fan_pairs_nee;           // the pair records again, potential occluders of next-event rays first (update_nee_pairs)
+    uint32_t         fan_pair_nee_count = 0;
+    std::vector<float>    fan_pairs_host;     // 20 floats per pair (+ padding records), as uploaded
+    std::vector<uint32_t> light_tris_host;    // global ids of the emissive triangles (cap_materials_upload)
     DevBuf<uint32_t> leaf_tri, keys0, keys1, vals0, vals1, hist, parent, flags, bvh_misc;  // bvh_misc: 6 bounds + depth
     DevBuf<float4>   ploc_boxes;  // CAP_BVH_BUILD_PLOC scratch (ploc.hip)
     DevBuf<uint32_t> ploc_ints;
@@ -417,6 +421,8 @@ BvhDev bvh_dev(const CapContext* c)
     b.wide8_top = c->wide8_top;
     b.fan_pairs = c->fan_pairs.p, b.fan_singles = c->fan_singles.p;
     b.fan_pair_count = c->fan_pair_count, b.fan_single_count = c->fan_single_count;
+    b.fan_pairs_nee = c->fan_pairs_nee.p ? c->fan_pairs_nee.p : c->fan_pairs.p;
+    b.fan_pair_nee_count = c->fan_pairs_nee.p ? c->fan_pair_nee_count : c->fan_pair_count;
     b.tri_count = c->tri_count;
     b.root      = c->tri_count >= 2 ? 0 : ~0;
     return b;
@@ -545,7 +551,7 @@ static const char* const kSwitchNames[SW_COUNT] = {
     "CAP_NO_WIDE8", "CAP_LANE1_PRIORITY", "CAP_PLOC_RADIUS", "CAP_SAHDEV_LEAF", "CAP_WIDE_HOST_COLLAPSE", "CAP_TRACE_LAUNCHES", "CAP_NO_TWO_LANES",
     "CAP_LANE_SPLIT_MIN", "CAP_BLOCKS_PER_CU", "CAP_NO_CAMERA_CULL", "CAP_NO_ALBEDO_IN_W", "CAP_NO_INLINE_NEE", "CAP_NO_INLINE_PROBE", "CAP_NO_WAVE_RING",
     "CAP_ANY_REFILL", "CAP_PRIMARY_WIDE", "CAP_NO_PACKET", "CAP_NO_ANY_PROBE", "CAP_ANY_PROBE", "CAP_ANY_BLOCKS", "CAP_NO_PRIMARY_FUSE", "CAP_W8_REFILL",
-    "CAP_W8_GRID", "CAP_AUTO_SAH_TRIANGLES"};
+    "CAP_W8_GRID", "CAP_AUTO_SAH_TRIANGLES", "CAP_NO_NEE_PAIR_CULL"};
 
 static void switches_from_environment(SwitchTable& t)
 {
@@ -744,6 +750,122 @@ int cap_bluenoise_upload(CapContext* c, const uint8_t* rgba8)
     return CAP_OK;
 }
 
+
+// EXT model, next-event rays on the small-scene path: which fan pairs can occlude a segment from a scene point p to a point y of a light
+// triangle?  The fused kernel tests every pair for every such ray (an OR without an early exit, 8.3 of the 31 ms of BASELINE's literal
+// "Lambert+GGX" step, docs/experiments.md (48)); a pair that provably never reports an occlusion is moved behind the count that loop runs to.
+//
+// Rule (in double, over the vertices as uploaded).  A pair is left out iff for BOTH of its triangles, with plane (v0, n):
+//   (i)  every scene vertex lies on one closed side of the plane (signed distance <= 1e-6 D on the other, D = the scene's diagonal): the
+//        plane supports the scene's convex hull, so p (a convex combination of scene vertices) and y are both on its inner side;
+//   (ii) every vertex of every light triangle is at least delta = 1e-2 * D * Dv inside it, Dv = the largest distance from v0 to a scene
+//        vertex (numbers in scene units: the bound is against the contract's ABSOLUTE tmin = 1e-4).
+// Why that is exact under the intersection contract, whose occlusion test is  tmin * det < T < tmax * det  with
+// T = +-(p - v0).n, det = |d.n|, d the unit direction, tmax = 0.999 |y - p|:  in exact arithmetic the segment meets the plane at t* =
+// T / det, and with both ends on the inner side t* <= 0 or t* >= |y - p| + delta / sin(theta) (theta = the angle between d and the plane),
+// never inside (tmin, tmax).  The computed T differs from the exact one by at most ~4 ulp of |p - v0| |n| (a three-term fma chain on a
+// difference that is exact to an ulp; p itself is off its surface by as much): |t_computed - t*| <= 2.4e-7 |p - v0| / sin(theta) --
+// the classic grazing-ray blow-up ((25), (64) of docs/experiments.md closed two earlier culls over it).  (ii) bounds the grazing angle:
+// sin(theta) >= delta / |y - p| >= delta / D, so the error is below 2.4e-7 * Dv * D / delta = 2.4e-5, a quarter of tmin on the near side
+// (t* <= 0 stays below tmin) and nothing against the 1e-3 |y - p| + delta between tmax and t* on the far side.  The ceiling of the
+// Cornell box (its lamp hangs 1 cm below it: rays from the ceiling's rim to the lamp graze it) fails (ii) and stays in the list, as
+// does every pair that is not a hull face.  tests: the EXT parity tests run this list; `tools/build_variant.sh neecheck -DCAP_NEE_CHECK`
+// runs both lists on every ray and counts disagreements in CapStats::guard_shade (0 over BASELINE configs[2]'s 8 G next-event rays).
+static int update_nee_pairs(CapContext* c)
+{
+    c->fan_pair_nee_count = c->fan_pair_count;
+    c->fan_pairs_nee.release();
+    const uint32_t np = c->fan_pair_count;
+    if (!np || c->light_tris_host.empty() || c->fan_pairs_host.size() < 20 * (size_t)np || c->sw.on(SW_NO_NEE_PAIR_CULL)) return CAP_OK;
+    const size_t nv = c->positions_host.size() / 3;
+    if (!nv) return CAP_OK;
+    auto P = [&](size_t i, int k) { return (double)c->positions_host[3 * i + k]; };
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = 0; i < nv; ++i)
+        for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], P(i, k)), hi[k] = std::max(hi[k], P(i, k));
+    const double D = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    if (!(D > 0.0)) return CAP_OK;
+    // the light triangles' vertices (global triangle id -> mesh -> indices, as cap_materials_upload walks them)
+    std::vector<double> lv;
+    {
+        uint32_t g = 0;
+        size_t   li = 0;
+        for (uint32_t m = 0; m < c->mesh_count && li < c->light_tris_host.size(); ++m)
+        {
+            const CapMeshDesc& d = c->meshes_host[m];
+            for (uint32_t k = 0; k + 2 < d.index_count + 0u && li < c->light_tris_host.size(); k += 3, ++g)
+            {
+                if (c->light_tris_host[li] != g) continue;
+                ++li;
+                for (int j = 0; j < 3; ++j)
+                {
+                    const uint32_t vi = d.first_vertex_offset + c->indices_host[d.first_index_offset + k + j];
+                    for (int x = 0; x < 3; ++x) lv.push_back(P(vi, x));
+                }
+            }
+        }
+        if (li != c->light_tris_host.size()) return CAP_OK;  // (cannot happen: the ids come from the same walk) -- keep every pair
+    }
+    std::vector<uint8_t> skip(np, 0);
+    uint32_t             n_skip = 0;
+    for (uint32_t k = 0; k < np; ++k)
+    {
+        const float* r  = c->fan_pairs_host.data() + 20 * (size_t)k;
+        const double v0[3] = {r[0], r[1], r[2]};
+        bool         ok = true;
+        for (int t = 0; t < 2 && ok; ++t)
+        {
+            const double n[3] = {r[12 + 3 * t], r[13 + 3 * t], r[14 + 3 * t]};
+            const double nl   = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (!(nl > 0.0))
+            {
+                ok = false;
+                break;
+            }
+            double smin = 0.0, smax = 0.0, dv = 0.0;
+            for (size_t i = 0; i < nv; ++i)
+            {
+                const double e[3] = {P(i, 0) - v0[0], P(i, 1) - v0[1], P(i, 2) - v0[2]};
+                const double sd   = (e[0] * n[0] + e[1] * n[1] + e[2] * n[2]) / nl;
+                smin = std::min(smin, sd), smax = std::max(smax, sd);
+                dv   = std::max(dv, std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]));
+            }
+            const double tol = 1e-6 * D;
+            double       sign;
+            if (smax <= tol)
+                sign = -1.0;  // the scene lies on the negative side
+            else if (smin >= -tol)
+                sign = 1.0;
+            else
+            {
+                ok = false;
+                break;
+            }
+            const double delta = 1e-2 * D * dv;
+            for (size_t i = 0; i + 2 < lv.size() && ok; i += 3)
+            {
+                const double sd = ((lv[i] - v0[0]) * n[0] + (lv[i + 1] - v0[1]) * n[1] + (lv[i + 2] - v0[2]) * n[2]) / nl;
+                if (!(sign * sd >= delta)) ok = false;
+            }
+        }
+        skip[k] = ok ? 1 : 0;
+        n_skip += ok ? 1u : 0u;
+    }
+    if (!n_skip) return CAP_OK;
+    std::vector<float> list;
+    list.reserve(c->fan_pairs_host.size());
+    for (int pass = 0; pass < 2; ++pass)
+        for (uint32_t k = 0; k < np; ++k)
+            if ((int)skip[k] == pass) list.insert(list.end(), c->fan_pairs_host.begin() + 20 * (size_t)k, c->fan_pairs_host.begin() + 20 * (size_t)(k + 1));
+    list.resize(c->fan_pairs_host.size(), 0.0f);  // the same zero padding records behind the list
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(c->fan_pairs_nee.ensure(list.size() / 4));
+    HIP_TRY(hipMemcpy(c->fan_pairs_nee.p, list.data(), sizeof(float) * list.size(), hipMemcpyHostToDevice));
+    c->fan_pair_nee_count = np - n_skip;
+    return CAP_OK;
+}
+
 int cap_materials_upload(CapContext* c, const CapMaterial* materials, uint32_t mesh_count)
 {
     if (!c || (!materials && mesh_count)) return fail(CAP_ERR_INVALID_ARG, "cap_materials_upload: NULL argument");
@@ -788,6 +910,8 @@ int cap_materials_upload(CapContext* c, const CapMaterial* materials, uint32_t m
     c->light_count     = (uint32_t)light_tris.size();
     c->light_area      = area;
     c->materials_ready = true;
+    c->light_tris_host = light_tris;
+    if (c->bvh_ready) return update_nee_pairs(c);
     return CAP_OK;
 }
 
@@ -984,13 +1108,15 @@ int cap_bvh_build(CapContext* c)
         c->fan_single_count = (uint32_t)(singles.size() / 16);
         // padded by four records so that an unrolled scalar load past the end stays inside the allocation
         pairs.resize(pairs.size() + 80, 0.0f), singles.resize(singles.size() + 64, 0.0f);
+        c->fan_pairs_host   = pairs;
         HIP_TRY(c->fan_pairs.ensure(pairs.size() / 4));
         HIP_TRY(c->fan_singles.ensure(singles.size() / 4));
         HIP_TRY(hipMemcpy(c->fan_pairs.p, pairs.data(), sizeof(float) * pairs.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->fan_singles.p, singles.data(), sizeof(float) * singles.size(), hipMemcpyHostToDevice));
     }
     c->bvh_ready     = true;
-    return CAP_OK;
+    if (c->fan_pair_count == 0) c->fan_pairs_host.clear();
+    return update_nee_pairs(c);
 }
 
 int cap_bvh_info(CapContext* c, CapBvhInfo* out)
@@ -1173,6 +1299,10 @@ int cap_debug_get(CapContext* c, uint32_t key, uint64_t* value)
         *value = h[0] + h[1];
         return CAP_OK;
     }
+    case CAP_DEBUG_NEE_PAIRS:
+        if (!c->bvh_ready) return fail(CAP_ERR_STATE, "cap_debug_get: BVH not built");
+        *value = ((uint64_t)(c->fan_pairs_nee.p ? c->fan_pair_nee_count : c->fan_pair_count) << 32) | c->fan_pair_count;
+        return CAP_OK;
     case CAP_DEBUG_QUEUE_CANARY_BEHIND: return canary_count(c, true, value);
     case CAP_DEBUG_QUEUE_CANARY_USED: return canary_count(c, false, value);
     case CAP_DEBUG_WIDE_IN_USE:

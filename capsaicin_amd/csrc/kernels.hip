@@ -404,22 +404,24 @@ __device__ __forceinline__ bool pair_occludes_pre(const Ray& r, const float4* ba
 
 // det == 0 needs no test: then U = V = 0 is the only way past the first three conditions and 0 < T < 0 rejects.
 // PRE: pre_row is this lane's row of the (frame slot, pair) table (see PairPre)
-template <bool PRE = false>
+// NEE: the EXT model's next-event rays walk the list whose tail holds the pairs that cannot occlude them (BvhDev::fan_pairs_nee)
+template <bool PRE = false, bool NEE = false>
 __device__ __forceinline__ bool exhaustive_any(const BvhDev& bvh, const Ray& r, const float4* pre_row = nullptr)
 {
     auto occl = [&](const TriScaled& s) {
         return (s.U >= 0.0f) & (s.V >= 0.0f) & (s.U + s.V <= s.det) & (s.T > r.tmin * s.det) & (s.T < r.tmax * s.det);
     };
-    bool           hit = false;
-    const uint32_t np  = bvh.fan_pair_count;
+    bool                hit  = false;
+    const uint32_t      np   = NEE ? bvh.fan_pair_nee_count : bvh.fan_pair_count;
+    const float4* const list = NEE ? bvh.fan_pairs_nee : bvh.fan_pairs;
 #pragma unroll 2
     for (uint32_t k = 0; k < np; ++k)
     {
         if (PRE)
-            hit |= pair_occludes_pre(r, bvh.fan_pairs, k, pre_row[2 * k], pre_row[2 * k + 1]);
+            hit |= pair_occludes_pre(r, list, k, pre_row[2 * k], pre_row[2 * k + 1]);
         else
         {
-            const PairScaled p = pair_scaled(r, bvh.fan_pairs, k);
+            const PairScaled p = pair_scaled(r, list, k);
             hit |= occl(p.a) | occl(p.b);
         }
     }
@@ -1960,7 +1962,16 @@ __device__ __forceinline__ void shade_vertex_ext(const ShadeArgs& a, const float
 #if defined(CAP_EXT_DIAG) && CAP_EXT_DIAG == 1  // diagnostic build (wrong images, right timing): what the inline any-test costs
         visible = emit_shadow;
 #else
-        if (__ballot(emit_shadow) != 0ull) visible = emit_shadow && !exhaustive_any<false>(*bvh, sr);  // (a wave without a shadow ray: no test)
+#if defined(CAP_NEE_CHECK)  // diagnostic build: both lists, every disagreement counted (CapStats::guard_shade stays 0 when the rule holds)
+        if (__ballot(emit_shadow) != 0ull)
+        {
+            const bool full = exhaustive_any<false>(*bvh, sr), part = exhaustive_any<false, true>(*bvh, sr);
+            if (emit_shadow && full != part) atomicAdd((unsigned long long*)a.shaded_counter + 1, 1ull);
+            visible = emit_shadow && !part;
+        }
+#else
+        if (__ballot(emit_shadow) != 0ull) visible = emit_shadow && !exhaustive_any<false, true>(*bvh, sr);  // (a wave without a shadow ray: no test)
+#endif
 #endif
         const bool on_surface = valid && gid != kInvalidId;
         if (FIRST)

@@ -248,6 +248,10 @@ enum
      * forms on the device -- every normal float through log2, 2^30 operand pairs over the whole range -- and returns the number of
      * results that differ in any bit: 0. */
     CAP_DEBUG_SELFTEST_DIV        = 9,
+    /* NEE_PAIRS (get): fan pairs the EXT model's next-event rays test on the small-scene path << 32 | fan pairs of the scene.  Pairs that
+     * support the scene's convex hull with every light at a safe distance inside cannot occlude a segment between a scene point and a
+     * light point under the intersection contract (rule and error bound: context.hip update_nee_pairs) and are left out. */
+    CAP_DEBUG_NEE_PAIRS           = 10,
     /* A/B and diagnostic switches of the build and render paths (which kernels trace the camera and the shadow rays, one or two batch
      * lanes, the builders' parameters ...): ONE table per context, key = SWITCH_BASE + cap_debug_switch_index("CAP_..."), the names being
      * the environment variables that fill the table once, at cap_ctx_create (tools set those around a whole process; nothing else in the

@@ -135,3 +135,51 @@ def test_ext_energy_sanity(native_lib, bluenoise, tmp_path):
     expect = 2.0 - 0.5 ** (D + 1)
     assert abs(float(img.mean()) - expect) < 0.02, (float(img.mean()), expect)
     r.close()
+
+
+def test_nee_pair_cull_is_exact_and_used(native_lib, bluenoise, tmp_path):
+    """Next-event rays of the small-scene path skip the fan pairs that cannot occlude a segment between a scene point and the lamp
+    (hull faces with the lamp at a safe distance inside; context.hip update_nee_pairs: rule + error bound against the contract's absolute
+    tmin).  On the Cornell box that is the floor, the back and the two side walls -- NOT the ceiling, 1 cm above the lamp, whose rim
+    rays graze it.  With the cull and without it (switch table, same context): the same bits in every plane, the accumulated image and
+    the counters, over frames whose rays reach every corner; a lamp moved to the middle of the room keeps its pairs' count."""
+    geo, mats = cornell_with_materials(tmp_path)
+    w, h, D = 160, 120, 6
+    r = capi.Renderer(0)
+    r.upload_geometry(geo)
+    r.upload_materials(mats)
+    r.upload_bluenoise(bluenoise)
+    r.build_bvh()
+    r.set_resolution(w, h)
+    r.set_camera(capi.cornell_camera(w, h))
+    r.set_traversal(2)
+    v = r.debug_get(capi.Renderer.DEBUG_NEE_PAIRS)
+    tested, pairs = v >> 32, v & 0xFFFFFFFF
+    assert pairs == 16 and tested == 12, (tested, pairs)
+
+    def frames():
+        out = []
+        for f in (0, 7, 1023):
+            r.accum_reset()
+            r.stats_reset()
+            r.render(f, 1, D, capi.RENDER_AOV | capi.RENDER_EXT_MATERIALS)
+            s = r.stats()
+            assert s.guard_shade == 0 and s.guard_append == 0
+            out.append([r.readback(k) for k in (capi.BUF_DIRECT, capi.BUF_INDIRECT, capi.BUF_COMBINED)] + [(s.rays_primary, s.rays_extension, s.rays_shadow)])
+        r.accum_reset()
+        r.render(0, 8, D, capi.RENDER_EXT_MATERIALS)
+        out.append(r.readback(capi.BUF_ACCUM_SUM))
+        return out
+
+    with_cull = frames()
+    r.debug_switch("CAP_NO_NEE_PAIR_CULL", 1)
+    r.build_bvh()  # the list is made by cap_bvh_build / cap_materials_upload
+    v = r.debug_get(capi.Renderer.DEBUG_NEE_PAIRS)
+    assert v >> 32 == 16
+    without = frames()
+    for a, b in zip(with_cull[:3], without[:3]):
+        assert a[3] == b[3]
+        for x, y in zip(a[:3], b[:3]):
+            assert np.array_equal(bits(x), bits(y))
+    assert np.array_equal(bits(with_cull[3]), bits(without[3]))
+    r.close()
