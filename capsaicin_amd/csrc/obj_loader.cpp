@@ -43,16 +43,7 @@ bool parse_float(const std::string& s, float* out)
     return true;
 }
 
-// OBJ indices are 1-based; negative values count back from the current end of the attribute array.
-bool fix_index(const std::string& s, int count, int* out)
-{
-    char* end = nullptr;
-    long  v   = std::strtol(s.c_str(), &end, 10);
-    if (end == s.c_str() || v == 0) return false;
-    *out = v > 0 ? (int)v - 1 : count + (int)v;
-    return *out >= 0 && *out < count;
-}
-
+// (OBJ indices are 1-based; negative values count back from the current end of the attribute array: fast_index below)
 std::string join_from(const std::vector<std::string>& t, size_t first)
 {
     std::string s;
@@ -91,16 +82,123 @@ bool load_mtl(const std::string& path, std::vector<material_t>* materials, std::
 }
 }  // namespace
 
+// ---- the hot records (v / vn / vt / f: all but a few dozen lines of a scene file) are parsed in place, round 6 ----
+// (std::getline + a std::string per token + strtod per number parsed the 262 k-triangle hall's 26 MB at 170 MB/s: bench.py `ingest`)
+namespace
+{
+const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                           1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+inline bool is_blank(char c) { return c == ' ' || c == '\t' || c == '\r'; }
+
+// (float)strtod(token) for the token [p, e): decimal literals of at most 15 significant digits and a power of ten within 1e+-22 are
+// converted exactly like strtod does (an exact integer times or over an exact power of ten: one correctly rounded operation, W. D.
+// Clinger 1990); anything else -- longer mantissas, inf / nan / hex, a bare sign -- goes to strtod itself.  Like parse_float(): true when
+// a number starts the token; what follows it inside the token is ignored.
+bool fast_float(const char* p, const char* e, float* out)
+{
+    const char* q   = p;
+    bool        neg = false;
+    if (q < e && (*q == '-' || *q == '+')) neg = *q == '-', ++q;
+    uint64_t mant = 0;
+    int      digits = 0, exp10 = 0;
+    bool     any = false, simple = true;
+    for (; q < e && *q >= '0' && *q <= '9'; ++q)
+    {
+        any = true;
+        if (mant == 0 && *q == '0') continue;
+        if (digits < 19) mant = mant * 10 + (uint64_t)(*q - '0'), ++digits;
+        else ++exp10, simple = false;
+    }
+    if (q < e && *q == '.')
+    {
+        ++q;
+        for (; q < e && *q >= '0' && *q <= '9'; ++q)
+        {
+            any = true;
+            if (mant == 0 && *q == '0')
+            {
+                --exp10;
+                continue;
+            }
+            if (digits < 19) mant = mant * 10 + (uint64_t)(*q - '0'), ++digits, --exp10;
+            else simple = false;
+        }
+    }
+    if (any && q < e && (*q == 'e' || *q == 'E'))
+    {
+        const char* r    = q + 1;
+        bool        eneg = false;
+        if (r < e && (*r == '-' || *r == '+')) eneg = *r == '-', ++r;
+        if (r < e && *r >= '0' && *r <= '9')
+        {
+            int ex = 0;
+            for (; r < e && *r >= '0' && *r <= '9'; ++r) ex = ex < 10000 ? ex * 10 + (*r - '0') : ex;
+            exp10 += eneg ? -ex : ex;
+            q = r;
+        }
+    }
+    if (any && simple && q == e && digits <= 15 && exp10 >= -22 && exp10 <= 22)  // (q == e: nothing behind the number inside the token)
+    {
+        double d = (double)mant;
+        d        = exp10 < 0 ? d / kPow10[-exp10] : d * kPow10[exp10];
+        *out     = (float)(neg ? -d : d);
+        return true;
+    }
+    // the general case, on a terminated copy of the token
+    char        buf[64];
+    std::string big;
+    const size_t n = (size_t)(e - p);
+    const char*  z;
+    if (n < sizeof(buf))
+        std::memcpy(buf, p, n), buf[n] = 0, z = buf;
+    else
+        big.assign(p, e), z = big.c_str();
+    char*  endp = nullptr;
+    double v    = std::strtod(z, &endp);
+    if (endp == z) return false;
+    *out = (float)v;
+    return true;
+}
+
+// fix_index() on [p, e)
+bool fast_index(const char* p, const char* e, int count, int* out)
+{
+    const char* q   = p;
+    bool        neg = false;
+    if (q < e && (*q == '-' || *q == '+')) neg = *q == '-', ++q;
+    if (!(q < e && *q >= '0' && *q <= '9')) return false;
+    long v = 0;
+    for (; q < e && *q >= '0' && *q <= '9'; ++q) v = v < (1L << 40) ? v * 10 + (*q - '0') : v;
+    if (neg) v = -v;
+    if (v == 0) return false;
+    *out = v > 0 ? (int)v - 1 : count + (int)v;
+    return *out >= 0 && *out < count;
+}
+}  // namespace
+
 bool LoadObj(attrib_t* attrib, std::vector<shape_t>* shapes, std::vector<material_t>* materials, std::string* warn,
              std::string* err, const char* filename, const char* mtl_basedir)
 {
     attrib->vertices.clear(), attrib->normals.clear(), attrib->texcoords.clear();
     shapes->clear(), materials->clear();
-    std::ifstream f(filename);
-    if (!f)
+    std::string text;
     {
-        if (err) *err += std::string("Cannot open file [") + filename + "]\n";
-        return false;
+        std::ifstream f(filename, std::ios::binary);
+        if (!f)
+        {
+            if (err) *err += std::string("Cannot open file [") + filename + "]\n";
+            return false;
+        }
+        f.seekg(0, std::ios::end);
+        const std::streamoff size = f.tellg();
+        f.seekg(0, std::ios::beg);
+        if (size > 0)
+        {
+            text.resize((size_t)size);
+            f.read(&text[0], size);
+            text.resize((size_t)f.gcount());
+        }
     }
     std::string basedir;
     if (mtl_basedir && *mtl_basedir)
@@ -117,57 +215,75 @@ bool LoadObj(attrib_t* attrib, std::vector<shape_t>* shapes, std::vector<materia
     std::map<std::string, int> material_by_name;
     shape_t                    cur;
     int                        cur_material = -1;
-    std::string                line;
     size_t                     line_no = 0;
     auto flush = [&]() {
         if (!cur.mesh.indices.empty()) shapes->push_back(cur);
         cur = shape_t();
     };
-    while (std::getline(f, line))
+    std::vector<index_t> face;
+    const char*          p   = text.data();
+    const char* const    end = p + text.size();
+    while (p < end)
     {
+        const char* eol = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+        if (!eol) eol = end;
+        const char* q = p;
+        p             = eol < end ? eol + 1 : end;
         ++line_no;
-        auto t = split_ws(line);
-        if (t.empty() || t[0][0] == '#') continue;
-        const std::string& k = t[0];
         auto bad = [&](const char* what) {
             if (err) *err += std::string(filename) + ":" + std::to_string(line_no) + ": " + what + "\n";
             return false;
         };
-        if (k == "v" || k == "vn")
+        // next token of the line: [a, b); false at the end of the line
+        auto token = [&](const char*& a, const char*& b) {
+            while (q < eol && is_blank(*q)) ++q;
+            a = q;
+            while (q < eol && !is_blank(*q)) ++q;
+            b = q;
+            return b > a;
+        };
+        const char *k0, *k1;
+        if (!token(k0, k1) || *k0 == '#') continue;
+        const size_t kl = (size_t)(k1 - k0);
+        const bool   is_v = kl == 1 && k0[0] == 'v', is_vn = kl == 2 && k0[0] == 'v' && k0[1] == 'n';
+        if (is_v || is_vn)
         {
-            if (t.size() < 4) return bad("expected 3 coordinates");
-            float v[3];
+            float       v[3];
+            const char *a[3], *b[3];
             for (int c = 0; c < 3; ++c)
-                if (!parse_float(t[1 + c], &v[c])) return bad("malformed number");
-            auto& dst = k == "v" ? attrib->vertices : attrib->normals;
+                if (!token(a[c], b[c])) return bad("expected 3 coordinates");
+            for (int c = 0; c < 3; ++c)
+                if (!fast_float(a[c], b[c], &v[c])) return bad("malformed number");
+            auto& dst = is_v ? attrib->vertices : attrib->normals;
             dst.insert(dst.end(), v, v + 3);
         }
-        else if (k == "vt")
+        else if (kl == 2 && k0[0] == 'v' && k0[1] == 't')
         {
-            if (t.size() < 2) return bad("expected texture coordinates");
+            const char *a, *b;
+            if (!token(a, b)) return bad("expected texture coordinates");
             float u = 0.f, v = 0.f;
-            if (!parse_float(t[1], &u)) return bad("malformed number");
-            if (t.size() > 2 && !parse_float(t[2], &v)) return bad("malformed number");
+            if (!fast_float(a, b, &u)) return bad("malformed number");
+            if (token(a, b) && !fast_float(a, b, &v)) return bad("malformed number");
             attrib->texcoords.push_back(u), attrib->texcoords.push_back(v);
         }
-        else if (k == "f")
+        else if (kl == 1 && k0[0] == 'f')
         {
-            std::vector<index_t> face;
-            for (size_t i = 1; i < t.size(); ++i)
+            face.clear();
+            const char *a, *b;
+            while (token(a, b))
             {
                 index_t     idx{-1, -1, -1};
-                std::string tok = t[i];
-                size_t      s1  = tok.find('/');
-                std::string a = tok.substr(0, s1), b, c;
-                if (s1 != std::string::npos)
+                const char* s1 = (const char*)std::memchr(a, '/', (size_t)(b - a));
+                const char* s2 = s1 ? (const char*)std::memchr(s1 + 1, '/', (size_t)(b - s1 - 1)) : nullptr;
+                const char* ae = s1 ? s1 : b;
+                if (!fast_index(a, ae, (int)attrib->vertices.size() / 3, &idx.vertex_index)) return bad("vertex index out of range");
+                if (s1)
                 {
-                    size_t s2 = tok.find('/', s1 + 1);
-                    b         = tok.substr(s1 + 1, s2 == std::string::npos ? std::string::npos : s2 - s1 - 1);
-                    if (s2 != std::string::npos) c = tok.substr(s2 + 1);
+                    const char* tb = s1 + 1;
+                    const char* te = s2 ? s2 : b;
+                    if (te > tb && !fast_index(tb, te, (int)attrib->texcoords.size() / 2, &idx.texcoord_index)) return bad("texcoord index out of range");
+                    if (s2 && b > s2 + 1 && !fast_index(s2 + 1, b, (int)attrib->normals.size() / 3, &idx.normal_index)) return bad("normal index out of range");
                 }
-                if (!fix_index(a, (int)attrib->vertices.size() / 3, &idx.vertex_index)) return bad("vertex index out of range");
-                if (!b.empty() && !fix_index(b, (int)attrib->texcoords.size() / 2, &idx.texcoord_index)) return bad("texcoord index out of range");
-                if (!c.empty() && !fix_index(c, (int)attrib->normals.size() / 3, &idx.normal_index)) return bad("normal index out of range");
                 face.push_back(idx);
             }
             if (face.size() < 3) return bad("face with fewer than 3 vertices");
@@ -179,23 +295,30 @@ bool LoadObj(attrib_t* attrib, std::vector<shape_t>* shapes, std::vector<materia
                 cur.mesh.material_ids.push_back(cur_material);
             }
         }
-        else if (k == "o" || k == "g")
+        else
         {
-            flush();
-            cur.name = join_from(t, 1);
+            // the rare records, as before: tokens as strings
+            const std::string line(k0, eol);
+            auto              t = split_ws(line);
+            const std::string& k = t[0];
+            if (k == "o" || k == "g")
+            {
+                flush();
+                cur.name = join_from(t, 1);
+            }
+            else if (k == "usemtl")
+            {
+                auto it      = material_by_name.find(join_from(t, 1));
+                cur_material = it == material_by_name.end() ? -1 : it->second;
+            }
+            else if (k == "mtllib")
+            {
+                for (size_t i = 1; i < t.size(); ++i)
+                    if (!load_mtl(basedir + t[i], materials, &material_by_name) && warn)
+                        *warn += "Material file [ " + t[i] + " ] not found in a path : " + basedir + "\n";
+            }
+            // s, l, p and unknown records are ignored
         }
-        else if (k == "usemtl")
-        {
-            auto it      = material_by_name.find(join_from(t, 1));
-            cur_material = it == material_by_name.end() ? -1 : it->second;
-        }
-        else if (k == "mtllib")
-        {
-            for (size_t i = 1; i < t.size(); ++i)
-                if (!load_mtl(basedir + t[i], materials, &material_by_name) && warn)
-                    *warn += "Material file [ " + t[i] + " ] not found in a path : " + basedir + "\n";
-        }
-        // s, l, p and unknown records are ignored
     }
     flush();
     return true;
@@ -263,20 +386,40 @@ int cap_obj_load(const char* obj_path, const char* mtl_dir, CapGeometry** out)
     for (uint32_t si = 0; si < shapes.size(); ++si)
     {
         // asset_load_system.cpp:100-142
-        std::map<std::tuple<int, int, int>, uint32_t> cache;
-        const auto&                                   sh = shapes[si];
-        uint32_t                                      nverts = 0;
-        const uint32_t                                first_index = index_total;
+        // (vertex, normal, texcoord) -> the shape's vertex number, first use first: an open-addressing table (a std::map of tuples was a
+        // third of the load time of a 262 k-triangle scene)
+        const auto&    sh = shapes[si];
+        size_t         cap = 16;
+        while (cap < 2 * sh.mesh.indices.size()) cap <<= 1;
+        std::vector<uint32_t> slot(cap, ~0u);  // index into `keys`
+        std::vector<tinyobj::index_t> keys;
+        keys.reserve(sh.mesh.indices.size() / 2);
+        uint32_t       nverts = 0;
+        const uint32_t first_index = index_total;
+        g->indices.reserve(g->indices.size() + sh.mesh.indices.size());
         for (const auto& ix : sh.mesh.indices)
         {
-            auto key = std::make_tuple(ix.vertex_index, ix.normal_index, ix.texcoord_index);
-            auto it  = cache.find(key);
-            if (it != cache.end())
+            uint64_t h = (uint64_t)(uint32_t)ix.vertex_index * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uint32_t)ix.normal_index * 0xC2B2AE3D27D4EB4Full ^
+                         (uint64_t)(uint32_t)ix.texcoord_index * 0x165667B19E3779F9ull;
+            size_t   at = (size_t)(h >> 20) & (cap - 1);
+            uint32_t found = ~0u;
+            for (;; at = (at + 1) & (cap - 1))
             {
-                g->indices.push_back(it->second);
+                const uint32_t k = slot[at];
+                if (k == ~0u) break;
+                if (keys[k].vertex_index == ix.vertex_index && keys[k].normal_index == ix.normal_index && keys[k].texcoord_index == ix.texcoord_index)
+                {
+                    found = k;
+                    break;
+                }
+            }
+            if (found != ~0u)
+            {
+                g->indices.push_back(found);
                 continue;
             }
-            cache[key] = nverts;
+            slot[at] = nverts;
+            keys.push_back(ix);
             g->indices.push_back(nverts++);
             for (int k = 0; k < 3; ++k) g->positions.push_back(attrib.vertices[3 * ix.vertex_index + k]);
             for (int k = 0; k < 3; ++k) g->normals.push_back(ix.normal_index != -1 ? attrib.normals[3 * ix.normal_index + k] : 0.f);
