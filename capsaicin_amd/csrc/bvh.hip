@@ -30,11 +30,14 @@ __device__ __forceinline__ float ordered_to_float(uint32_t o)
 // intersection record (v0, e1, e2), the pre-gathered shading record and the triangle box; reduce scene bounds.
 __global__ __launch_bounds__(kBlock) void k_tri_setup(BvhBuildArgs a)
 {
+    __shared__ float s_lo[kBlock / 64][3], s_hi[kBlock / 64][3];
     float4* tri_box = a.tri_box;
-    const uint32_t g  = blockIdx.x * kBlock + threadIdx.x;
-    float          lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    if (g < a.tri_count)
+    float   slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    // a fixed grid strides over the triangles: the scene bounds cost six atomics per WORKGROUP (one per wave and component was 1.6 M
+    // atomics on six words at 16.8 M triangles: 17 of the kernel's 18 ms)
+    for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < a.tri_count; g += gridDim.x * kBlock)
     {
+        float lo[3], hi[3];
         const uint4    id  = a.tri_ids[g];
         const uint4    mo  = a.mesh_offsets[id.x];
         const uint32_t io  = mo.y + 3u * id.y;
@@ -63,21 +66,27 @@ __global__ __launch_bounds__(kBlock) void k_tri_setup(BvhBuildArgs a)
         hi[0] = fmaxf(p0.x, fmaxf(p1.x, p2.x)), hi[1] = fmaxf(p0.y, fmaxf(p1.y, p2.y)), hi[2] = fmaxf(p0.z, fmaxf(p1.z, p2.z));
         tri_box[2 * (size_t)g + 0] = make_float4(lo[0], lo[1], lo[2], 0.f);
         tri_box[2 * (size_t)g + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        for (int k = 0; k < 3; ++k) slo[k] = fminf(slo[k], lo[k]), shi[k] = fmaxf(shi[k], hi[k]);
     }
-    // wave reduction, then one atomic per wave and component
+    // wave reduction, workgroup reduction, then one atomic per workgroup and component
     for (int k = 0; k < 3; ++k)
     {
-        float l = lo[k], h = hi[k];
+        float l = slo[k], h = shi[k];
         for (int off = 32; off > 0; off >>= 1)
         {
             l = fminf(l, __shfl_down(l, off));
             h = fmaxf(h, __shfl_down(h, off));
         }
-        if ((threadIdx.x & 63u) == 0)
-        {
-            if (l != INFINITY) atomicMin(&a.bounds[k], float_to_ordered(l));
-            if (h != -INFINITY) atomicMax(&a.bounds[3 + k], float_to_ordered(h));
-        }
+        if ((threadIdx.x & 63u) == 0) s_lo[threadIdx.x >> 6][k] = l, s_hi[threadIdx.x >> 6][k] = h;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3u)
+    {
+        const int k = (int)threadIdx.x;
+        float     l = s_lo[0][k], h = s_hi[0][k];
+        for (uint32_t w = 1; w < kBlock / 64; ++w) l = fminf(l, s_lo[w][k]), h = fmaxf(h, s_hi[w][k]);
+        if (l != INFINITY) atomicMin(&a.bounds[k], float_to_ordered(l));
+        if (h != -INFINITY) atomicMax(&a.bounds[3 + k], float_to_ordered(h));
     }
 }
 
@@ -125,32 +134,81 @@ __global__ __launch_bounds__(kBlock) void k_radix_hist(const uint32_t* keys, uin
     hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of hist (digit-major, block-minor) by one workgroup
-__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t* hist, uint32_t total)
+// exclusive scan of hist (digit-major, block-minor) in three launches (round 6; one workgroup looping over 2 M entries with twenty
+// barriers per 1024 took 3.6 ms per pass at 16.8 M triangles -- a third of the clustering build): per tile of kScanTile entries a sum,
+// an exclusive scan of the tile sums by one workgroup, then every tile scans itself on top of its sum's prefix.
+constexpr uint32_t kScanTile = 4096;  // 1024 threads x 4
+__global__ __launch_bounds__(1024) void k_scan_tile_sums(const uint32_t* v, uint32_t total, uint32_t* sums)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t      i0 = blockIdx.x * kScanTile + threadIdx.x * 4u;
+    uint32_t            s  = 0;
+    for (uint32_t k = 0; k < 4u; ++k) s += i0 + k < total ? v[i0 + k] : 0u;
+    for (int off = 32; off > 0; off >>= 1) s += (uint32_t)__shfl_xor((int)s, off);
+    if ((threadIdx.x & 63u) == 0) s_wave[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += s_wave[w];
+        sums[blockIdx.x] = t;
+    }
+}
+// exclusive scan of n values by ONE workgroup (n <= a few thousand tile sums): per-thread runs + a Hillis-Steele scan of the run sums
+__global__ __launch_bounds__(1024) void k_scan_small(uint32_t* v, uint32_t n)
 {
     __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
+    const uint32_t      t = threadIdx.x, per = (n + 1023u) / 1024u, b0 = min(n, t * per), b1 = min(n, b0 + per);
+    uint32_t            s = 0;
+    for (uint32_t b = b0; b < b1; ++b) s += v[b];
+    part[t] = s;
     __syncthreads();
-    for (uint32_t base = 0; base < total; base += 1024)
+    for (uint32_t off = 1; off < 1024u; off <<= 1)
     {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < total ? hist[i] : 0u;
-        part[threadIdx.x] = v;
+        const uint32_t x = t >= off ? part[t - off] : 0u;
         __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1)
-        {
-            const uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        const uint32_t incl = part[threadIdx.x];
-        if (i < total) hist[i] = carry + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += incl;
+        part[t] += x;
         __syncthreads();
     }
+    uint32_t e = part[t] - s;
+    for (uint32_t b = b0; b < b1; ++b)
+    {
+        const uint32_t x = v[b];
+        v[b] = e;
+        e += x;
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* v, uint32_t total, const uint32_t* sums)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t      i0 = blockIdx.x * kScanTile + threadIdx.x * 4u, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t            x[4], s = 0;
+    for (uint32_t k = 0; k < 4u; ++k) x[k] = i0 + k < total ? v[i0 + k] : 0u, s += x[k];
+    // inclusive scan of the threads' sums inside the wave, then across the 16 waves
+    uint32_t incl = s;
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, off);
+        if ((int)lane >= off) incl += y;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = sums[blockIdx.x];
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+    uint32_t e = base + incl - s;
+    for (uint32_t k = 0; k < 4u; ++k)
+    {
+        if (i0 + k < total) v[i0 + k] = e;
+        e += x[k];
+    }
+}
+// scratch: ceil(total / kScanTile) words
+static void launch_exclusive_scan(hipStream_t stream, uint32_t* v, uint32_t total, uint32_t* scratch)
+{
+    const uint32_t tiles = (total + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(1024), 0, stream, v, total, scratch);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, stream, scratch, tiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(1024), 0, stream, v, total, scratch);
 }
 
 __global__ __launch_bounds__(kBlock) void k_radix_scatter(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
@@ -404,15 +462,33 @@ __global__ __launch_bounds__(kBlock) void k_wide_count(WideCollapseArgs a)
     a.cnt[2 * (size_t)(w - a.begin)] = n_inner, a.cnt[2 * (size_t)(w - a.begin) + 1] = n_tris;
 }
 
-// exclusive scan of the level's (inner children, triangles) pairs on top of alloc[0..1], one workgroup; alloc takes the totals.  The
-// blocks a level's nodes get are in the level's own order: the layout is the same on every run and a node's children lie next to its
-// siblings' children.
-__global__ __launch_bounds__(1024) void k_wide_scan(WideCollapseArgs a)
+// exclusive scan of the level's (inner children, triangles) pairs on top of alloc[0..1]; alloc takes the totals.  The blocks a level's
+// nodes get are in the level's own order: the layout is the same on every run and a node's children lie next to its siblings' children.
+// Three launches (tile sums, their scan by one workgroup, the tiles): a level of the 16.8 M-triangle tree has 1.4 M nodes.
+constexpr uint32_t kWideScanTile = 1024;  // pairs per workgroup (256 threads x 4)
+__global__ __launch_bounds__(kBlock) void k_wide_scan_sums(WideCollapseArgs a, uint32_t* sums)
+{
+    __shared__ uint32_t s_wave[kBlock / 64][2];
+    const uint32_t      n = a.end - a.begin, i0 = blockIdx.x * kWideScanTile + threadIdx.x * 4u;
+    uint32_t            s0 = 0, s1 = 0;
+    for (uint32_t k = 0; k < 4u; ++k)
+        if (i0 + k < n) s0 += a.cnt[2 * (size_t)(i0 + k)], s1 += a.cnt[2 * (size_t)(i0 + k) + 1];
+    for (int off = 32; off > 0; off >>= 1) s0 += (uint32_t)__shfl_xor((int)s0, off), s1 += (uint32_t)__shfl_xor((int)s1, off);
+    if ((threadIdx.x & 63u) == 0) s_wave[threadIdx.x >> 6][0] = s0, s_wave[threadIdx.x >> 6][1] = s1;
+    __syncthreads();
+    if (threadIdx.x < 2u)
+    {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < kBlock / 64; ++w) t += s_wave[w][threadIdx.x];
+        sums[2 * (size_t)blockIdx.x + threadIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_wide_scan_small(WideCollapseArgs a, uint32_t* sums, uint32_t tiles)
 {
     __shared__ uint32_t s_part[2][1024];
-    const uint32_t n = a.end - a.begin, t = threadIdx.x, per = (n + 1023u) / 1024u, b0 = min(n, t * per), b1 = min(n, b0 + per);
+    const uint32_t t = threadIdx.x, per = (tiles + 1023u) / 1024u, b0 = min(tiles, t * per), b1 = min(tiles, b0 + per);
     uint32_t       s0 = 0, s1 = 0;
-    for (uint32_t b = b0; b < b1; ++b) s0 += a.cnt[2 * (size_t)b], s1 += a.cnt[2 * (size_t)b + 1];
+    for (uint32_t b = b0; b < b1; ++b) s0 += sums[2 * (size_t)b], s1 += sums[2 * (size_t)b + 1];
     s_part[0][t] = s0, s_part[1][t] = s1;
     __syncthreads();
     for (uint32_t off = 1; off < 1024u; off <<= 1)
@@ -425,12 +501,38 @@ __global__ __launch_bounds__(1024) void k_wide_scan(WideCollapseArgs a)
     uint32_t e0 = a.alloc[0] + s_part[0][t] - s0, e1 = a.alloc[1] + s_part[1][t] - s1;
     for (uint32_t b = b0; b < b1; ++b)
     {
-        const uint32_t k0 = a.cnt[2 * (size_t)b], k1 = a.cnt[2 * (size_t)b + 1];
-        a.cnt[2 * (size_t)b] = e0, a.cnt[2 * (size_t)b + 1] = e1;
+        const uint32_t k0 = sums[2 * (size_t)b], k1 = sums[2 * (size_t)b + 1];
+        sums[2 * (size_t)b] = e0, sums[2 * (size_t)b + 1] = e1;
         e0 += k0, e1 += k1;
     }
     __syncthreads();  // every read of alloc is done
     if (t == 1023u) a.alloc[0] += s_part[0][t], a.alloc[1] += s_part[1][t];
+}
+__global__ __launch_bounds__(kBlock) void k_wide_scan_tiles(WideCollapseArgs a, const uint32_t* sums)
+{
+    __shared__ uint32_t s_wave[kBlock / 64][2];
+    const uint32_t      n = a.end - a.begin, i0 = blockIdx.x * kWideScanTile + threadIdx.x * 4u, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t            x0[4], x1[4], s0 = 0, s1 = 0;
+    for (uint32_t k = 0; k < 4u; ++k)
+    {
+        x0[k] = i0 + k < n ? a.cnt[2 * (size_t)(i0 + k)] : 0u, x1[k] = i0 + k < n ? a.cnt[2 * (size_t)(i0 + k) + 1] : 0u;
+        s0 += x0[k], s1 += x1[k];
+    }
+    uint32_t c0 = s0, c1 = s1;
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        const uint32_t y0 = (uint32_t)__shfl_up((int)c0, off), y1 = (uint32_t)__shfl_up((int)c1, off);
+        if ((int)lane >= off) c0 += y0, c1 += y1;
+    }
+    if (lane == 63u) s_wave[wave][0] = c0, s_wave[wave][1] = c1;
+    __syncthreads();
+    uint32_t e0 = sums[2 * (size_t)blockIdx.x] + c0 - s0, e1 = sums[2 * (size_t)blockIdx.x + 1] + c1 - s1;
+    for (uint32_t w = 0; w < wave; ++w) e0 += s_wave[w][0], e1 += s_wave[w][1];
+    for (uint32_t k = 0; k < 4u; ++k)
+    {
+        if (i0 + k < n) a.cnt[2 * (size_t)(i0 + k)] = e0, a.cnt[2 * (size_t)(i0 + k) + 1] = e1;
+        e0 += x0[k], e1 += x1[k];
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_wide_level(WideCollapseArgs a)
@@ -559,7 +661,13 @@ int launch_wide_collapse(hipStream_t stream, WideCollapseArgs a, uint32_t* node_
         if (levels <= 3) top = end < kWideTopNodes ? end : kWideTopNodes;
         a.begin = begin, a.end = end;
         hipLaunchKernelGGL(k_wide_count, dim3((end - begin + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
-        hipLaunchKernelGGL(k_wide_scan, dim3(1), dim3(1024), 0, stream, a);
+        {
+            const uint32_t tiles = (end - begin + kWideScanTile - 1) / kWideScanTile;
+            uint32_t*      sums  = a.cnt + 2 * (size_t)a.capacity;  // (the tail of the per-level scratch: 2 * (capacity / 1024 + 2) words)
+            hipLaunchKernelGGL(k_wide_scan_sums, dim3(tiles), dim3(kBlock), 0, stream, a, sums);
+            hipLaunchKernelGGL(k_wide_scan_small, dim3(1), dim3(1024), 0, stream, a, sums, tiles);
+            hipLaunchKernelGGL(k_wide_scan_tiles, dim3(tiles), dim3(kBlock), 0, stream, a, sums);
+        }
         hipLaunchKernelGGL(k_wide_level, dim3((end - begin + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
         uint32_t allocated = 0u;
         if (hipMemcpyAsync(&allocated, a.alloc, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;
@@ -582,7 +690,7 @@ static void bvh_setup(hipStream_t stream, const BvhBuildArgs& a)
     (void)hipMemcpyAsync(a.bounds, init, sizeof(init), hipMemcpyHostToDevice, stream);
     (void)hipMemsetAsync(a.flags, 0, sizeof(uint32_t) * n, stream);
     (void)hipMemsetAsync(a.max_depth, 0, sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(k_tri_setup, dim3(blocks), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(k_tri_setup, dim3(blocks < 4096u ? blocks : 4096u), dim3(kBlock), 0, stream, a);
 }
 
 void launch_bvh_setup(hipStream_t stream, const BvhBuildArgs& a)
@@ -614,7 +722,7 @@ int launch_bvh_sort(hipStream_t stream, const BvhBuildArgs& a)
         for (uint32_t shift = 0; shift < 32; shift += 8)
         {
             hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(kBlock), 0, stream, a.keys[src], n, shift, nb, a.hist);
-            hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, stream, a.hist, 256u * nb);
+            launch_exclusive_scan(stream, a.hist, 256u * nb, a.parent);  // (a.parent: 2 n words that every builder writes in full after the sort)
             hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(kBlock), 0, stream, a.keys[src], a.vals[src], a.keys[src ^ 1],
                                a.vals[src ^ 1], n, shift, nb, a.hist);
             src ^= 1;

@@ -209,7 +209,7 @@ struct WideCollapseArgs
     uint32_t        n_tris, capacity;
     double          pad;
     uint32_t *      task, *alloc, *nodes8, *tri_src;
-    uint32_t*       cnt;  // 2 * capacity words: per node of the level being written, (inner children, triangles) -> their bases
+    uint32_t*       cnt;  // 2 * capacity + 2 * (capacity / 1024 + 2) words: per node of the level being written, (inner children, triangles) -> their bases; the scan's tile sums behind
     uint32_t        begin, end;
 };
 int      launch_wide_collapse(hipStream_t stream, WideCollapseArgs a, uint32_t* node_count, uint32_t* depth, uint32_t* top_nodes);

@@ -87,7 +87,7 @@ __device__ __forceinline__ WideNode wide_node_load(const float4* __restrict__ N)
 }
 
 // Box tests of the eight children of a node; replaces the cursor's groups by the node's.
-#ifndef CAP_W8_NODE_V1
+#if !defined(CAP_W8_NODE_V1) && !defined(CAP_W8_COUNT)  // (the step-counting diagnostic build keeps the round-2 form: it exports the children's entry distances)
 // Box tests of the eight children of a node; replaces the cursor's groups by the node's.
 // Round 6 form, written against the measured issue rates of docs/experiments.md (74) (tools/micro/valu_cost.hip): per SIMD a wave64
 // v_fma / v_sub / v_bitop3 costs 2 cycles, a select, a compare, a two-operand min / max, a byte conversion or a shift 4.  So
@@ -200,7 +200,7 @@ __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay&
     c.t_hits  = __builtin_amdgcn_perm(h8, h8, 0x0c000000u) & tvalid;  // h8 in the three low bytes (one v_perm_b32)
 }
 
-#endif  // CAP_W8_NODE_V1
+#endif  // CAP_W8_NODE_V1 || CAP_W8_COUNT
 
 // Takes the next due triangle out of the triangle group; returns its record index.
 __device__ __forceinline__ uint32_t wide_pick_triangle(WideCursor& c)

@@ -1038,7 +1038,7 @@ int cap_bvh_build(CapContext* c)
             const uint32_t cap = n / 2u + 16u;  // an inner child stands for >= 4 triangles
             HIP_TRY(c->nodes8.ensure((kWideNodeStride / 4) * std::max<size_t>((size_t)cap + 1, kWideTopNodes)));
             HIP_TRY(c->wide_task.ensure(cap));
-            HIP_TRY(c->wide_cnt.ensure(2 * (size_t)cap));
+            HIP_TRY(c->wide_cnt.ensure(2 * (size_t)cap + 2 * ((size_t)cap / 1024 + 2)));  // per-level bases + the scan's tile sums
             HIP_TRY(c->wide_alloc.ensure(2));
             double m = 0.0;
             for (int k = 0; k < 3; ++k)

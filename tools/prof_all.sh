@@ -26,10 +26,13 @@ for n in 1 8; do
     CAP_NO_TWO_LANES=1 bash tools/shard_trace.sh $n sponza > $OUT/shard${n}_sponza.txt 2>&1
 done
 echo "w8_counts (diagnostic build)" >> $OUT/prof_all_progress.log
-# the checkout is left with the PRODUCT build whatever happens below
-trap '(cd $ROOT/capsaicin_amd/csrc && make -B trace8.o kernels.o context.o && make) > /dev/null 2>&1' EXIT
-(cd capsaicin_amd/csrc && make -B trace8.o kernels.o context.o EXTRA=-DCAP_W8_COUNT > /dev/null 2>&1 && make EXTRA=-DCAP_W8_COUNT > /dev/null 2>&1)
-timeout -k 5 200 python tools/w8_counts.py > $OUT/w8_counts.json 2> $OUT/w8_counts.err
-timeout -k 5 300 python tools/w8_counts.py 8 > $OUT/w8_counts_big.json 2> $OUT/w8_counts_big.err
+# the step-counting build is a VARIANT made beside the product build before the call (tools/build_variant.sh w8count -DCAP_W8_COUNT;
+# capsaicin_amd/variants/, picked with CAP_LIB_VARIANT): nothing is compiled on the GPU box and the product build is never touched
+if [ -f capsaicin_amd/variants/libcapsaicin_hip_w8count.so ]; then
+    CAP_LIB_VARIANT=w8count timeout -k 5 200 python tools/w8_counts.py > $OUT/w8_counts.json 2> $OUT/w8_counts.err
+    CAP_LIB_VARIANT=w8count timeout -k 5 300 python tools/w8_counts.py 8 > $OUT/w8_counts_big.json 2> $OUT/w8_counts_big.err
+else
+    echo "no capsaicin_amd/variants/libcapsaicin_hip_w8count.so: run tools/build_variant.sh w8count -DCAP_W8_COUNT first" >> $OUT/prof_all_progress.log
+fi
 echo "done" >> $OUT/prof_all_progress.log
 tail -3 $OUT/prof_sh.log; tail -2 $OUT/tree_trace.txt; tail -1 $OUT/w8_counts.json | cut -c1-200
