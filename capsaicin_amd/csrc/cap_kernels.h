@@ -242,7 +242,6 @@ struct PostChainArgs
     const float4 *tiled_indirect, *tiled_normal_depth;
     float4*       indirect_rowmajor;  // where the untiled indirect plane goes (the chain's `indirect` when tiled)
     ScreenDev     screen;
-    uint32_t      cu_count;  // compute units of the device (0: unknown, 256 assumed): the persistent stencil kernels size their grids by it
     // persistent state (raytracing_system.cpp:262-317)
     float4 *indirect_history[2], *moments_history[2], *combined_history[2], *prev_normal_depth;
     // scratch

@@ -5,7 +5,7 @@
 // below 2^-103, a quotient that would be denormal or whose exponents differ by 96 or more (CDNA ISA, V_DIV_SCALE_F32) -- and the
 // fix-up only on zeros, infinities and NaNs.  Everywhere else they pass their operands through, and what remains is the sequence
 // below: the same instructions on the same operands, so the same bits (29 cycles).  It is therefore ONLY called on operands known to
-// be in range -- |a| = 0 or in [2^-80, 2^41], b in [2^-40, 2^40]; the reconstruction chain establishes that per tile (post.hip) and
+// be in range -- |a| = 0 or in [2^-80, 2^41], b in [2^-40, 2^41) (a sigma <= 2^38 times a tap length <= sqrt(18): the range the self-test draws from); the reconstruction chain establishes that per tile (post.hip) and
 // takes the plain `/` for a tile or wave that fails: the same result by definition.  cap_debug_get(CAP_DEBUG_SELFTEST_DIV) compares both
 // forms on the device, bit for bit.  (The same treatment of sqrtf and of the small-scene shading's per-vertex divisions measured
 // slower -- per-vertex guards are not amortised the way a tile's are: docs/experiments.md (70).)

@@ -184,6 +184,7 @@ struct CapContext
     // The smallest second working set (paths = slots x padded pixels) whose allocation has failed since the last call that can free
     // memory: cap_render does not try that size or a larger one again (every call repeated ~28 GB of hipMalloc / hipFree).
     uint64_t      lane1_failed_paths = 0;
+    uint32_t      lane1_failed_bounces = 0, lane1_retry_tick = 0;
     uint32_t      lanes_last_render = 0;       // cap_debug_get(CAP_DEBUG_LANES_USED)
     uint32_t      last_class_capacity = 0;     // sub-queue capacity of the last cap_render batch (CAP_DEBUG_QUEUE_CANARY_*)
     uint32_t      traversal_mode  = CAP_TRAVERSAL_AUTO;
@@ -1223,8 +1224,9 @@ static int canary_count(CapContext* c, bool behind, uint64_t* value)
 {
     if (!c->q_org[0].p || !c->last_class_capacity) return fail(CAP_ERR_STATE, "cap_debug_get: no render yet");
     HIP_TRY(hipSetDevice(c->device));
-    unsigned long long* d = nullptr;
-    HIP_TRY(hipMalloc(&d, sizeof(*d)));
+    DevBuf<unsigned long long> dbuf;  // (released on every path: ADVICE r5)
+    HIP_TRY(dbuf.ensure(1));
+    unsigned long long* d = dbuf.p;
     HIP_TRY(hipMemsetAsync(d, 0, sizeof(*d), c->stream));
     const size_t used = std::min((size_t)kQueueClasses * c->last_class_capacity, c->q_org[0].n);
     for (int k = 0; k < 2; ++k)
@@ -1233,10 +1235,10 @@ static int canary_count(CapContext* c, bool behind, uint64_t* value)
             const size_t lo = behind ? used : 0, hi = behind ? b->n : used;
             if (hi > lo) hipLaunchKernelGGL(k_canary_count, dim3(512), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(b->p), lo, hi, d);
         }
+    HIP_TRY(hipGetLastError());
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(d);
     *value = h;
     return CAP_OK;
 }
@@ -1288,14 +1290,17 @@ int cap_debug_get(CapContext* c, uint32_t key, uint64_t* value)
     case CAP_DEBUG_SELFTEST_DIV:
     {
         HIP_TRY(hipSetDevice(c->device));
-        unsigned long long* d = nullptr;
-        unsigned long long  h[2] = {0, 0};
-        HIP_TRY(hipMalloc(&d, sizeof(h)));
-        HIP_TRY(hipMemsetAsync(d, 0, sizeof(h), c->stream));
-        launch_div_selftest(c->stream, d);
-        HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        DevBuf<unsigned long long> d;  // (released on every path: ADVICE r5)
+        unsigned long long         h[3] = {0, 0, 0};
+        HIP_TRY(d.ensure(3));
+        HIP_TRY(hipMemsetAsync(d.p, 0, sizeof(h), c->stream));
+        launch_div_selftest(c->stream, d.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        (void)hipFree(d);
+        // positive control: every normal float once + 2^30 operand pairs must have been compared
+        const unsigned long long expected = (0x7f7fffffull - 0x00800000ull + 1ull) + (1ull << 30);
+        if (h[2] != expected) return fail(CAP_ERR_HIP, "cap_debug_get: the division self-test compared %llu of %llu cases", h[2], expected);
         *value = h[0] + h[1];
         return CAP_OK;
     }
@@ -1444,10 +1449,17 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     // render launches what the plain one does -- and run one after the other on lane 0)
     if ((flags & CAP_RENDER_STAGE_TIMERS) || c->sw.on(SW_TRACE_LAUNCHES)) two_lanes = false;
     if (ensure_wavefront(c, slots, num_bounces) != CAP_OK) return CAP_ERR_HIP;
-    if (two_lanes && c->lane1_failed_paths && (uint64_t)slots * Ppad >= c->lane1_failed_paths)
+    if (two_lanes && c->lane1_failed_paths && (uint64_t)slots * Ppad >= c->lane1_failed_paths && num_bounces >= c->lane1_failed_bounces)
     {
-        two_lanes = false;  // this size has already failed and nothing has been freed since: one lane, without asking again
-        ++c->stats.lane1_dropped;
+        // this size has already failed: one lane, without asking again -- except every 32nd time, and at once when the device reports
+        // room for it (memory can come back without any call on this context: another context closed, a co-tenant left)
+        size_t free_b = 0, total_b = 0;
+        const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (size_t)slots * Ppad * 256u;  // a working set is ~208 B per path
+        if (!room && (++c->lane1_retry_tick % 32u) != 0u)
+        {
+            two_lanes = false;
+            ++c->stats.lane1_dropped;
+        }
     }
     if (two_lanes)
     {
@@ -1463,7 +1475,7 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
             // size until something is freed
             (void)hipGetLastError();
             c->lane1 = CapContext::Lane{};
-            c->lane1_failed_paths = (uint64_t)slots * Ppad;
+            c->lane1_failed_paths = (uint64_t)slots * Ppad, c->lane1_failed_bounces = num_bounces;  // (ensure_lane1's size depends on both)
             ++c->stats.lane1_dropped;
             two_lanes = false;
         }
@@ -1919,7 +1931,6 @@ static int run_post_chain(CapContext* c, const CapPostSettings* s, uint32_t fram
                                  s->gather_depth_sigma, s->gather_luma_sigma, s->temporal_upscale_feedback, s->taa_feedback, s->lowres_indirect,
                                  s->disable_variance ? 0 : 1, s->fast_weights, s->output};
     a.width = c->screen.width, a.height = c->screen.height, a.frame_count = frame_count;
-    a.cu_count = (uint32_t)std::max(c->cu_count, 0);
     a.camera = camera_dev(c->camera), a.prev_camera = camera_dev(*prev_camera);
     a.indirect = c->post_in[0].p, a.direct = c->post_in[1].p, a.albedo = c->post_in[2].p, a.normal_depth = c->post_in[3].p;
     if (tiled)

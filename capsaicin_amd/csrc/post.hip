@@ -124,7 +124,7 @@ __device__ __forceinline__ v3 oct_decode(float fx, float fy)
 // 2^-103, a quotient that would be denormal or whose exponents differ by 96 or more (CDNA ISA, V_DIV_SCALE_F32) --, and
 // v_div_fixup only on zeros, infinities and NaNs; everywhere else they pass their operands through and what remains is the
 // sequence below: the same instructions on the same operands, so the same bits (29 cycles).  `div_unscaled` is therefore ONLY called
-// where the operands are known to be in range -- |a| = 0 or in [2^-80, 2^41], b in [2^-40, 2^40] -- which the stencil kernels
+// where the operands are known to be in range -- |a| = 0 or in [2^-80, 2^41], b in [2^-40, 2^41) -- which the stencil kernels
 // establish per tile while staging (depths in [1e-5, 2^40], luminances 0 or in [2^-50, 2^30], the pixel's sigmas in [2^-38, 2^38];
 // a tile or wave that fails takes the IEEE form: the same result by definition).  cap_debug_get(CAP_DEBUG_SELFTEST_DIV) compares both
 // forms on the device: every float for log2's (m - 1) / (m + 1), 2^30 pseudo-random pairs over the whole stated range for the rest.
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(kBlock) void k_taa(PostSettingsDev s, CameraDev cam
 // cap_debug_get(CAP_DEBUG_SELFTEST_DIV): div_unscaled against the compiler's IEEE division, bit for bit, on the device.
 //   out[0]: log2_c_ns(x) != log2_c(x) over EVERY positive normal float x (the only division inside is (m - 1) / (m + 1));
 //   out[1]: div_unscaled(a, b) != a / b over 2^30 pseudo-random pairs that cover the range it is used on: a = 0 or in [2^-80, 2^42),
-//           b in [2^-40, 2^41), exponents and mantissas drawn independently.
+//           b in [2^-40, 2^41) (what the call sites can pass: a sigma <= 2^38 times a tap length <= sqrt(18)), exponents and mantissas drawn independently.
 __device__ __forceinline__ uint32_t selftest_hash(uint32_t x)
 {
     x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
@@ -1034,6 +1034,12 @@ __global__ __launch_bounds__(kBlock) void k_div_selftest(unsigned long long* out
     }
     if (bad0) atomicAdd(&out[0], bad0);
     if (bad1) atomicAdd(&out[1], bad1);
+    // positive control: how many comparisons this thread made -- the host fails the self-test unless the total is the
+    // number of normal floats + 2^30 (a kernel that never ran leaves zeros everywhere and used to read as "passed")
+    unsigned long long n = 0;
+    for (uint64_t b = 0x00800000ull + tid; b <= 0x7f7fffffull; b += total) ++n;
+    for (uint32_t i = tid; i < (1u << 30); i += total) ++n;
+    atomicAdd(&out[2], n);
 }
 }  // namespace
 

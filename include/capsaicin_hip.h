@@ -142,8 +142,9 @@ typedef struct CapStats
      * offending wave saw (extension << 32 | shadow).  cap_debug_set(CAP_DEBUG_QUEUE_CAPACITY_DIV) provokes it for the tests. */
     uint64_t guard_append;
     /* cap_render calls that wanted two batch lanes (tree path, see cap_render) and ran on one because the second working set could not
-     * be allocated: same image, ~7 % less throughput.  A size that has failed is not tried again until cap_set_resolution /
-     * cap_set_shard / cap_set_batch_paths change what is needed. */
+     * be allocated: same image, ~7 % less throughput.  A (paths, bounces) size that has failed is not tried again until
+     * cap_scene_upload / cap_set_resolution / cap_set_shard / cap_set_batch_paths change what is needed, the device reports enough free
+     * memory for it (memory can come back without a call on this context), or every 32nd call. */
     uint64_t lane1_dropped;
 } CapStats;
 
