@@ -99,6 +99,9 @@ __device__ __forceinline__ WideNode wide_node_load(const float4* __restrict__ N)
 // 26 -> 20 instructions per child, 16 of the 24 that remain half-rate are the six byte conversions and the two three-operand min / max.
 // Same verdicts for every finite operand: max(entry, tmin) <= min(exit, tfar)  <=>  entry <= exit, entry <= tfar, tmin <= exit (tmin <=
 // tfar holds for a live ray); a NaN difference (inf - inf) reads as "hit", which only costs a visit.  The hit rule never looks at boxes.
+// ORDER: 0 = front to back along the ray's octant (closest hit needs it: best_t prunes what lies behind), 1 = slot order (no permutation),
+// 2 = back to front.  An occlusion query's answer does not depend on the visiting order: see kAnyOrder.
+template <int ORDER = 0>
 __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay& r, float tmin, float tfar, WideCursor& c)
 {
     const float4   h0 = n.h0, h1 = n.h1, q2 = n.q2, q3 = n.q3, q4 = n.q4;
@@ -138,12 +141,16 @@ __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay&
     // an unused slot is told by the masks, not by its planes (no plane content fails the conservative test reliably)
     // the hit inner children in visiting priority: bit i <- bit i ^ octinv (octinv's bits are the negated signs: swap where the sign is +)
     uint32_t m = h8 & imask;
-    uint32_t a = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
-    m          = CAP_W8_SEL(mx, m, a);
-    a          = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
-    m          = CAP_W8_SEL(my, m, a);
-    a          = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
-    m          = CAP_W8_SEL(mz, m, a);
+    if (ORDER != 1)
+    {
+        // (back to front: the complementary octant, i.e. the swaps where the sign is NEGATIVE)
+        uint32_t a = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+        m          = ORDER == 0 ? CAP_W8_SEL(mx, m, a) : CAP_W8_SEL(mx, a, m);
+        a          = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+        m          = ORDER == 0 ? CAP_W8_SEL(my, m, a) : CAP_W8_SEL(my, a, m);
+        a          = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+        m          = ORDER == 0 ? CAP_W8_SEL(mz, m, a) : CAP_W8_SEL(mz, a, m);
+    }
 #undef CAP_W8_SEL
     c.g_base  = f2u(h1.x);
     c.g_mask  = (m << 24) | imask;
@@ -159,6 +166,7 @@ __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay&
 #define CAP_W8_TN_ARG
 #define CAP_W8_TN_OUT(slot, tn)
 #endif
+template <int ORDER = 0>  // (the round-2 form always orders front to back)
 __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay& r, float tmin, float tfar, WideCursor& c CAP_W8_TN_ARG)
 {
     const float4   h0 = n.h0, h1 = n.h1, q2 = n.q2, q3 = n.q3, q4 = n.q4;
@@ -242,6 +250,22 @@ __device__ __forceinline__ uint2* wide_spill_of_thread(const BvhDev& bvh)
     return reinterpret_cast<uint2*>(bvh.stack_spill + (size_t)(blockIdx.x * kBlock + threadIdx.x) * kSpillEntries);
 }
 
+// Any-hit queries visit the hit children BACK TO FRONT (round 6, docs/experiments.md (83)).  An occlusion query is answered by any occluder,
+// so the order is free; front to back -- what the closest-hit kernel needs -- starts with the boxes around the ray's own origin, which a
+// ray that leaves a surface enters and leaves without hitting anything, and reaches the structures that do block (whatever stands between
+// the scene and the light) last.  Measured, shadow rays of the reference model's light: 262 k hall 4.77 -> 4.03 ms per 32 spp, 4.2 M hall
+// 2.11 -> 1.90 per 8 spp, 16.8 M hall 2.63 -> 2.38.  (-DCAP_W8_ANY_ORDER=0 front to back, 1 slot order without the permutation -- for this
+// light's octant the same order as 2 and 15 instructions per node step cheaper: 3.88 / 1.84 / 2.34 --, 2 back to front.)
+#ifndef CAP_W8_ANY_ORDER
+#define CAP_W8_ANY_ORDER 2
+#endif
+#if !defined(CAP_W8_NODE_V1) && !defined(CAP_W8_COUNT)
+constexpr int kAnyOrder = CAP_W8_ANY_ORDER;
+#else
+constexpr int kAnyOrder = 0;
+#endif
+__device__ __forceinline__ uint32_t kAnyOct(uint32_t octinv) { return kAnyOrder == 0 ? octinv : (kAnyOrder == 1 ? 0u : octinv ^ 7u); }
+
 // Any hit on the wide tree (lighting.h:48-61 semantics as traverse_any): true when some triangle has tmin < t < tmax.
 // lds_words: this lane's column of a [entries][kBlock] uint32 LDS array of STACK_WORDS entries, reused as STACK_WORDS / 2 pairs.
 template <int STACK_WORDS>
@@ -269,7 +293,7 @@ __device__ __forceinline__ bool traverse_any8(const BvhDev& bvh, const Ray& r, u
         else
         {
             bool           rest;
-            const uint32_t node = wide_pick_child(c, w.octinv, rest);
+            const uint32_t node = wide_pick_child(c, kAnyOct(w.octinv), rest);
             if (rest)
             {
                 if (st.sp < kPairs)
@@ -290,7 +314,7 @@ __device__ __forceinline__ bool traverse_any8(const BvhDev& bvh, const Ray& r, u
         else
         {
             nd.q3 = src[3], nd.q4 = src[4];
-            wide_node_test(nd, w, r.tmin, r.tmax, c);
+            wide_node_test<kAnyOrder>(nd, w, r.tmin, r.tmax, c);
         }
         // nothing due: the next node group off the stack, or done
         if (c.t_hits == 0u && (c.g_mask >> 24) == 0u)

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_any8_refill(Bvh
         else if (node_lane)
         {
             bool           rest;
-            const uint32_t node = wide_pick_child(c, w.octinv, rest);
+            const uint32_t node = wide_pick_child(c, kAnyOct(w.octinv), rest);
             if (rest) st.push(c.g_base, c.g_mask);
             src = bvh.nodes8 + (kWideNodeStride / 4u) * (size_t)node;
         }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_any8_refill(Bvh
         if (node_lane) nd.q3 = src[3], nd.q4 = src[4];  // (a triangle lane needs 48 of its record's 64 bytes: no id for an occlusion test)
         bool occluded = false;
         if (tri_lane) occluded = tri_occludes(r, nd.h0, nd.h1, nd.q2);
-        if (node_lane) wide_node_test(nd, w, r.tmin, r.tmax, c);
+        if (node_lane) wide_node_test<kAnyOrder>(nd, w, r.tmin, r.tmax, c);
         if (occluded)
             alive = false;  // lighting.h:57: an occluded ray adds nothing
         else if (alive && c.t_hits == 0u && (c.g_mask >> 24) == 0u)
