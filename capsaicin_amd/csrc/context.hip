@@ -686,6 +686,7 @@ int cap_scene_upload(CapContext* c, const float* positions, const float* normals
     c->meshes_host.assign(meshes, meshes + mesh_count);
     c->materials_ready = false;  // per-mesh materials belong to the previous scene
     c->light_count     = 0;
+    c->light_tris_host.clear();  // (and with them the next-event pair list: rebuilt by the next cap_materials_upload)
     c->vertex_count = vertex_count, c->index_count = index_count, c->mesh_count = mesh_count, c->tri_count = (uint32_t)tri_ids.size();
     c->scene_ready = true;
     c->bvh_ready   = false;
@@ -777,7 +778,7 @@ static int update_nee_pairs(CapContext* c)
     c->fan_pair_nee_count = c->fan_pair_count;
     c->fan_pairs_nee.release();
     const uint32_t np = c->fan_pair_count;
-    if (!np || c->light_tris_host.empty() || c->fan_pairs_host.size() < 20 * (size_t)np || c->sw.on(SW_NO_NEE_PAIR_CULL)) return CAP_OK;
+    if (!np || !c->materials_ready || c->light_tris_host.empty() || c->fan_pairs_host.size() < 20 * (size_t)np || c->sw.on(SW_NO_NEE_PAIR_CULL)) return CAP_OK;
     const size_t nv = c->positions_host.size() / 3;
     if (!nv) return CAP_OK;
     auto P = [&](size_t i, int k) { return (double)c->positions_host[3 * i + k]; };
