@@ -505,15 +505,88 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_primar
 // records through the scalar cache; a child is entered when any lane's ray hits its box (each lane prunes with its own
 // closest hit so far), nearer child first by majority.  Per-lane traversal is bound by the texture-address unit here -- seven
 // 16-B loads per lane and step, 64 lanes, all to the same address: ~112 TA cycles per step and wave -- while this form issues no
-// vector loads at all (262 k-triangle scene: 3.7 -> 2.4 ms; it is then bound by the latency of the dependent scalar fetches,
-// hence eight workgroups per CU.  The same walk on the wide view of the tree, four boxes per step ordered by the packet's
+// vector loads at all (262 k-triangle scene: 3.7 -> 2.4 ms; what then bounds it is instruction issue -- ~3 900 vector and ~1 800
+// scalar instructions per packet, docs/experiments.md (85) -- not, as assumed until round 6, the chain of scalar fetches).  The same walk on the wide view of the tree, four boxes per step ordered by the packet's
 // first live lane, was slower: 3.2 ms, the scalar sorting costs more than the halved fetch chain saves).
 // The hit rule is visit-order independent (minimum t, ties to the lower id), so the result is bit-identical.
 // wstack: this wave's kPacketStack entries (the tree depth is checked on the host against the same 64).
 constexpr uint32_t kPacketStack = 64;
-__device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const Ray& r, bool alive, uint32_t* wstack, float& best_t,
+// One box of a packet step, written for what the step is bound by -- vector ISSUE (round 6: 3 880 vector instructions per packet at
+// ~3 cycles each fill the SIMD's time; docs/experiments.md (85)).  The values are slab()'s: (lo - o) * inv <= (hi - o) * inv for
+// inv > 0 and the other way round for inv < 0 (rounding is monotonic), so min / max of the two products IS the product picked by
+// the sign of inv -- a full-rate v_bitop3 select with the ray's sign word instead of a half-rate min / max.  Where slab()'s
+// min / max drop a NaN (0 * inf) the select keeps it, and the fmaxf / fminf behind it drop it: only wider.
+__device__ __forceinline__ float packet_sel(uint32_t m, float a, float b) { return u2f(__builtin_amdgcn_bitop3_b32(m, f2u(a), f2u(b), 0xca)); }
+// v_max3 / v_min3 / v_max / v_min as the hardware has them.  Through fmaxf / fminf the compiler first canonicalises every operand it
+// cannot prove quiet (four of the selected words per box, 4 cycles each): a signalling NaN would pass through v_max instead of being
+// dropped.  None can occur here -- every operand is the result of an arithmetic instruction (NaNs from 0 * inf are quiet), a select
+// between two such results, or a constant -- so the hardware forms drop NaNs exactly as fmaxf / fminf do.
+__device__ __forceinline__ float packet_max3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float packet_min3(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float packet_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float packet_min(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// entry distance and (widened) exit distance of one box: the box is hit when tn <= tf
+#if defined(CAP_PACKET_SUB)
+__device__ __forceinline__ void packet_slab(const Ray& r, v3, uint32_t mx, uint32_t my, uint32_t mz, float lox, float loy, float loz, float hix,
+                                            float hiy, float hiz, float tfar, float& tn, float& tf)
+{
+    const float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
+    const float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
+    const float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
+#else
+// Plane distances as ONE fused operation each, t = fma(plane, inv, -(o * inv)), instead of slab()'s subtraction and product (12 of a
+// step's 49 vector instructions).  In space the crossing moves by at most u |o| (the rounding of o * inv) + u |plane - o| (the fma's),
+// u = 2^-24, against slab()'s 2 u |plane - o|: both sit two orders of magnitude inside the boxes' padding of 1e-5 max(1, |coordinate|)
+// for a camera within ~80 scene sizes of the scene (intersection contract), and the hit rule never looks at boxes.
+// With inv = +-inf (a zero direction component) the fma can give inf - inf = NaN where slab() gave +-inf; the max / min drop it:
+// the axis is ignored, which is wider.
+__device__ __forceinline__ void packet_slab(const Ray& r, v3 noi, uint32_t mx, uint32_t my, uint32_t mz, float lox, float loy, float loz, float hix,
+                                            float hiy, float hiz, float tfar, float& tn, float& tf)
+{
+    const float ax = fmaf(lox, r.inv.x, noi.x), bx = fmaf(hix, r.inv.x, noi.x);
+    const float ay = fmaf(loy, r.inv.y, noi.y), by = fmaf(hiy, r.inv.y, noi.y);
+    const float az = fmaf(loz, r.inv.z, noi.z), bz = fmaf(hiz, r.inv.z, noi.z);
+#endif
+    tn = packet_max(packet_max3(packet_sel(mx, bx, ax), packet_sel(my, by, ay), packet_sel(mz, bz, az)), r.tmin);
+    tf = packet_min(packet_min3(packet_sel(mx, ax, bx), packet_sel(my, ay, by), packet_sel(mz, az, bz)), tfar) * 1.0000004f;
+}
+
+__device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const Ray& r_in, bool alive, uint32_t* wstack, float& best_t,
                                                         float& best_u, float& best_v, uint32_t& best_gid)
 {
+    // The camera position is wave-uniform and the compiler keeps it in scalar registers -- next to the node's words, which arrive
+    // in scalar registers too, and a vector instruction reads at most one: six moves per step.  Kept in vector registers instead.
+    Ray r = r_in;
+#if !defined(CAP_PACKET_V1)
+#if defined(CAP_PACKET_SUB)
+    asm volatile("" : "+v"(r.o.x), "+v"(r.o.y), "+v"(r.o.z));
+    const v3 noi = mk3(0.f, 0.f, 0.f);
+#else
+    const v3 noi = mk3(-(r.o.x * r.inv.x), -(r.o.y * r.inv.y), -(r.o.z * r.inv.z));
+#endif
+    const uint32_t mx = (uint32_t)((int)f2u(r.inv.x) >> 31), my = (uint32_t)((int)f2u(r.inv.y) >> 31), mz = (uint32_t)((int)f2u(r.inv.z) >> 31);
+    const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
+#endif
     best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
     int      node = bvh.root;
     uint32_t sp   = 0;
@@ -526,9 +599,18 @@ __device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const
             float4 q0, q1, q2, q3;
             load_const_tri(bvh.nodes, (uint32_t)node, q0, q1, q2, q3);
             float      tn0, tn1;
+#if defined(CAP_PACKET_V1)
             const bool h0 = alive && slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tn0);
             const bool h1 = alive && slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tn1);
+#else
+            // (no short-circuit: a lane without a pixel computes on its dummy ray; the branches around the tests cost scalar issue
+            // slots and kept the two boxes from being scheduled together)
+            float tf0, tf1;
+            packet_slab(r, noi, mx, my, mz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tn0, tf0);
+            packet_slab(r, noi, mx, my, mz, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tn1, tf1);
+#endif
             const int  c0 = (int)f2u(q3.z), c1 = (int)f2u(q3.w);
+#if defined(CAP_PACKET_V1)
             const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
             if (m0 != 0ull && m1 != 0ull)
             {
@@ -544,6 +626,22 @@ __device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const
                 node = m0 ? c0 : c1;
                 pop  = false;
             }
+#else
+            // Lanes that hit both vote for the nearer child, the others for the one they hit; the majority's child is entered first.
+            // One rule for all three cases: only child 1 hit -> every voter says 1, only child 0 -> nobody does.
+            // (the compares' lane masks, AND-ed with the mask of lanes that have a pixel: the ballot of a computed bool costs two
+            // half-rate vector instructions, the ballot of a compare none)
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(tn0 <= tf0) & alive_mask, m1 = __builtin_amdgcn_ballot_w64(tn1 <= tf1) & alive_mask;
+            const unsigned long long first1 = m1 & (~m0 | __builtin_amdgcn_ballot_w64(tn1 < tn0));
+            const bool               swap   = 2 * __popcll(first1) > __popcll(m0 | m1);
+            if ((m0 | m1) != 0ull)
+            {
+                // (no depth guard: the host refuses trees deeper than kPacketStack for this walk; the index is masked for safety)
+                if (m0 != 0ull && m1 != 0ull) wstack[(sp++) & (kPacketStack - 1u)] = (uint32_t)(swap ? c0 : c1);
+                node = swap ? c1 : c0;
+                pop  = false;
+            }
+#endif
         }
         else
         {
@@ -553,7 +651,11 @@ __device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const
                 float4 t0, t1, t2, t3;
                 load_const_tri(bvh.tris, leaf, t0, t1, t2, t3);
                 float t, u, v;
+#if defined(CAP_PACKET_V1)
                 if (alive && tri_test(r, t0, t1, t2, t, u, v))
+#else
+                if (tri_test(r, t0, t1, t2, t, u, v))  // (a lane without a pixel walks its dummy ray: its result is dropped by the caller)
+#endif
                 {
                     const uint32_t gid = f2u(t3.x);
                     if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
@@ -566,6 +668,9 @@ __device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const
             node = (int)wstack[--sp];
         }
     }
+#if !defined(CAP_PACKET_V1)
+    if (!alive) best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
+#endif
 }
 
 template <int DUMMY>
@@ -1159,7 +1264,7 @@ void launch_trace_primary(const LaunchCfg& cfg, const BvhDev& bvh, const CameraD
     const bool no_packet = cfg.sw_on(SW_NO_PACKET);  // A/B switch
     if (cfg.stack_entries != 0 && work && bvh.tri_count >= 2 && !no_packet)
     {
-        // latency-bound on the dependent scalar node fetches and light on registers: as many waves as fit
+        // issue-bound and light on registers: as many waves as fit
         uint32_t gx = (chunks * n_slots + 3) / 4;
         const uint32_t cap = cfg.cu_count ? resident_grid<k_trace_primary_packet<0>>(cfg, ~0u) : cfg.grid_blocks;
         if (gx > cap) gx = cap;
