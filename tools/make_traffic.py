@@ -19,6 +19,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 # key -> (workload whose passes are read, kernel name)
 KERNELS = {"headline": ("cornell", "k_trace_shade<false, false, false, true>"), "ext": ("ext", "k_trace_shade<false, true, false, true>"),
            "tree": ("tree", "k_trace_closest8"), "tree_shade": ("tree", "k_shade<"), "tree_any": ("tree", "k_trace_any<"),
+           "tree_primary": ("tree", "k_primary_shade"),
            "big": ("big", "k_trace_closest8"), "big_shade": ("big", "k_shade<"), "big_any": ("big", "k_trace_any"),
            "config3": ("config3", "k_trace_shade<false, true, false, true>"), "config5": ("config5", "k_trace_shade<false, true, false, true>")}
 # every kernel of a render step (tree path): bench.py big_variant.step_traffic = the FRAME's measured bytes, not one kernel's
@@ -76,7 +77,7 @@ def static_issue_costs():
         for src, keys in (("trace8.hip", {"k_trace_closest8": "k_trace_closest8"}),
                           ("kernels.hip", {"k_trace_shade<false, false, false, true>": "k_trace_shadeILb0ELb0ELb0ELb1E",
                                            "k_trace_shade<false, true, false, true>": "k_trace_shadeILb0ELb1ELb0ELb1E", "k_shade<": "k_shadeILb0E",
-                                           "k_trace_any<": "k_trace_anyILi24E"})):
+                                           "k_trace_any<": "k_trace_anyILi24E", "k_primary_shade": "k_primary_shadeILb0E"})):
             lst = os.path.join(tmp, src + ".s")
             try:
                 subprocess.run(["/opt/rocm/bin/hipcc"] + flags + [os.path.join(csrc, src), "-o", lst], check=True, capture_output=True, timeout=900)
@@ -129,6 +130,12 @@ for key, (wl, name) in KERNELS.items():
             vs, _, ns3 = total_timed("prof_%s_pmc_SQ_WAVES*" % wl, "SQ_INSTS_VALU", name)
             k["valu_busy"]["static_issue_cycles_per_inst"] = cyc
             k["valu_busy"]["issue_cycles_frac"] = vs * cyc / (ns3 * clock_ghz * 1024.0)
+            # the scalar unit's share: one per CU, it serves the four SIMDs in turn -- tools/micro/wave_chase.hip measures ~3.4-3.9
+            # cycles per scalar instruction and SIMD (profiles/r06_micro/wave_chase.txt, docs/experiments.md (85)); priced at 3.6
+            ss, ns_, _ = total_timed("prof_%s_pmc_SQ_WAVES*" % wl, "SQ_INSTS_SALU", name)
+            if ns_:
+                k["valu_busy"]["salu_insts_per_launch"] = ss / ns_
+                k["valu_busy"]["scalar_issue_cycles_frac"] = ss * 3.6 / (ns3 * clock_ghz * 1024.0)
     out["kernels"][key] = k
 for wl in ("big", "tree"):
     fetch = sum(total("prof_%s_pmc_FETCH_SIZE" % wl, "FETCH_SIZE", k)[0] for k in STEP_KERNELS)
