@@ -304,7 +304,7 @@ def tree_rooflines(tp, key, scene_note, dense=False):
     """The tree path's two priced kernels from one stage-timed render: k_trace_closest8 -- (A) queue bytes, 32-B ray read + 16-B hit
     written, and (A + B) with the nodes and triangle records a ray requests (instrumented build, tools/w8_counts.py,
     committed with the counter passes) -- and k_shade (144 B per shaded vertex; escapes priced separately).
-    dense: the scene has >= 1 triangle per pixel, so the camera rays went through k_trace_closest8 as well (context.hip primary_wide):
+    dense: the scene has >= 2 triangles per pixel, so the camera rays went through k_trace_closest8 as well (context.hip primary_wide):
     one more launch per batch, timed under the primary stage together with the 0.1 ms of k_raygen_identity that feeds it; its rays,
     launches and time are part of the kernel's totals here, as they are of the counter passes' per-dispatch averages."""
     pmc, _ = committed_counters(key)
@@ -393,7 +393,7 @@ def big_variant(dev, stream):
     troof, sroof = tree_rooflines(bp, "big", "16.8 M triangles: the wide nodes and intersection records no longer fit the Infinity Cache, so "
                                   "`traffic` (measured HBM bytes) approaches the (A + B) bytes a ray requests; frac = (A) alone, "
                                   "frac_with_traversal_bytes = (A + B) against the 8 TB/s peak, traffic_frac = measured bytes against it",
-                                  dense=n_tri_per_pixel >= 1.0)
+                                  dense=n_tri_per_pixel >= 2.0)
     r.close()
     rays = bs.rays_primary + bs.rays_extension + bs.rays_shadow
     n = int(bi.triangle_count)

@@ -83,8 +83,9 @@ struct DevBuf
     }
 };
 
-// camera rays take the per-lane wide kernel instead of the packet walk from this many triangles per pixel on (measured: cap_render)
-constexpr double kPrimaryWideTrianglesPerPixel = 1.0;
+// camera rays take the per-lane wide kernel instead of the packet walk from this many triangles per pixel on (measured: cap_render;
+// 1.0 until the walk's node step was rewritten in round 6 -- at 1.0 the walk now wins by 6 % of the step, at 2.0 the two are level)
+constexpr double kPrimaryWideTrianglesPerPixel = 2.0;
 // shadow rays take the lane-refill kernel from this many bytes of wide nodes + intersection records on (measured: cap_render)
 constexpr uint64_t kAnyRefillTreeBytes = 512ull << 20;
 // AUTO builds with surface-area splits (ploc.hip, sah_device) from this many triangles on, the clustering alone below (see cap_bvh_build)

@@ -545,48 +545,47 @@ __device__ __forceinline__ float packet_min(float a, float b)
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// entry distance and (widened) exit distance of one box: the box is hit when tn <= tf
-#if defined(CAP_PACKET_SUB)
-__device__ __forceinline__ void packet_slab(const Ray& r, v3, uint32_t mx, uint32_t my, uint32_t mz, float lox, float loy, float loz, float hix,
-                                            float hiy, float hiz, float tfar, float& tn, float& tf)
-{
-    const float ax = (lox - r.o.x) * r.inv.x, bx = (hix - r.o.x) * r.inv.x;
-    const float ay = (loy - r.o.y) * r.inv.y, by = (hiy - r.o.y) * r.inv.y;
-    const float az = (loz - r.o.z) * r.inv.z, bz = (hiz - r.o.z) * r.inv.z;
-#else
+// Entry distance and (widened) exit distance of one box: the box is hit when tn <= tf.
 // Plane distances as ONE fused operation each, t = fma(plane, inv, -(o * inv)), instead of slab()'s subtraction and product (12 of a
-// step's 49 vector instructions).  In space the crossing moves by at most u |o| (the rounding of o * inv) + u |plane - o| (the fma's),
+// step's vector instructions).  In space the crossing moves by at most u |o| (the rounding of o * inv) + u |plane - o| (the fma's),
 // u = 2^-24, against slab()'s 2 u |plane - o|: both sit two orders of magnitude inside the boxes' padding of 1e-5 max(1, |coordinate|)
 // for a camera within ~80 scene sizes of the scene (intersection contract), and the hit rule never looks at boxes.
 // With inv = +-inf (a zero direction component) the fma can give inf - inf = NaN where slab() gave +-inf; the max / min drop it:
 // the axis is ignored, which is wider.
-__device__ __forceinline__ void packet_slab(const Ray& r, v3 noi, uint32_t mx, uint32_t my, uint32_t mz, float lox, float loy, float loz, float hix,
-                                            float hiy, float hiz, float tfar, float& tn, float& tf)
+// OCT 0 .. 7: the packet's 64 rays agree in the signs of their direction (all but the tiles a zero of a component runs through) and
+// OCT holds them (bit 0: 1 / d.x negative, bit 1: y, bit 2: z): which plane is the near one is then known when the code is compiled,
+// and the walk exists once per octant -- no select at all, vector or scalar (a scalar select per plane, 12 more scalar instructions
+// per step, would only move the work to the unit that is second-busiest; (85)).  OCT 8: mixed signs, per-lane selects.
+struct PacketSigns
 {
-    const float ax = fmaf(lox, r.inv.x, noi.x), bx = fmaf(hix, r.inv.x, noi.x);
-    const float ay = fmaf(loy, r.inv.y, noi.y), by = fmaf(hiy, r.inv.y, noi.y);
-    const float az = fmaf(loz, r.inv.z, noi.z), bz = fmaf(hiz, r.inv.z, noi.z);
-#endif
-    tn = packet_max(packet_max3(packet_sel(mx, bx, ax), packet_sel(my, by, ay), packet_sel(mz, bz, az)), r.tmin);
-    tf = packet_min(packet_min3(packet_sel(mx, ax, bx), packet_sel(my, ay, by), packet_sel(mz, az, bz)), tfar) * 1.0000004f;
+    uint32_t mx, my, mz;  // per lane: all ones where 1 / d is negative
+};
+template <int OCT>
+__device__ __forceinline__ void packet_slab(const Ray& r, v3 noi, const PacketSigns& g, float lox, float loy, float loz, float hix, float hiy,
+                                            float hiz, float tfar, float& tn, float& tf)
+{
+    if constexpr (OCT < 8)
+    {
+        const float nx = (OCT & 1) ? hix : lox, ny = (OCT & 2) ? hiy : loy, nz = (OCT & 4) ? hiz : loz;
+        const float fx = (OCT & 1) ? lox : hix, fy = (OCT & 2) ? loy : hiy, fz = (OCT & 4) ? loz : hiz;
+        tn = packet_max(packet_max3(fmaf(nx, r.inv.x, noi.x), fmaf(ny, r.inv.y, noi.y), fmaf(nz, r.inv.z, noi.z)), r.tmin);
+        tf = packet_min(packet_min3(fmaf(fx, r.inv.x, noi.x), fmaf(fy, r.inv.y, noi.y), fmaf(fz, r.inv.z, noi.z)), tfar) * 1.0000004f;
+    }
+    else
+    {
+        const float ax = fmaf(lox, r.inv.x, noi.x), bx = fmaf(hix, r.inv.x, noi.x);
+        const float ay = fmaf(loy, r.inv.y, noi.y), by = fmaf(hiy, r.inv.y, noi.y);
+        const float az = fmaf(loz, r.inv.z, noi.z), bz = fmaf(hiz, r.inv.z, noi.z);
+        tn = packet_max(packet_max3(packet_sel(g.mx, bx, ax), packet_sel(g.my, by, ay), packet_sel(g.mz, bz, az)), r.tmin);
+        tf = packet_min(packet_min3(packet_sel(g.mx, ax, bx), packet_sel(g.my, ay, by), packet_sel(g.mz, az, bz)), tfar) * 1.0000004f;
+    }
 }
 
-__device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const Ray& r_in, bool alive, uint32_t* wstack, float& best_t,
+#if defined(CAP_PACKET_V1)
+// the round-2 form of the walk, kept for A/B runs (tools/build_variant.sh packetv1 -DCAP_PACKET_V1)
+__device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const Ray& r, bool alive, uint32_t* wstack, float& best_t,
                                                         float& best_u, float& best_v, uint32_t& best_gid)
 {
-    // The camera position is wave-uniform and the compiler keeps it in scalar registers -- next to the node's words, which arrive
-    // in scalar registers too, and a vector instruction reads at most one: six moves per step.  Kept in vector registers instead.
-    Ray r = r_in;
-#if !defined(CAP_PACKET_V1)
-#if defined(CAP_PACKET_SUB)
-    asm volatile("" : "+v"(r.o.x), "+v"(r.o.y), "+v"(r.o.z));
-    const v3 noi = mk3(0.f, 0.f, 0.f);
-#else
-    const v3 noi = mk3(-(r.o.x * r.inv.x), -(r.o.y * r.inv.y), -(r.o.z * r.inv.z));
-#endif
-    const uint32_t mx = (uint32_t)((int)f2u(r.inv.x) >> 31), my = (uint32_t)((int)f2u(r.inv.y) >> 31), mz = (uint32_t)((int)f2u(r.inv.z) >> 31);
-    const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
-#endif
     best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
     int      node = bvh.root;
     uint32_t sp   = 0;
@@ -599,18 +598,9 @@ __device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const
             float4 q0, q1, q2, q3;
             load_const_tri(bvh.nodes, (uint32_t)node, q0, q1, q2, q3);
             float      tn0, tn1;
-#if defined(CAP_PACKET_V1)
             const bool h0 = alive && slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tn0);
             const bool h1 = alive && slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tn1);
-#else
-            // (no short-circuit: a lane without a pixel computes on its dummy ray; the branches around the tests cost scalar issue
-            // slots and kept the two boxes from being scheduled together)
-            float tf0, tf1;
-            packet_slab(r, noi, mx, my, mz, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tn0, tf0);
-            packet_slab(r, noi, mx, my, mz, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tn1, tf1);
-#endif
             const int  c0 = (int)f2u(q3.z), c1 = (int)f2u(q3.w);
-#if defined(CAP_PACKET_V1)
             const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
             if (m0 != 0ull && m1 != 0ull)
             {
@@ -626,7 +616,50 @@ __device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const
                 node = m0 ? c0 : c1;
                 pop  = false;
             }
+        }
+        else
+        {
+            const uint32_t code = (uint32_t)~node, first = code & kLeafFirstMask, last = first + (code >> kLeafCountShift);
+            for (uint32_t leaf = first; leaf <= last; ++leaf)
+            {
+                float4 t0, t1, t2, t3;
+                load_const_tri(bvh.tris, leaf, t0, t1, t2, t3);
+                float t, u, v;
+                if (alive && tri_test(r, t0, t1, t2, t, u, v))
+                {
+                    const uint32_t gid = f2u(t3.x);
+                    if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
+                }
+            }
+        }
+        if (pop)
+        {
+            if (sp == 0) break;
+            node = (int)wstack[--sp];
+        }
+    }
+}
 #else
+template <int OCT>
+__device__ __forceinline__ void packet_walk(const BvhDev& bvh, const Ray& r, v3 noi, const PacketSigns& g, unsigned long long alive_mask,
+                                            uint32_t* wstack, float& best_t, float& best_u, float& best_v, uint32_t& best_gid)
+{
+    int      node = bvh.root;
+    uint32_t sp   = 0;
+    while (true)
+    {
+        node = __builtin_amdgcn_readfirstlane(node);
+        bool pop = true;
+        if (node >= 0)
+        {
+            float4 q0, q1, q2, q3;
+            load_const_tri(bvh.nodes, (uint32_t)node, q0, q1, q2, q3);
+            // (no `alive &&` around the tests: a lane without a pixel computes on its dummy ray; the branches cost scalar issue slots
+            // and kept the two boxes from being scheduled together)
+            float tn0, tn1, tf0, tf1;
+            packet_slab<OCT>(r, noi, g, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, best_t, tn0, tf0);
+            packet_slab<OCT>(r, noi, g, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, best_t, tn1, tf1);
+            const int c0 = (int)f2u(q3.z), c1 = (int)f2u(q3.w);
             // Lanes that hit both vote for the nearer child, the others for the one they hit; the majority's child is entered first.
             // One rule for all three cases: only child 1 hit -> every voter says 1, only child 0 -> nobody does.
             // (the compares' lane masks, AND-ed with the mask of lanes that have a pixel: the ballot of a computed bool costs two
@@ -641,7 +674,6 @@ __device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const
                 node = swap ? c1 : c0;
                 pop  = false;
             }
-#endif
         }
         else
         {
@@ -651,11 +683,7 @@ __device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const
                 float4 t0, t1, t2, t3;
                 load_const_tri(bvh.tris, leaf, t0, t1, t2, t3);
                 float t, u, v;
-#if defined(CAP_PACKET_V1)
-                if (alive && tri_test(r, t0, t1, t2, t, u, v))
-#else
-                if (tri_test(r, t0, t1, t2, t, u, v))  // (a lane without a pixel walks its dummy ray: its result is dropped by the caller)
-#endif
+                if (tri_test(r, t0, t1, t2, t, u, v))  // (a lane without a pixel walks its dummy ray: its result is dropped below)
                 {
                     const uint32_t gid = f2u(t3.x);
                     if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
@@ -668,10 +696,31 @@ __device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const
             node = (int)wstack[--sp];
         }
     }
-#if !defined(CAP_PACKET_V1)
-    if (!alive) best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
-#endif
 }
+
+__device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const Ray& r, bool alive, uint32_t* wstack, float& best_t,
+                                                        float& best_u, float& best_v, uint32_t& best_gid)
+{
+    const v3 noi = mk3(-(r.o.x * r.inv.x), -(r.o.y * r.inv.y), -(r.o.z * r.inv.z));
+    PacketSigns g;
+    g.mx = (uint32_t)((int)f2u(r.inv.x) >> 31), g.my = (uint32_t)((int)f2u(r.inv.y) >> 31), g.mz = (uint32_t)((int)f2u(r.inv.z) >> 31);
+    const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(alive);
+    const unsigned long long bx = __builtin_amdgcn_ballot_w64(g.mx != 0u), by = __builtin_amdgcn_ballot_w64(g.my != 0u),
+                             bz = __builtin_amdgcn_ballot_w64(g.mz != 0u);
+    // every lane of the wave is active here (the chunk loop is wave-uniform), so "all 64 agree" is a ballot of 0 or of all ones
+    const bool     uniform = alive_mask == ~0ull && (bx == 0ull || bx == ~0ull) && (by == 0ull || by == ~0ull) && (bz == 0ull || bz == ~0ull);
+    const uint32_t oct     = uniform ? ((bx != 0ull ? 1u : 0u) | (by != 0ull ? 2u : 0u) | (bz != 0ull ? 4u : 0u)) : 8u;
+    best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
+    switch (oct)
+    {
+#define CAP_PACKET_CASE(K) case K: packet_walk<K>(bvh, r, noi, g, alive_mask, wstack, best_t, best_u, best_v, best_gid); break;
+        CAP_PACKET_CASE(0) CAP_PACKET_CASE(1) CAP_PACKET_CASE(2) CAP_PACKET_CASE(3) CAP_PACKET_CASE(4) CAP_PACKET_CASE(5) CAP_PACKET_CASE(6) CAP_PACKET_CASE(7)
+#undef CAP_PACKET_CASE
+        default: packet_walk<8>(bvh, r, noi, g, alive_mask, wstack, best_t, best_u, best_v, best_gid); break;
+    }
+    if (!alive) best_t = r.tmax, best_u = 0.0f, best_v = 0.0f, best_gid = kInvalidId;
+}
+#endif
 
 template <int DUMMY>
 __global__ __launch_bounds__(kBlock, 8) void k_trace_primary_packet(BvhDev bvh, CameraDev cam, ScreenDev screen, const FrameConst* frames,
