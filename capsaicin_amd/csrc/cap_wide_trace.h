@@ -101,7 +101,10 @@ __device__ __forceinline__ WideNode wide_node_load(const float4* __restrict__ N)
 // tfar holds for a live ray); a NaN difference (inf - inf) reads as "hit", which only costs a visit.  The hit rule never looks at boxes.
 // ORDER: 0 = front to back along the ray's octant (closest hit needs it: best_t prunes what lies behind), 1 = slot order (no permutation),
 // 2 = back to front.  An occlusion query's answer does not depend on the visiting order: see kAnyOrder.
-template <int ORDER = 0>
+// OCT: -1 = the signs of the ray's direction are per-lane data; 0 .. 7 = every ray of the launch has these (bit 0: d.x negative, bit 1: y,
+// bit 2: z -- the reference model's shadow rays all point at one directional light): near / far words and the visiting permutation are
+// then compile-time choices, 12 selects, three sign words and up to three conditional swaps per node step fewer.
+template <int ORDER = 0, int OCT = -1>
 __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay& r, float tmin, float tfar, WideCursor& c)
 {
     const float4   h0 = n.h0, h1 = n.h1, q2 = n.q2, q3 = n.q3, q4 = n.q4;
@@ -109,10 +112,13 @@ __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay&
     const float    ax = h0.w * r.inv.x, ay = u2f(syz & 0xffff0000u) * r.inv.y, az = u2f(syz << 16) * r.inv.z;
     const float    bx = fmaf(h0.x, r.inv.x, r.noi.x), by = fmaf(h0.y, r.inv.y, r.noi.y), bz = fmaf(h0.z, r.inv.z, r.noi.z);
     // all ones where the direction component is negative (1 / d is never +-0: |d| <= 1): such a ray enters through the high plane
-    const uint32_t mx = (uint32_t)((int32_t)f2u(r.inv.x) >> 31), my = (uint32_t)((int32_t)f2u(r.inv.y) >> 31), mz = (uint32_t)((int32_t)f2u(r.inv.z) >> 31);
+    const uint32_t mx = OCT >= 0 ? ((OCT & 1) ? ~0u : 0u) : (uint32_t)((int32_t)f2u(r.inv.x) >> 31),
+                   my = OCT >= 0 ? ((OCT & 2) ? ~0u : 0u) : (uint32_t)((int32_t)f2u(r.inv.y) >> 31),
+                   mz = OCT >= 0 ? ((OCT & 4) ? ~0u : 0u) : (uint32_t)((int32_t)f2u(r.inv.z) >> 31);
     const uint32_t lx0 = f2u(q2.x), lx1 = f2u(q2.y), ly0 = f2u(q2.z), ly1 = f2u(q2.w), lz0 = f2u(q3.x), lz1 = f2u(q3.y);
     const uint32_t hx0 = f2u(q3.z), hx1 = f2u(q3.w), hy0 = f2u(q4.x), hy1 = f2u(q4.y), hz0 = f2u(q4.z), hz1 = f2u(q4.w);
-#define CAP_W8_SEL(m, a, b) __builtin_amdgcn_bitop3_b32((m), (a), (b), 0xca) /* m ? a : b, bit by bit: truth-table index = m * 4 + a * 2 + b */
+    /* m ? a : b, bit by bit: truth-table index = m * 4 + a * 2 + b (a constant mask folds to a or b) */
+#define CAP_W8_SEL(m, a, b) (OCT >= 0 ? ((m) ? (a) : (b)) : __builtin_amdgcn_bitop3_b32((m), (a), (b), 0xca))
     const uint32_t nx0 = CAP_W8_SEL(mx, hx0, lx0), nx1 = CAP_W8_SEL(mx, hx1, lx1), fx0 = CAP_W8_SEL(mx, lx0, hx0), fx1 = CAP_W8_SEL(mx, lx1, hx1);
     const uint32_t ny0 = CAP_W8_SEL(my, hy0, ly0), ny1 = CAP_W8_SEL(my, hy1, ly1), fy0 = CAP_W8_SEL(my, ly0, hy0), fy1 = CAP_W8_SEL(my, ly1, hy1);
     const uint32_t nz0 = CAP_W8_SEL(mz, hz0, lz0), nz1 = CAP_W8_SEL(mz, hz1, lz1), fz0 = CAP_W8_SEL(mz, lz0, hz0), fz1 = CAP_W8_SEL(mz, lz1, hz1);
@@ -268,7 +274,8 @@ __device__ __forceinline__ uint32_t kAnyOct(uint32_t octinv) { return kAnyOrder 
 
 // Any hit on the wide tree (lighting.h:48-61 semantics as traverse_any): true when some triangle has tmin < t < tmax.
 // lds_words: this lane's column of a [entries][kBlock] uint32 LDS array of STACK_WORDS entries, reused as STACK_WORDS / 2 pairs.
-template <int STACK_WORDS>
+// OCT: see wide_node_test (0 .. 7: the caller has checked that every ray of the launch lies in that octant).
+template <int STACK_WORDS, int OCT = -1>
 __device__ __forceinline__ bool traverse_any8(const BvhDev& bvh, const Ray& r, uint32_t* lds_words)
 {
     // the pair (k) of this lane lives in words 2k and 2k + 1 of its column: two 4-B accesses, conflict-free like the word stack
@@ -293,7 +300,7 @@ __device__ __forceinline__ bool traverse_any8(const BvhDev& bvh, const Ray& r, u
         else
         {
             bool           rest;
-            const uint32_t node = wide_pick_child(c, kAnyOct(w.octinv), rest);
+            const uint32_t node = wide_pick_child(c, kAnyOct(OCT >= 0 ? 7u - (uint32_t)OCT : w.octinv), rest);
             if (rest)
             {
                 if (st.sp < kPairs)
@@ -314,7 +321,7 @@ __device__ __forceinline__ bool traverse_any8(const BvhDev& bvh, const Ray& r, u
         else
         {
             nd.q3 = src[3], nd.q4 = src[4];
-            wide_node_test<kAnyOrder>(nd, w, r.tmin, r.tmax, c);
+            wide_node_test<kAnyOrder, OCT>(nd, w, r.tmin, r.tmax, c);
         }
         // nothing due: the next node group off the stack, or done
         if (c.t_hits == 0u && (c.g_mask >> 24) == 0u)

@@ -856,6 +856,18 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_any(Bv
         }
         __syncthreads();
     }
+    // Reference model on the wide tree: every shadow ray of the launch points at its frame's light, and the frames of a batch differ by
+    // a jitter -- one direction octant for the whole launch unless a component of the light direction is (almost) zero.  Told here from
+    // the LDS copy of the lights (sign bits, as make_wide_ray reads them off 1 / d); the traversal then runs in the copy compiled for
+    // that octant (traverse_any8<.., OCT>: near / far planes and the visiting permutation are constants; docs/experiments.md (86)).
+    uint32_t oct = 8u;  // mixed, or not this instantiation: per-lane signs
+    if constexpr (!RMW && STACK == (int)kWideLdsEntries)
+    {
+        const float4   L  = lds_light[(threadIdx.x & 63u) < n_slots ? (threadIdx.x & 63u) : 0u];
+        const uint32_t o  = (f2u(L.x) >> 31) | ((f2u(L.y) >> 31) << 1) | ((f2u(L.z) >> 31) << 2);
+        const uint32_t o0 = __builtin_amdgcn_readfirstlane(o);
+        if (__builtin_amdgcn_ballot_w64(o != o0) == 0ull && bvh.wide8_ok && bvh.tri_count != 0u) oct = o0;  // (all 64 lanes are active here)
+    }
     // Memory round trips a chunk starts with, in order: (1) the grab issued one chunk ago (its wait also covers the previous
     // chunk's plane updates: vmcnt retires in order), (2) the queue entry.  The class's length is read once per wave (constant
     // during the launch), and the next grab is issued AFTER the entry loads, so that the wait for the entry is a counted
@@ -909,7 +921,21 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_any(Bv
             }
             const float4* row = use_ddn ? lds_pre + (good ? (pid >> kPidShift) : 0u) * pre_row : nullptr;
             if (STACK == 0) __builtin_amdgcn_s_setprio(0);
-            const bool occluded = trace_any_any_size<STACK>(bvh, r, stack, row);
+            bool occluded;
+            if constexpr (!RMW && STACK == (int)kWideLdsEntries)
+            {
+                switch (oct)  // wave-uniform
+                {
+#define CAP_ANY_OCT(K) case K: occluded = traverse_any8<STACK, K>(bvh, r, stack); break;
+                    // (the four octants the reference's light visits: it turns about the vertical axis, y stays positive -- lighting.h:20-33;
+                    // tests/test_sponza_class_gpu.py test_light_octants_parity renders a frame of each)
+                    CAP_ANY_OCT(0) CAP_ANY_OCT(1) CAP_ANY_OCT(4) CAP_ANY_OCT(5)
+#undef CAP_ANY_OCT
+                    default: occluded = trace_any_any_size<STACK>(bvh, r, stack, row); break;
+                }
+            }
+            else
+                occluded = trace_any_any_size<STACK>(bvh, r, stack, row);
             if (STACK == 0) __builtin_amdgcn_s_setprio(3);
             if (!occluded)
             {

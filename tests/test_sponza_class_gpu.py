@@ -85,6 +85,44 @@ def test_small_scale_parity(native_lib, bluenoise, tmp_path, build):
     r.close()
 
 
+@pytest.mark.parametrize("first_frame,n_frames", [(1100, 2), (2100, 2), (3100, 2), (1022, 4), (4094, 4)])
+def test_light_octants_parity(native_lib, bluenoise, tmp_path, first_frame, n_frames):
+    """The reference's light turns around the vertical axis once per 4096 frames (lighting.h:20-33), so its direction visits four
+    octants.  The shadow rays' traversal exists once per octant (kernels.hip k_trace_any: traverse_any8<.., OCT>, chosen per launch from
+    the batch's lights) plus the per-lane form for a batch that straddles a quadrant boundary: frames 1100 / 2100 / 3100 are the other
+    three quadrants (every other test renders frames < 1024), 1022 .. 1025 and 4094 .. 4097 straddle.  Accumulated image and ray counters
+    bit for bit against the oracle."""
+    from oracle import cap_oracle as O
+    geo, texs = _setup(tmp_path, 0.1, 64)
+    w, h, D = 96, 64, 3
+    r = capi.Renderer(0)
+    r.upload_geometry(geo)
+    for i, t in enumerate(texs):
+        r.upload_texture(i, t)
+    r.upload_bluenoise(bluenoise)
+    info = r.build_bvh()
+    assert info.triangle_count > 64 and r.bvh_wide_readback()[0].shape[0] > 0  # tree path, wide view present
+    cam = _camera(w, h)
+    r.set_resolution(w, h)
+    r.set_camera(cam)
+    r.render(first_frame, n_frames, D, 0)
+    got = r.readback(capi.BUF_ACCUM_SUM)
+    sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes, textures=texs)
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1], cam.focal_length)
+    acc = np.zeros((h, w, 4), np.float32)
+    rays = np.zeros(3, np.int64)
+    for f in range(first_frame, first_frame + n_frames):
+        ref = sc.render_frame(ocam, bluenoise, w, h, f, D, flags=O.FLAG_USE_BVH, threads=8)
+        acc[..., :3] = acc[..., :3] + ref["combined"][..., :3]  # the plain running fp32 sum in frame order (k_resolve)
+        acc[..., 3] += 1.0
+        rays += np.array(ref["rays"], np.int64)
+    nbad = int((bits(got) != bits(acc)).any(-1).sum())
+    assert nbad == 0, "%d pixels differ" % nbad
+    s = r.stats()
+    assert (s.rays_primary, s.rays_extension, s.rays_shadow) == tuple(int(x) for x in rays) and s.guard_trace_any == 0
+    r.close()
+
+
 def test_full_scale_properties(native_lib, bluenoise, tmp_path):
     geo, texs = _setup(tmp_path, 1.0, 128)
     ntri = geo.indices.size // 3
