@@ -172,7 +172,7 @@ __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay&
 #define CAP_W8_TN_ARG
 #define CAP_W8_TN_OUT(slot, tn)
 #endif
-template <int ORDER = 0>  // (the round-2 form always orders front to back)
+template <int ORDER = 0, int OCT = -1>  // (the round-2 form always orders front to back and reads the signs per lane)
 __device__ __forceinline__ void wide_node_test(const WideNode& n, const WideRay& r, float tmin, float tfar, WideCursor& c CAP_W8_TN_ARG)
 {
     const float4   h0 = n.h0, h1 = n.h1, q2 = n.q2, q3 = n.q3, q4 = n.q4;
