@@ -683,7 +683,9 @@ __device__ __forceinline__ void packet_walk(const BvhDev& bvh, const Ray& r, v3 
                 float4 t0, t1, t2, t3;
                 load_const_tri(bvh.tris, leaf, t0, t1, t2, t3);
                 float t, u, v;
-                if (tri_test(r, t0, t1, t2, t, u, v))  // (a lane without a pixel walks its dummy ray: its result is dropped below)
+                // (a lane without a pixel walks its dummy ray: its result is dropped below.  Skipping the reciprocal and the interval test
+                // when no lane of the wave is inside the triangle measured nothing: (85))
+                if (tri_test(r, t0, t1, t2, t, u, v))
                 {
                     const uint32_t gid = f2u(t3.x);
                     if (t < best_t || (t == best_t && gid < best_gid)) best_t = t, best_u = u, best_v = v, best_gid = gid;
@@ -698,9 +700,15 @@ __device__ __forceinline__ void packet_walk(const BvhDev& bvh, const Ray& r, v3 
     }
 }
 
-__device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const Ray& r, bool alive, uint32_t* wstack, float& best_t,
+__device__ __forceinline__ void traverse_closest_packet(const BvhDev& bvh, const Ray& r_in, bool alive, uint32_t* wstack, float& best_t,
                                                         float& best_u, float& best_v, uint32_t& best_gid)
 {
+    // 1 / d for the BOX tests from v_rcp_f32 (1 ulp; d = +-0 gives +-inf like the division): three IEEE divisions per ray less.  Like
+    // the wide view's make_wide_ray: the boxes' padding covers it and the hit rule never looks at boxes (tri_test does not use inv).
+    Ray r = r_in;
+    r.inv = mk3(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+    // (The camera position is wave-uniform and lives in scalar registers, like the triangle records: three moves per triangle test.
+    // Pinning it into vector registers saves them and costs more in spills at this kernel's 64 registers: + 1 %.)
     const v3 noi = mk3(-(r.o.x * r.inv.x), -(r.o.y * r.inv.y), -(r.o.z * r.inv.z));
     PacketSigns g;
     g.mx = (uint32_t)((int)f2u(r.inv.x) >> 31), g.my = (uint32_t)((int)f2u(r.inv.y) >> 31), g.mz = (uint32_t)((int)f2u(r.inv.z) >> 31);
