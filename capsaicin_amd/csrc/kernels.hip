@@ -247,9 +247,15 @@ __device__ __forceinline__ void exhaustive_closest(const BvhDev& bvh, const floa
     // candidate is +inf either way.  Pairs some lane is inside both triangles of (non-planar fans, rays on the diagonal) take
     // the two-reciprocal form for the whole wave (wave-uniform branch, rare).
     auto pair_cand = [&](const PairScaled& p, float& m, uint32_t& im) {
-        const bool ia = (p.a.U >= 0.0f) & (p.a.V >= 0.0f) & (p.a.U + p.a.V <= p.a.det);
-        const bool ib = (p.b.U >= 0.0f) & (p.b.V >= 0.0f) & (p.b.U + p.b.V <= p.b.det);
-        if (__builtin_expect(__ballot(ia & ib) != 0ull, 0))
+        const bool a0 = p.a.U >= 0.0f, a1 = p.a.V >= 0.0f, a2 = p.a.U + p.a.V <= p.a.det;
+        const bool b0 = p.b.U >= 0.0f, b1 = p.b.V >= 0.0f, b2 = p.b.U + p.b.V <= p.b.det;
+        const bool ia = a0 & a1 & a2, ib = b0 & b1 & b2;
+        // "some lane is inside both": the six compares' own lane masks AND-ed in scalar registers.  The ballot of the computed bool
+        // (ia & ib) instead costs four half-rate vector instructions per pair -- two 0 / 1 materialisations, an AND and a compare -- and
+        // keeps the 0 / 1 words alive for the compiler to build (ia | ib) and the id from: 20 issue cycles of a pair's ~165 (round 6, (87)).
+        const unsigned long long both = __builtin_amdgcn_ballot_w64(a0) & __builtin_amdgcn_ballot_w64(a1) & __builtin_amdgcn_ballot_w64(a2) &
+                                        __builtin_amdgcn_ballot_w64(b0) & __builtin_amdgcn_ballot_w64(b1) & __builtin_amdgcn_ballot_w64(b2);
+        if (__builtin_expect(both != 0ull, 0))
         {
             const float ta = p.a.T * rcp_c(p.a.det), tb = p.b.T * rcp_c(p.b.det);
             const float ca = (ia & (ta > r.tmin)) ? ta : __builtin_inff(), cb = (ib & (tb > r.tmin)) ? tb : __builtin_inff();
