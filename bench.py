@@ -345,21 +345,20 @@ def tree_rooflines(tp, key, scene_note, dense=False):
 
 
 def tree_variant(dev, stream):
-    """BASELINE configs[3] at its own sample count: the 262 k-triangle textured hall, 1920x1080, 128 spp (four batches of 32),
-    depth 8; the stage split and the rooflines come from one stage-timed 32-spp batch (sub-key batch_32spp)."""
+    """BASELINE configs[3] at its own sample count: the 262 k-triangle textured hall, 1920x1080, 128 spp, depth 8 -- two batches of 64
+    frame slots, one per lane (the tree path's default of 128 Mi paths per batch, context.hip cap_render).  The stage split and the
+    rooflines come from the same render under the stage timers (sub-key batch_64spp: per batch)."""
     from capsaicin_amd import capi
     r2, bi2 = make_hall(dev, stream)
-    # warm-up with the batch structure of the timed render (two lanes, 32 frame slots each): a working set that still has to grow
-    # inside the timed region costs a fresh 14-GB hipMalloc per lane, 0.4 s each
-    r2.render(0, 2 * TREE_SPP, DEPTH, 0)
+    # warm-up with the batch structure of the timed render (two lanes, 64 frame slots each): a working set that still has to grow
+    # inside the timed region costs a fresh 28-GB hipMalloc per lane
+    r2.render(0, TREE_FULL_SPP, DEPTH, 0)
     dt, ts = timed(r2, 0, TREE_FULL_SPP, DEPTH, 0, 1)
     check_guards(ts, "tree_variant")
-    dt32, ts32 = timed(r2, 0, TREE_SPP, DEPTH, 0, 2)
-    # Stage split and rooflines: TWO whole batches (2 x 32 spp), stage-timed, i.e. one after the other on one stream.  A render that
-    # fits one batch would be cut in two halves for the two lanes (context.hip) and keep that cut under the stage timers; whole
-    # batches are what tools/prof.sh profiles (CAP_NO_TWO_LANES=1: a launch's duration is its own), so the per-launch figures of this
-    # line, of profiles/r04_kernel_stats_tree.csv and of the counter passes describe the same launches.
-    _, tp = timed(r2, 0, 2 * TREE_SPP, DEPTH, capi.RENDER_STAGE_TIMERS, 1)
+    # Stage split and rooflines: the same two batches, stage-timed, i.e. one after the other on one stream -- what tools/prof.sh
+    # profiles (CAP_NO_TWO_LANES=1: a launch's duration is its own), so the per-launch figures of this line, of
+    # profiles/rNN_kernel_stats_tree.csv and of the counter passes describe the same launches.
+    dts, tp = timed(r2, 0, TREE_FULL_SPP, DEPTH, capi.RENDER_STAGE_TIMERS, 1)
     troof, sroof = tree_rooflines(tp, "tree", "texture-address path + vector-instruction issue + exposed latency (DESIGN.md 5): on this "
                                   "scene the nodes and triangles a ray touches come from L2 / Infinity Cache, not HBM; achieved / frac = "
                                   "queue-stream bytes (A), achieved_with_traversal_bytes = (A + B) requested bytes, traffic = measured HBM bytes")
@@ -369,7 +368,8 @@ def tree_variant(dev, stream):
                         (bi2.triangle_count, WIDTH, HEIGHT, TREE_FULL_SPP, DEPTH),
             "value": rays(ts) / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
             "bvh": {"build": "device SAH splits + clustering + 8-wide collapse (cap_bvh_build AUTO)", "depth": int(bi2.max_depth), "build_ms": float(bi2.build_ms)},
-            "batch_32spp": {"value": rays(ts32) / 2 / dt32 / 1e6, "ms_per_step": dt32 * 1e3,
+            "batch_64spp": {"what": "one batch of 64 frame slots, batches one after the other on one stream (stage timers)",
+                            "value": rays(tp) / dts / 1e6, "ms_per_step": dts * 1e3 / 2,
                             "stage_ms": {k: v / 2 for k, v in stage_ms(tp).items()}},
             "roofline": troof, "shade_roofline": sroof}
 
@@ -460,7 +460,7 @@ def step_traffic(sp, ms_per_step):
 
 def config3_variant(dev, stream):
     """BASELINE configs[2], "the HBM-roofline run": cornell_box 3840x2160, 512 spp, depth 8, EXT model (next-event estimation of
-    the emissive lamp), ONE step; the roofline object comes from a stage-timed 64-spp slice of it (eight batches)."""
+    the emissive lamp), ONE step; the roofline object comes from a stage-timed 64-spp slice of it (four batches of 16 frame slots)."""
     from capsaicin_amd import capi
     w, h, spp = 3840, 2160, 512
     r = make_cornell(dev, stream, w, h, ext=True)
@@ -490,10 +490,10 @@ def config5_share(dev, stream):
     spp, depth = 1024, 16
     r = make_cornell(dev, stream, w, h, ext=True, shard=(0, 8))
     fl = capi.RENDER_EXT_MATERIALS
-    r.render(0, 64, depth, fl)  # two whole batches of 32 frame slots: every buffer at its final size before the timed render
+    r.render(0, 64, depth, fl)  # one whole batch of 64 frame slots: every buffer at its final size before the timed render
     dt, st = timed(r, 0, spp, depth, fl, 1)
     check_guards(st, "config5_share")
-    _, sp = timed(r, 0, 32, depth, fl | capi.RENDER_STAGE_TIMERS, 1)  # one batch of 32 frame slots, stage-timed
+    _, sp = timed(r, 0, 64, depth, fl | capi.RENDER_STAGE_TIMERS, 1)  # one batch of 64 frame slots (what the step's batches are), stage-timed
     roof, _ = fused_roofline(sp, "k_trace_shade<bounce>=1, EXT>, shard 0 of 8 of 4096x4096", "config5", True, True)
     r.close()
     rays = st.rays_primary + st.rays_extension + st.rays_shadow
@@ -501,7 +501,7 @@ def config5_share(dev, stream):
                         (w, h, spp, depth),
             "value": rays / dt / 1e6, "unit": "Mrays/s (this rank)", "ms_per_step": dt * 1e3,
             "rays_per_step": {"primary": st.rays_primary, "extension": st.rays_extension, "shadow": st.rays_shadow},
-            "predicted_8gpu_value_before_gather": 8 * rays / dt / 1e6, "roofline": roof, "stage_ms_32spp_slice": stage_ms(sp)}
+            "predicted_8gpu_value_before_gather": 8 * rays / dt / 1e6, "roofline": roof, "stage_ms_64spp_slice": stage_ms(sp)}
 
 
 def post_chain_variant(dev, stream):

@@ -1413,6 +1413,25 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     // 32 Mi 22.1, 64 Mi 21.2, 128 Mi 21.1 per step -- every launch has a fixed cost (grid start, tables, tail) that fewer, larger
     // batches amortise; 64 Mi paths are ~14 GB of queues and planes
     uint64_t       budget = c->max_batch_paths ? c->max_batch_paths : (uint64_t)64 << 20;
+    const bool tree_path = c->traversal_mode == CAP_TRAVERSAL_EXHAUSTIVE ? false
+                                                                         : !(c->traversal_mode == CAP_TRAVERSAL_AUTO && c->tri_count <= kExhaustiveMax);
+    if (!c->max_batch_paths && (uint64_t)n_frames * Ppad > budget)
+    {
+        // Twice that when the card has the room (round 6, docs/experiments.md (88)): the tree path has 27 launches per batch, most of
+        // them short, and gains 1.7 % (the 262 k hall at 128 spp: 92.1 -> 90.5 ms; round 4 measured 101.2 -> 99.4 and kept 64 Mi for
+        // its 14 GB per lane), the small-scene path 1.0 % (headline 20.22 -> 20.01 ms).  Taken when the working set is already that
+        // large or the device reports room for it with a margin -- 128 Mi paths are ~28 GB per lane of the card's 288, and the tree
+        // path runs two lanes; cap_set_batch_paths overrides either way.
+        const uint64_t big       = (uint64_t)128 << 20;
+        const uint64_t big_slots = std::max<uint64_t>(1, std::min<uint64_t>(big / std::max(1u, Ppad), kMaxFrameSlots));
+        bool           room      = c->pl_color.n >= big_slots * Ppad && (!tree_path || c->lane1.pl_color.n >= big_slots * Ppad);
+        if (!room)
+        {
+            size_t free_b = 0, total_b = 0;
+            room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 3u * big_slots * Ppad * 256u;  // ~208 B per path and lane
+        }
+        if (room) budget = big;
+    }
     uint32_t       slots  = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(budget / std::max(1u, Ppad), kMaxFrameSlots));
     slots                 = std::min(slots, n_frames);
     // Two lanes (CapContext::Lane): consecutive batches alternate between two working sets on two streams, so that the tail of
@@ -1424,8 +1443,6 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
     // Only on the tree path: its bounces are three launches each, and from the third bounce on they are short (the 262 k scene: 27
     // launches per batch, the last 15 under 0.2 ms each) -- 28.3 -> 26.4 ms per 32 spp.  The small-scene path's nine long fused
     // launches gain nothing measurable (20.45 -> 20.25 ms with the context's own stream, 20.56 -> 20.9 beside a torch stream).
-    const bool tree_path = c->traversal_mode == CAP_TRAVERSAL_EXHAUSTIVE ? false
-                                                                         : !(c->traversal_mode == CAP_TRAVERSAL_AUTO && c->tri_count <= kExhaustiveMax);
     bool two_lanes = !no_two_lanes && tree_path && c->bvh_info.stack_entries != 0 && !(flags & CAP_RENDER_GBUFFER_FEEDBACK) &&
                      !(flags & CAP_RENDER_LOWRES_INDIRECT) && n_frames >= 2;
     if (two_lanes && slots >= n_frames)
