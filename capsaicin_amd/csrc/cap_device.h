@@ -136,6 +136,17 @@ __device__ __forceinline__ bool local_pixel_to_xy(const ScreenDev& sc, uint32_t 
     return gt < sc.tile_count && x < sc.width && y < sc.height;
 }
 
+// camera.h:39-63
+__device__ __forceinline__ v3 primary_dir(const CameraDev& cam, const ScreenDev& sc, const FrameConst& fc, uint32_t x, uint32_t y)
+{
+    const float ix = ((float)x + fc.jitter_x) / (float)sc.width, iy = ((float)y + fc.jitter_y) / (float)sc.height;
+    const float cx = (ix - 0.5f) * cam.sensor_x, cy = (iy - 0.5f) * cam.sensor_y;
+    const v3    d  = mk3(fmaf(cy, cam.up[0], fmaf(cx, cam.right[0], cam.focal_length * cam.forward[0])),
+                         fmaf(cy, cam.up[1], fmaf(cx, cam.right[1], cam.focal_length * cam.forward[1])),
+                         fmaf(cy, cam.up[2], fmaf(cx, cam.right[2], cam.focal_length * cam.forward[2])));
+    return normalize3(d);
+}
+
 // Wavefront queues, all SoA planes of float4 (16 B per lane per access, 1 KiB per wave instruction).
 // Sub-queue k occupies entries [k * class_capacity, (k + 1) * class_capacity) and is counted by count[k * kCounterStride].
 struct RayQueue

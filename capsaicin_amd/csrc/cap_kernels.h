@@ -36,6 +36,7 @@ enum CapSwitch : uint32_t
     SW_W8_GRID,
     SW_AUTO_SAH_TRIANGLES,  // AUTO builds with surface-area splits from this many triangles on
     SW_NO_NEE_PAIR_CULL,    // EXT model: next-event rays test every fan pair (read by the next cap_bvh_build / cap_materials_upload)
+    SW_RAYGEN_KERNEL,       // dense scenes: the camera rays' identity queue written out by k_raygen_identity instead of generated in the trace kernel
     SW_COUNT
 };
 struct SwitchTable
@@ -73,6 +74,8 @@ void launch_raygen_identity(const LaunchCfg& cfg, const CameraDev& cam, const Sc
 void launch_trace_closest(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits);
 // The same on the compressed 8-wide view of the tree (trace8.hip; needs bvh.wide8_ok).  work: kQueueClasses zeroed chunk-grab counters.
 void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work);
+void launch_trace_closest8_camera(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work,
+                                  const CameraDev& cam, const ScreenDev& screen, const FrameConst* frames, uint32_t n_slots);
 // Any hit for the shadow-ray queue (lighting.h:48-61); unoccluded rays add contrib to target[plane index].
 // guard: 8 x uint64 {-, malformed path ids seen by shade, by trace_any, last offender, appends beyond a class's capacity, -, -, -}
 // work: kQueueClasses zeroed chunk-grab counters for this launch (exhaustive path; may be NULL for the LBVH kernels)

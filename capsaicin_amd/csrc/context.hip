@@ -553,7 +553,7 @@ static const char* const kSwitchNames[SW_COUNT] = {
     "CAP_NO_WIDE8", "CAP_LANE1_PRIORITY", "CAP_PLOC_RADIUS", "CAP_SAHDEV_LEAF", "CAP_WIDE_HOST_COLLAPSE", "CAP_TRACE_LAUNCHES", "CAP_NO_TWO_LANES",
     "CAP_LANE_SPLIT_MIN", "CAP_BLOCKS_PER_CU", "CAP_NO_CAMERA_CULL", "CAP_NO_ALBEDO_IN_W", "CAP_NO_INLINE_NEE", "CAP_NO_INLINE_PROBE", "CAP_NO_WAVE_RING",
     "CAP_ANY_REFILL", "CAP_PRIMARY_WIDE", "CAP_NO_PACKET", "CAP_NO_ANY_PROBE", "CAP_ANY_PROBE", "CAP_ANY_BLOCKS", "CAP_NO_PRIMARY_FUSE", "CAP_W8_REFILL",
-    "CAP_W8_GRID", "CAP_AUTO_SAH_TRIANGLES", "CAP_NO_NEE_PAIR_CULL"};
+    "CAP_W8_GRID", "CAP_AUTO_SAH_TRIANGLES", "CAP_NO_NEE_PAIR_CULL", "CAP_RAYGEN_KERNEL"};
 
 static void switches_from_environment(SwitchTable& t)
 {
@@ -1714,8 +1714,13 @@ int cap_render(CapContext* c, uint32_t frame_begin, uint32_t n_frames, uint32_t 
                             // dense scene: camera rays as an identity queue through the wide per-lane kernel (see above)
                             const uint32_t id_cap = (((max_count + kQueueClasses - 1) / kQueueClasses) + 63u) & ~63u;
                             const RayQueue idq{L.q_org[0], L.q_dir[0], nullptr, L.counters + 3 * counter_words, id_cap, nullptr};
-                            launch_raygen_identity(cfg, cam, c->screen, frames, ns, idq);
-                            launch_trace_closest8(cfg, bvh, idq, max_count, L.hits, sa.work);
+                            if (c->sw.on(SW_RAYGEN_KERNEL) || bvh.tri_count == 0)  // A/B switch: the identity queue written out by its own kernel
+                            {
+                                launch_raygen_identity(cfg, cam, c->screen, frames, ns, idq);
+                                launch_trace_closest8(cfg, bvh, idq, max_count, L.hits, sa.work);
+                            }
+                            else
+                                launch_trace_closest8_camera(cfg, bvh, idq, max_count, L.hits, sa.work, cam, c->screen, frames, ns);
                         }
                         else
                         {

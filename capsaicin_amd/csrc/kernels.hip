@@ -461,17 +461,6 @@ __device__ __forceinline__ bool trace_any_any_size(const BvhDev& bvh, const Ray&
         return traverse_any<STACK>(bvh, r, stack);
 }
 
-// camera.h:39-63
-__device__ __forceinline__ v3 primary_dir(const CameraDev& cam, const ScreenDev& sc, const FrameConst& fc, uint32_t x, uint32_t y)
-{
-    const float ix = ((float)x + fc.jitter_x) / (float)sc.width, iy = ((float)y + fc.jitter_y) / (float)sc.height;
-    const float cx = (ix - 0.5f) * cam.sensor_x, cy = (iy - 0.5f) * cam.sensor_y;
-    const v3    d  = mk3(fmaf(cy, cam.up[0], fmaf(cx, cam.right[0], cam.focal_length * cam.forward[0])),
-                         fmaf(cy, cam.up[1], fmaf(cx, cam.right[1], cam.focal_length * cam.forward[1])),
-                         fmaf(cy, cam.up[2], fmaf(cx, cam.right[2], cam.focal_length * cam.forward[2])));
-    return normalize3(d);
-}
-
 // Workgroups per CU the stack kernels are register-allocated for: what their LDS stacks allow.  A workgroup's stack is
 // entries x 256 lanes x 4 B; of 32-KB stacks four fit into the CU's 160 KB beside the runtime's own share, of 24-KB ones six.
 // (0 = no hint: the small-scene kernels keep the compiler's default allocation; a hint of 8 squeezed k_trace_any<0> from 44 to

@@ -45,15 +45,37 @@ __device__ unsigned long long g_w8_counts[16];
 #define W8_COUNT(i, v) ((void)0)
 #endif
 
-__global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev bvh, RayQueue q, float4* hits, uint32_t* work, uint32_t refill_idle)
+// CAMERA: the queue is the camera rays' identity queue (entry i = frame slot i / Ppad, local pixel i % Ppad; class k owns entries
+// [k * capacity, min((k + 1) * capacity, total)): dense scenes, context.hip primary_wide) and is never materialised -- a chunk's rays are
+// generated where the other instantiation loads them (the same primary_dir() on the same operands as k_raygen_identity, which this
+// replaces: 32 B written and read per camera ray and one launch less; docs/experiments.md (89)).
+struct CameraFeed
+{
+    CameraDev         cam;
+    ScreenDev         screen;
+    const FrameConst* frames;
+    uint32_t          n_slots;
+};
+template <bool CAMERA>
+__global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev bvh, RayQueue q, float4* hits, uint32_t* work, uint32_t refill_idle,
+                                                                          CameraFeed feed)
 {
     __shared__ uint2  lds_stack[kW8Lds * kBlock];
     __shared__ float4 lds_rays[2 * kBlock];  // per wave: 64 x (origin, tmin) then 64 x (direction, tmax)
     const uint32_t lane = threadIdx.x & 63u;
     float4* const  rbuf = lds_rays + (threadIdx.x >> 6) * 128u;
     const uint32_t my_class = wave_global_id() % kQueueClasses;
-    uint32_t       n_class  = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.count[my_class * kCounterStride]);
-    n_class                 = n_class < q.class_capacity ? n_class : q.class_capacity;
+    uint32_t       n_class;
+    if (CAMERA)
+    {
+        const uint64_t total = (uint64_t)feed.n_slots * feed.screen.pixels_padded, begin = (uint64_t)my_class * q.class_capacity;
+        n_class              = begin < total ? (uint32_t)(total - begin < q.class_capacity ? total - begin : q.class_capacity) : 0u;
+    }
+    else
+    {
+        n_class = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.count[my_class * kCounterStride]);
+        n_class = n_class < q.class_capacity ? n_class : q.class_capacity;
+    }
 
     // ---- feed: chunk j of this wave's class, one chunk ahead in registers (pa, pb), the current one in LDS (rbuf) ----
     uint32_t grab   = grab_issue(work, my_class);
@@ -65,7 +87,20 @@ __global__ __launch_bounds__(kBlock, CAP_W8_BLOCKS) void k_trace_closest8(BvhDev
         if (start >= n_class) return;  // past the end of this class's sub-queue: the feed has ended
         pend_n    = n_class - start < 64u ? n_class - start : 64u;
         pend_base = my_class * q.class_capacity + start;
-        if (lane < pend_n) pa = q.org_tmin[pend_base + lane], pb = q.dir_tmax[pend_base + lane];
+        if (CAMERA)
+        {
+            if (lane < pend_n)
+            {
+                const uint32_t i = pend_base + lane, slot = i / feed.screen.pixels_padded, pl = i - slot * feed.screen.pixels_padded;
+                uint32_t       x = 0, y = 0;
+                const bool     in_image = local_pixel_to_xy(feed.screen, pl, x, y);  // (padding lanes of partial tiles: an empty interval)
+                const v3       d        = in_image ? primary_dir(feed.cam, feed.screen, feed.frames[slot], x, y) : mk3(0.f, 0.f, 1.f);
+                pa = make_float4(feed.cam.position[0], feed.cam.position[1], feed.cam.position[2], 0.0f);
+                pb = make_float4(d.x, d.y, d.z, in_image ? kPrimaryFar : 0.0f);
+            }
+        }
+        else if (lane < pend_n)
+            pa = q.org_tmin[pend_base + lane], pb = q.dir_tmax[pend_base + lane];
         grab = grab_issue(work, my_class);
     };
     fetch();
@@ -413,7 +448,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest8_empty(RayQueue q, flo
 
 uint32_t wide8_stack_pairs() { return kW8StackPairs; }
 
-void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work)
+static void launch_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work,
+                            const CameraFeed* camera)
 {
     uint32_t g = (max_count + kBlock - 1) / kBlock;
     const uint32_t per_cu = (uint32_t)cfg.sw_get(SW_W8_GRID, CAP_W8_BLOCKS);  // A/B switch
@@ -427,6 +463,22 @@ void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQue
         return;
     }
     const uint32_t refill = w8_refill_idle(cfg);
-    hipLaunchKernelGGL(k_trace_closest8, dim3(g), dim3(kBlock), 0, cfg.stream, bvh, q, hits, work, refill);
+    if (camera)
+        hipLaunchKernelGGL(k_trace_closest8<true>, dim3(g), dim3(kBlock), 0, cfg.stream, bvh, q, hits, work, refill, *camera);
+    else
+        hipLaunchKernelGGL(k_trace_closest8<false>, dim3(g), dim3(kBlock), 0, cfg.stream, bvh, q, hits, work, refill, CameraFeed{});
+}
+
+void launch_trace_closest8(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work)
+{
+    launch_closest8(cfg, bvh, q, max_count, hits, work, nullptr);
+}
+
+// Camera rays of a dense scene: q carries only the identity queue's class capacity (its planes and counters are not touched).
+void launch_trace_closest8_camera(const LaunchCfg& cfg, const BvhDev& bvh, const RayQueue& q, uint32_t max_count, float4* hits, uint32_t* work,
+                                  const CameraDev& cam, const ScreenDev& screen, const FrameConst* frames, uint32_t n_slots)
+{
+    const CameraFeed feed{cam, screen, frames, n_slots};
+    launch_closest8(cfg, bvh, q, max_count, hits, work, &feed);
 }
 }  // namespace cap
