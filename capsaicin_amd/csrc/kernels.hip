@@ -507,10 +507,10 @@ __global__ __launch_bounds__(kBlock, stack_residency(STACK)) void k_trace_primar
 // wstack: this wave's kPacketStack entries (the tree depth is checked on the host against the same 64).
 constexpr uint32_t kPacketStack = 64;
 // One box of a packet step, written for what the step is bound by -- vector ISSUE (round 6: 3 880 vector instructions per packet at
-// ~3 cycles each fill the SIMD's time; docs/experiments.md (85)).  The values are slab()'s: (lo - o) * inv <= (hi - o) * inv for
-// inv > 0 and the other way round for inv < 0 (rounding is monotonic), so min / max of the two products IS the product picked by
-// the sign of inv -- a full-rate v_bitop3 select with the ray's sign word instead of a half-rate min / max.  Where slab()'s
-// min / max drop a NaN (0 * inf) the select keeps it, and the fmaxf / fminf behind it drop it: only wider.
+// ~3 cycles each fill the SIMD's time; docs/experiments.md (85)).  Near and far plane as slab() picks them: the plane distance is
+// monotonic in the plane (rounding is monotonic), increasing for inv > 0 and decreasing for inv < 0, so min / max of a slab's two
+// distances IS the distance picked by the sign of inv -- a full-rate v_bitop3 select with the ray's sign word instead of a half-rate
+// min / max.  Where slab()'s min / max drop a NaN (0 * inf) the select keeps it, and the max / min behind it drop it: only wider.
 __device__ __forceinline__ float packet_sel(uint32_t m, float a, float b) { return u2f(__builtin_amdgcn_bitop3_b32(m, f2u(a), f2u(b), 0xca)); }
 // v_max3 / v_min3 / v_max / v_min as the hardware has them.  Through fmaxf / fminf the compiler first canonicalises every operand it
 // cannot prove quiet (four of the selected words per box, 4 cycles each): a signalling NaN would pass through v_max instead of being
