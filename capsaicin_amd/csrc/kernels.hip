@@ -1927,32 +1927,32 @@ __device__ __forceinline__ float lum3(v3 c) { return fmaf(c.z, 0.114f, fmaf(c.y,
 // along the sampled direction) share them, so they are computed once -- the same expressions on the same operands as before.
 struct ExtView
 {
-    float cos_o, g_o;
+    float cos_o, lam_o;  // lam_o = cos_o + sqrt(a2 + (1 - a2) cos_o^2): the outgoing direction's factor of the masking term
 };
 __device__ __forceinline__ ExtView ext_view(float a2, v3 nf, v3 wo)
 {
     ExtView w;
     w.cos_o = dot3(nf, wo);
-    w.g_o   = (2.0f * w.cos_o) / (w.cos_o + sqrtf(fmaf(1.0f - a2, w.cos_o * w.cos_o, a2)));
+    w.lam_o = w.cos_o + sqrtf(fmaf(1.0f - a2, w.cos_o * w.cos_o, a2));
     return w;
 }
 __device__ __forceinline__ ExtBsdf ext_bsdf(v3 kd, v3 ks, float a2, v3 nf, v3 wo, v3 wi, const ExtView& vw)
 {
-    const float cos_o = vw.cos_o, cos_i = dot3(nf, wi);
+    const float cos_i = dot3(nf, wi);
     const v3    h     = normalize3(wo + wi);
     const float cos_h = dot3(nf, h), woh = dot3(wo, h);
     const float dd    = fmaf(cos_h * cos_h, a2 - 1.0f, 1.0f);
-    const float D     = a2 / (kPi * dd * dd);
-    const float g_o   = vw.g_o;
-    const float g_i   = (2.0f * cos_i) / (cos_i + sqrtf(fmaf(1.0f - a2, cos_i * cos_i, a2)));
+    // D G / (4 cos_o cos_i) in its cancelled ("visibility") form, one division: see oracle/cap_oracle.cpp ext_bsdf (the same operations)
+    const float pdd   = kPi * dd * dd;
+    const float lam_i = cos_i + sqrtf(fmaf(1.0f - a2, cos_i * cos_i, a2));
 #if defined(CAP_EXT_DIAG) && CAP_EXT_DIAG == 3  // diagnostic build: no microfacet term (D, G and their divisions fall away)
-    const float spec  = 0.0f * (cos_o + woh);
+    const float spec  = 0.0f * (vw.cos_o + woh);
 #else
-    const float spec  = (D * (g_o * g_i)) / (4.0f * cos_o * cos_i);
+    const float spec  = a2 / (pdd * (vw.lam_o * lam_i));
 #endif
     ExtBsdf     r;
     r.f        = mk3(kd.x * kInvPi + ks.x * spec, kd.y * kInvPi + ks.y * spec, kd.z * kInvPi + ks.z * spec);
-    r.pdf_spec = (D * cos_h) / (4.0f * woh);
+    r.pdf_spec = (a2 * cos_h) / (pdd * (4.0f * woh));
     r.pdf_diff = cos_i * kInvPi;
     return r;
 }

@@ -804,13 +804,16 @@ ExtBsdf ext_bsdf(f3 kd, f3 ks, float a2, f3 nf, f3 wo, f3 wi)
     f3    h     = normalize(wo + wi);
     float cos_h = dot(nf, h), woh = dot(wo, h);
     float dd    = fmaf(cos_h * cos_h, a2 - 1.0f, 1.0f);
-    float D     = a2 / (kPi * dd * dd);
-    float g_o   = (2.0f * cos_o) / (cos_o + sqrtf(fmaf(1.0f - a2, cos_o * cos_o, a2)));
-    float g_i   = (2.0f * cos_i) / (cos_i + sqrtf(fmaf(1.0f - a2, cos_i * cos_i, a2)));
-    float spec  = (D * (g_o * g_i)) / (4.0f * cos_o * cos_i);
+    // D G / (4 cos_o cos_i) with Smith's G = g_o g_i, g = 2 cos / (cos + sqrt(a2 + (1 - a2) cos^2)), in its cancelled form: the
+    // 2 cos of either g and the 4 cos_o cos_i go, leaving ONE division, D V = a2 / (pi dd^2 (cos_o + s_o)(cos_i + s_i)) -- the
+    // "visibility" form of the same function (EXT shading model; until round 6 the five divisions were written out)
+    float pdd   = kPi * dd * dd;
+    float lam_o = cos_o + sqrtf(fmaf(1.0f - a2, cos_o * cos_o, a2));
+    float lam_i = cos_i + sqrtf(fmaf(1.0f - a2, cos_i * cos_i, a2));
+    float spec  = a2 / (pdd * (lam_o * lam_i));
     ExtBsdf r;
     r.f        = make3(kd.x * kInvPi + ks.x * spec, kd.y * kInvPi + ks.y * spec, kd.z * kInvPi + ks.z * spec);
-    r.pdf_spec = (D * cos_h) / (4.0f * woh);
+    r.pdf_spec = (a2 * cos_h) / (pdd * (4.0f * woh));
     r.pdf_diff = cos_i * kInvPi;
     return r;
 }
