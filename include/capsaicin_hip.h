@@ -219,7 +219,9 @@ int cap_prev_camera_set(CapContext* ctx, const CapCameraData* camera);
 int cap_set_resolution(CapContext* ctx, uint32_t width, uint32_t height);
 /* Screen-tile sharding: this context renders the 8x8 tiles t with t % shard_count == shard_index. */
 int cap_set_shard(CapContext* ctx, uint32_t shard_index, uint32_t shard_count);
-/* Upper bound of (frame, pixel) paths kept in flight per batch (0 = default). */
+/* Upper bound of (frame, pixel) paths kept in flight per batch.  0 = default: 128 Mi paths (~28 GB of queues and planes per working
+ * set; the tree path keeps two) when a call has more than 64 Mi to render and the device reports room for three such working sets,
+ * 64 Mi otherwise; at most 64 frames per batch either way.  Results do not depend on it. */
 int cap_set_batch_paths(CapContext* ctx, uint64_t max_paths);
 /* Test hooks (no reference counterpart; never needed by a host program).  CAP_DEBUG_QUEUE_CAPACITY_DIV: the sub-queues of the next
  * renders get 1 / value of the capacity they need (value 1 = normal), so that the kernels' append guard (CapStats::guard_append) can
