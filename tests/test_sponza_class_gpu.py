@@ -86,6 +86,48 @@ def test_small_scale_parity(native_lib, bluenoise, tmp_path, build, w, h):
     r.close()
 
 
+def test_packet_walk_octants(native_lib, bluenoise, tmp_path):
+    """The camera rays' packet walk exists once per direction octant (kernels.hip packet_walk<0..7>, chosen per 8 x 8 tile) plus the
+    per-lane form for tiles whose rays disagree in a sign: a narrow view along each of the eight diagonals (every tile in one octant)
+    and a wide one (mixed tiles along the axes through the image), hit records and the shaded frame against the oracle."""
+    from oracle import cap_oracle as O
+    import make_sponza_class as gen
+    geo, texs = _setup(tmp_path, 0.1, 64)
+    w, h, D = 64, 48, 2
+    r = capi.Renderer(0)
+    r.upload_geometry(geo)
+    for i, t in enumerate(texs):
+        r.upload_texture(i, t)
+    r.upload_bluenoise(bluenoise)
+    assert r.build_bvh().triangle_count > 64
+    r.set_resolution(w, h)
+    sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes, textures=texs)
+    base = gen.camera()
+    views = [((sx, sy, sz), 0.12) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)] + [((0.02, -0.01, 1.0), 0.012)]
+    for k, (fwd, focal) in enumerate(views):
+        cam = capi.CameraData()
+        f = np.float64(fwd)
+        f /= np.linalg.norm(f)
+        right = -np.cross(f, (0, 1, 0))
+        right /= np.linalg.norm(right)
+        cam.position[:] = base["position"]
+        cam.forward[:] = f
+        cam.right[:] = right
+        cam.up[:] = np.cross(f, right)
+        cam.focal_length = focal  # 0.12 on a 36 mm sensor: +- 8.5 degrees, well inside one octant around a diagonal; 0.012: +- 56 degrees
+        cam.sensor_size[0] = 0.036
+        cam.sensor_size[1] = np.float32(0.036) * (np.float32(h) / np.float32(w))
+        r.set_camera(cam)
+        r.accum_reset()
+        r.render(3 + k, 1, D, capi.RENDER_AOV)
+        ocam = O.make_camera(tuple(cam.position), tuple(cam.forward), tuple(cam.right), tuple(cam.up), cam.sensor_size[0], cam.sensor_size[1], cam.focal_length)
+        ref = sc.render_frame(ocam, bluenoise, w, h, 3 + k, D, flags=O.FLAG_USE_BVH, threads=8)
+        for name, kind in (("gbuffer_geo", capi.BUF_GBUFFER_GEO), ("combined", capi.BUF_COMBINED)):
+            nbad = int((bits(r.readback(kind)) != bits(ref[name])).any(-1).sum())
+            assert nbad == 0, "view %d %s: %s: %d pixels differ" % (k, fwd, name, nbad)
+    r.close()
+
+
 @pytest.mark.parametrize("first_frame,n_frames", [(1100, 2), (2100, 2), (3100, 2), (1022, 4), (4094, 4)])
 def test_light_octants_parity(native_lib, bluenoise, tmp_path, first_frame, n_frames):
     """The reference's light turns around the vertical axis once per 4096 frames (lighting.h:20-33), so its direction visits four
