@@ -86,8 +86,11 @@ struct DevBuf
 // camera rays take the per-lane wide kernel instead of the packet walk from this many triangles per pixel on (measured: cap_render;
 // 1.0 until the walk's node step was rewritten in round 6 -- at 1.0 the walk now wins by 6 % of the step, at 2.0 the two are level)
 constexpr double kPrimaryWideTrianglesPerPixel = 2.0;
-// shadow rays take the lane-refill kernel from this many bytes of wide nodes + intersection records on (measured: cap_render)
-constexpr uint64_t kAnyRefillTreeBytes = 512ull << 20;
+// shadow rays take the lane-refill kernel from this many bytes of wide nodes + intersection records on (measured: cap_render).
+// Round 6: never by default.  Until the per-chunk kernel's traversal was compiled per light octant (docs/experiments.md (86)) the refill
+// kernel won by 3 % from 512 MiB of tree on; now the per-chunk kernel wins by 6 - 8 % at 8.4 M and 16.8 M triangles (1.5 GB of tree),
+// as it always did below.  CAP_ANY_REFILL=1 still selects the refill kernel (tests/test_fallback_kernels_gpu.py keeps it honest).
+constexpr uint64_t kAnyRefillTreeBytes = ~0ull;
 // AUTO builds with surface-area splits (ploc.hip, sah_device) from this many triangles on, the clustering alone below (see cap_bvh_build)
 constexpr uint32_t kAutoSahTriangles = 4096;
 
