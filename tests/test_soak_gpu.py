@@ -20,7 +20,8 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def test_random_views_parity(native_lib, bluenoise, tmp_path):
+@pytest.mark.parametrize("mode", ["default", "dense"])  # dense: the kernels a scene of >= 2 triangles per pixel gets, forced on this one
+def test_random_views_parity(native_lib, bluenoise, tmp_path, mode):
     from oracle import cap_oracle as O
     import make_sponza_class as gen
     from test_sponza_class_gpu import _setup
@@ -32,6 +33,11 @@ def test_random_views_parity(native_lib, bluenoise, tmp_path):
         r.upload_texture(i, t)
     r.upload_bluenoise(bluenoise)
     assert r.build_bvh().triangle_count > 64
+    if mode == "dense":
+        # camera rays generated in the wide closest-hit kernel's feed (k_trace_closest8<CAMERA>) + the stand-alone bounce-0 shade stage,
+        # shadow rays through the lane-refill kernel
+        r.debug_switch("CAP_PRIMARY_WIDE", 1)
+        r.debug_switch("CAP_ANY_REFILL", 1)
     r.set_resolution(w, h)
     sc = O.Scene(geo.positions, geo.normals, geo.texcoords, geo.indices, geo.meshes, textures=texs)
     lo, hi = geo.positions.min(0), geo.positions.max(0)
