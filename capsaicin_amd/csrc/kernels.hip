@@ -1826,10 +1826,12 @@ __device__ __forceinline__ void shade_vertex(const ShadeArgs& a, const float4* s
                     {
                         reused        = true;
                         const v3 hc   = sample_bilinear(Img{a.fb.color_history, W, H}, puv);
-                        float*   c    = reinterpret_cast<float*>(a.planes.color + plane_idx);
-                        atomicAdd(c + 0, thr.x * hc.x);
-                        atomicAdd(c + 1, thr.y * hc.y);
-                        atomicAdd(c + 2, thr.z * hc.z);
+                        // the path is this entry's only writer within the launch (it either escapes or is shaded), and bounce 0 defined the
+                        // entry one launch ago: a 16-B load-add-store makes the same IEEE additions as three float atomics.  Unlike the sky
+                        // term above, where the atomics win by 1 %, here most vertices of a frame take this branch -- the previous frame saw
+                        // them -- and 6 M atomics per launch cost more than the load's latency: real-time frame 0.648 -> 0.638 ms.
+                        const float4 cur = a.planes.color[plane_idx];
+                        a.planes.color[plane_idx] = make_float4(cur.x + thr.x * hc.x, cur.y + thr.y * hc.y, cur.z + thr.z * hc.z, cur.w);
                     }
                 }
             }
