@@ -137,6 +137,7 @@ SYMBOLS = {
     "cap_post_readback": (_i, [_vp, _vp]),
     "cap_obj_load": (_i, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
     "cap_geometry_free": (None, [_vp]),
+    "cap_obj_set_threads": (None, [C.c_int]),
     "cap_geometry_view": (_i, [_vp, C.POINTER(GeometryView)]),
     "cap_geometry_texture_name": (C.c_char_p, [_vp, _u32]),
     "cap_geometry_warning": (C.c_char_p, [_vp]),

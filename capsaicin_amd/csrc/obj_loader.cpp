@@ -10,6 +10,7 @@
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <thread>
 #include <tuple>
 
 #include "../../include/capsaicin_scene.h"
@@ -177,6 +178,187 @@ bool fast_index(const char* p, const char* e, int count, int* out)
 }
 }  // namespace
 
+// ---- the hot records on several threads (round 6; bench.py `ingest`) ----
+// The parse below is one pass over the text whose cost is the numbers: 2 M floats and 2.4 M indices in the 262 k-triangle hall.  For a
+// large file the text is cut at line ends into one chunk per thread; pass A converts a chunk's v / vn / vt records into chunk-local
+// arrays and notes its f records (with the chunk-local attribute counts at that line: an index is valid against what the file has
+// defined SO FAR) and its rare records; pass B, once the counts in front of every chunk are known, converts the f records.  The merge
+// walks the chunks in file order and does what the sequential loop does with the rare records.  ANY anomaly -- a malformed number, an
+// index out of range, a short face -- abandons the attempt: the sequential parser then runs from the start and reports it, so error
+// texts, line numbers and the accept / reject decisions are its alone, and for a file without one the arrays are the same bytes.
+int g_obj_threads = 0;  // cap_obj_set_threads: 0 = one per hardware thread (at most 8) for files above 1 MB, 1 = the sequential parser only
+
+struct ObjChunk
+{
+    const char *begin = nullptr, *end = nullptr;
+    std::vector<float> v, vn, vt;
+    struct Face
+    {
+        const char *a, *e;         // the record's text behind the keyword
+        uint32_t    nv, nvt, nvn;  // chunk-local attribute counts in front of this line
+    };
+    struct Event
+    {
+        uint32_t    face_pos;  // faces of this chunk in front of the record
+        const char *k0, *eol;
+    };
+    std::vector<Face>     faces;
+    std::vector<Event>    events;
+    std::vector<index_t>  tris;       // pass B: three per triangle
+    std::vector<uint32_t> tri_start;  // pass B: first triangle of face i (size faces + 1)
+    uint32_t base_v = 0, base_vt = 0, base_vn = 0;  // attribute counts in front of the chunk
+    bool     anomaly = false;
+};
+
+void obj_chunk_pass_a(ObjChunk& c)
+{
+    const char* p = c.begin;
+    while (p < c.end)
+    {
+        const char* eol = (const char*)std::memchr(p, '\n', (size_t)(c.end - p));
+        if (!eol) eol = c.end;
+        const char* q = p;
+        p             = eol < c.end ? eol + 1 : c.end;
+        auto token = [&](const char*& a, const char*& b) {
+            while (q < eol && is_blank(*q)) ++q;
+            a = q;
+            while (q < eol && !is_blank(*q)) ++q;
+            b = q;
+            return b > a;
+        };
+        const char *k0, *k1;
+        if (!token(k0, k1) || *k0 == '#') continue;
+        const size_t kl = (size_t)(k1 - k0);
+        const bool   is_v = kl == 1 && k0[0] == 'v', is_vn = kl == 2 && k0[0] == 'v' && k0[1] == 'n';
+        if (is_v || is_vn)
+        {
+            float       v[3];
+            const char *a[3], *b[3];
+            for (int k = 0; k < 3; ++k)
+                if (!token(a[k], b[k])) { c.anomaly = true; return; }
+            for (int k = 0; k < 3; ++k)
+                if (!fast_float(a[k], b[k], &v[k])) { c.anomaly = true; return; }
+            auto& dst = is_v ? c.v : c.vn;
+            dst.insert(dst.end(), v, v + 3);
+        }
+        else if (kl == 2 && k0[0] == 'v' && k0[1] == 't')
+        {
+            const char *a, *b;
+            if (!token(a, b)) { c.anomaly = true; return; }
+            float u = 0.f, v = 0.f;
+            if (!fast_float(a, b, &u)) { c.anomaly = true; return; }
+            if (token(a, b) && !fast_float(a, b, &v)) { c.anomaly = true; return; }
+            c.vt.push_back(u), c.vt.push_back(v);
+        }
+        else if (kl == 1 && k0[0] == 'f')
+            c.faces.push_back({q, eol, (uint32_t)(c.v.size() / 3), (uint32_t)(c.vt.size() / 2), (uint32_t)(c.vn.size() / 3)});
+        else
+            c.events.push_back({(uint32_t)c.faces.size(), k0, eol});
+    }
+}
+
+void obj_chunk_pass_b(ObjChunk& c)
+{
+    std::vector<index_t> face;
+    c.tri_start.reserve(c.faces.size() + 1);
+    c.tris.reserve(c.faces.size() * 6);
+    for (const ObjChunk::Face& f : c.faces)
+    {
+        c.tri_start.push_back((uint32_t)(c.tris.size() / 3));
+        const int nv = (int)(c.base_v + f.nv), nvt = (int)(c.base_vt + f.nvt), nvn = (int)(c.base_vn + f.nvn);
+        const char* q = f.a;
+        face.clear();
+        while (true)
+        {
+            while (q < f.e && is_blank(*q)) ++q;
+            const char* a = q;
+            while (q < f.e && !is_blank(*q)) ++q;
+            const char* b = q;
+            if (b == a) break;
+            index_t     idx{-1, -1, -1};
+            const char* s1 = (const char*)std::memchr(a, '/', (size_t)(b - a));
+            const char* s2 = s1 ? (const char*)std::memchr(s1 + 1, '/', (size_t)(b - s1 - 1)) : nullptr;
+            const char* ae = s1 ? s1 : b;
+            if (!fast_index(a, ae, nv, &idx.vertex_index)) { c.anomaly = true; return; }
+            if (s1)
+            {
+                const char* tb = s1 + 1;
+                const char* te = s2 ? s2 : b;
+                if (te > tb && !fast_index(tb, te, nvt, &idx.texcoord_index)) { c.anomaly = true; return; }
+                if (s2 && b > s2 + 1 && !fast_index(s2 + 1, b, nvn, &idx.normal_index)) { c.anomaly = true; return; }
+            }
+            face.push_back(idx);
+        }
+        if (face.size() < 3) { c.anomaly = true; return; }
+        for (size_t j = 2; j < face.size(); ++j) c.tris.push_back(face[0]), c.tris.push_back(face[j - 1]), c.tris.push_back(face[j]);
+    }
+    c.tri_start.push_back((uint32_t)(c.tris.size() / 3));
+}
+
+template <class F>
+void obj_parallel_for(std::vector<ObjChunk>& chunks, F fn)
+{
+    std::vector<std::thread> pool;
+    for (size_t i = 1; i < chunks.size(); ++i) pool.emplace_back([&chunks, i, fn] { fn(chunks[i]); });
+    fn(chunks[0]);
+    for (auto& t : pool) t.join();
+}
+
+// handle_rare: the sequential loop's treatment of an o / g / usemtl / mtllib record (shared).  false: an anomaly; the caller starts over.
+template <class Rare>
+bool load_obj_parallel(const std::string& text, int threads, attrib_t* attrib, shape_t& cur, int& cur_material, Rare handle_rare)
+{
+    std::vector<ObjChunk> chunks((size_t)threads);
+    const char* const     base = text.data();
+    const size_t          n    = text.size();
+    size_t                at   = 0;
+    for (int i = 0; i < threads; ++i)
+    {
+        size_t stop = i + 1 == threads ? n : n * (size_t)(i + 1) / (size_t)threads;
+        if (stop < at) stop = at;
+        if (stop < n)
+        {
+            const char* nl = (const char*)std::memchr(base + stop, '\n', n - stop);
+            stop           = nl ? (size_t)(nl - base) + 1 : n;
+        }
+        chunks[(size_t)i].begin = base + at, chunks[(size_t)i].end = base + stop;
+        at = stop;
+    }
+    obj_parallel_for(chunks, obj_chunk_pass_a);
+    uint32_t nv = 0, nvt = 0, nvn = 0;
+    for (ObjChunk& c : chunks)
+    {
+        if (c.anomaly) return false;
+        c.base_v = nv, c.base_vt = nvt, c.base_vn = nvn;
+        nv += (uint32_t)(c.v.size() / 3), nvt += (uint32_t)(c.vt.size() / 2), nvn += (uint32_t)(c.vn.size() / 3);
+    }
+    obj_parallel_for(chunks, obj_chunk_pass_b);
+    for (const ObjChunk& c : chunks)
+        if (c.anomaly) return false;
+    attrib->vertices.reserve((size_t)nv * 3), attrib->texcoords.reserve((size_t)nvt * 2), attrib->normals.reserve((size_t)nvn * 3);
+    for (const ObjChunk& c : chunks)
+    {
+        attrib->vertices.insert(attrib->vertices.end(), c.v.begin(), c.v.end());
+        attrib->normals.insert(attrib->normals.end(), c.vn.begin(), c.vn.end());
+        attrib->texcoords.insert(attrib->texcoords.end(), c.vt.begin(), c.vt.end());
+        auto append = [&](uint32_t f0, uint32_t f1) {  // faces [f0, f1) of the chunk to the current shape, with the current material
+            if (f1 <= f0) return;
+            const uint32_t t0 = c.tri_start[f0], t1 = c.tri_start[f1];
+            cur.mesh.indices.insert(cur.mesh.indices.end(), c.tris.begin() + 3 * (size_t)t0, c.tris.begin() + 3 * (size_t)t1);
+            cur.mesh.material_ids.insert(cur.mesh.material_ids.end(), (size_t)(t1 - t0), cur_material);
+        };
+        uint32_t pos = 0;
+        for (const ObjChunk::Event& e : c.events)
+        {
+            append(pos, e.face_pos);
+            pos = e.face_pos;
+            handle_rare(e.k0, e.eol);
+        }
+        append(pos, (uint32_t)c.faces.size());
+    }
+    return true;
+}
+
 bool LoadObj(attrib_t* attrib, std::vector<shape_t>* shapes, std::vector<material_t>* materials, std::string* warn,
              std::string* err, const char* filename, const char* mtl_basedir)
 {
@@ -220,6 +402,51 @@ bool LoadObj(attrib_t* attrib, std::vector<shape_t>* shapes, std::vector<materia
         if (!cur.mesh.indices.empty()) shapes->push_back(cur);
         cur = shape_t();
     };
+    // the rare records: o / g / usemtl / mtllib (s, l, p and unknown records are ignored); tokens as strings
+    auto handle_rare = [&](const char* k0, const char* eol) {
+        const std::string line(k0, eol);
+        auto              t = split_ws(line);
+        const std::string& k = t[0];
+        if (k == "o" || k == "g")
+        {
+            flush();
+            cur.name = join_from(t, 1);
+        }
+        else if (k == "usemtl")
+        {
+            auto it      = material_by_name.find(join_from(t, 1));
+            cur_material = it == material_by_name.end() ? -1 : it->second;
+        }
+        else if (k == "mtllib")
+        {
+            for (size_t i = 1; i < t.size(); ++i)
+                if (!load_mtl(basedir + t[i], materials, &material_by_name) && warn)
+                    *warn += "Material file [ " + t[i] + " ] not found in a path : " + basedir + "\n";
+        }
+    };
+    {
+        int threads = g_obj_threads;
+        if (threads <= 0)
+        {
+            const unsigned hw = std::thread::hardware_concurrency();
+            threads           = text.size() < ((size_t)1 << 20) ? 1 : (int)(hw == 0 ? 1 : (hw > 8 ? 8 : hw));
+        }
+        if (threads > 1)
+        {
+            const std::string warn_before = warn ? *warn : std::string();
+            if (load_obj_parallel(text, threads, attrib, cur, cur_material, handle_rare))
+            {
+                flush();
+                return true;
+            }
+            // an anomaly somewhere: from the start, one line after the other, so that it is reported as it always was
+            attrib->vertices.clear(), attrib->normals.clear(), attrib->texcoords.clear();
+            shapes->clear(), materials->clear(), material_by_name.clear();
+            if (warn) *warn = warn_before;
+            cur          = shape_t();
+            cur_material = -1;
+        }
+    }
     std::vector<index_t> face;
     const char*          p   = text.data();
     const char* const    end = p + text.size();
@@ -296,29 +523,7 @@ bool LoadObj(attrib_t* attrib, std::vector<shape_t>* shapes, std::vector<materia
             }
         }
         else
-        {
-            // the rare records, as before: tokens as strings
-            const std::string line(k0, eol);
-            auto              t = split_ws(line);
-            const std::string& k = t[0];
-            if (k == "o" || k == "g")
-            {
-                flush();
-                cur.name = join_from(t, 1);
-            }
-            else if (k == "usemtl")
-            {
-                auto it      = material_by_name.find(join_from(t, 1));
-                cur_material = it == material_by_name.end() ? -1 : it->second;
-            }
-            else if (k == "mtllib")
-            {
-                for (size_t i = 1; i < t.size(); ++i)
-                    if (!load_mtl(basedir + t[i], materials, &material_by_name) && warn)
-                        *warn += "Material file [ " + t[i] + " ] not found in a path : " + basedir + "\n";
-            }
-            // s, l, p and unknown records are ignored
-        }
+            handle_rare(k0, eol);
     }
     flush();
     return true;
@@ -454,6 +659,8 @@ int cap_obj_load(const char* obj_path, const char* mtl_dir, CapGeometry** out)
 }
 
 void cap_geometry_free(CapGeometry* g) { delete g; }
+
+void cap_obj_set_threads(int threads) { tinyobj::g_obj_threads = threads < 0 ? 0 : threads; }
 
 int cap_geometry_view(const CapGeometry* g, CapGeometryView* out)
 {

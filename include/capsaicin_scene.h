@@ -23,6 +23,9 @@ typedef struct CapGeometry CapGeometry;
  * error, and leaves every mesh untextured.  Parse errors return CAP_ERR_IO (the reference throws). */
 int  cap_obj_load(const char* obj_path, const char* mtl_dir, CapGeometry** out_geometry);
 void cap_geometry_free(CapGeometry* g);
+/* Threads cap_obj_load parses the hot records of a large file on (process-wide; 0 = default: one per hardware thread, at most 8, for
+ * files above 1 MB; 1 = the sequential parser only).  The result does not depend on it: tests/test_obj_loader.py. */
+void cap_obj_set_threads(int threads);
 
 typedef struct CapGeometryView
 {

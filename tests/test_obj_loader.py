@@ -180,3 +180,46 @@ def test_number_parsing_is_strtod(native_lib, tmp_path):
     (tmp_path / "c.obj").write_text("v abc 2\n")
     with pytest.raises(capi.CapError, match="expected 3 coordinates"):
         capi.Geometry(str(tmp_path / "c.obj"))
+
+
+def test_threaded_parse_is_the_sequential_parse(native_lib, tmp_path):
+    """cap_obj_load parses the hot records of a file above 1 MB on several threads (obj_loader.cpp load_obj_parallel) and falls back to
+    the sequential parser on any anomaly: for a valid file the same bytes as with one thread (and the generator's own arrays), for a
+    file with a late error the sequential parser's message with its line number, whatever the thread count."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_sponza_class as gen
+    gen.write(str(tmp_path), 0.35, 64)
+    path = os.path.join(str(tmp_path), "sponza_class.obj")
+    assert os.path.getsize(path) > (1 << 20)  # above the threshold: the threaded path is what threads = 0 takes
+    lib = capi.lib()
+    try:
+        got = {}
+        for threads in (1, 0, 2, 3, 7):
+            lib.cap_obj_set_threads(threads)
+            got[threads] = capi.Geometry(path)
+        pos, nrm, uv, idx, meshes, _ = gen.arrays(0.35, 64)
+        for threads, g in got.items():
+            assert np.array_equal(g.positions.view(np.uint32), pos.reshape(-1).view(np.uint32)), threads
+            assert np.array_equal(g.normals.view(np.uint32), nrm.reshape(-1).view(np.uint32)), threads
+            assert np.array_equal(g.texcoords.view(np.uint32), uv.reshape(-1).view(np.uint32)), threads
+            assert np.array_equal(g.indices, idx) and np.array_equal(g.meshes, meshes), threads
+            assert g.texture_names == got[1].texture_names and g.warning == got[1].warning, threads
+        # a face that refers to a vertex the file only defines LATER (valid for no thread count), and a malformed number, both far into the file
+        text = open(path).read()
+        lines = text.split("\n")
+        first_f = next(i for i, l in enumerate(lines) if l.startswith("f "))
+        bad_index = lines[:first_f] + ["f 1 2 99999999"] + lines[first_f:]
+        late = len(lines) * 3 // 4
+        bad_number = lines[:late] + ["v 1.0 abc 2.0"] + lines[late:]
+        for name, ls in (("bad_index.obj", bad_index), ("bad_number.obj", bad_number)):
+            (tmp_path / name).write_text("\n".join(ls))
+            msgs = []
+            for threads in (1, 0, 5):
+                lib.cap_obj_set_threads(threads)
+                with pytest.raises(capi.CapError) as e:
+                    capi.Geometry(str(tmp_path / name))
+                msgs.append(str(e.value))
+            assert msgs[0] == msgs[1] == msgs[2] and name in msgs[0] and ":" in msgs[0], msgs
+    finally:
+        lib.cap_obj_set_threads(0)
