@@ -656,8 +656,17 @@ def ingest_variant(dev, stream):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def progress(what):
+    """A line on stderr per phase: where a run is, should it ever stop (stdout carries the one JSON line only)."""
+    print("[bench %7.1f s] %s" % (time.perf_counter() - T_START, what), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
 def guarded(fn, *a):
     """An extra line must never cost the contract line."""
+    progress(getattr(fn, "__name__", "extra"))
     try:
         return fn(*a)
     except SystemExit:
@@ -933,28 +942,10 @@ def main():
                              "whole_step_queue_stream_gbs": all_bytes / (sp.ms_total * 1e-3) / 1e9,
                              "stage_ms": stage_ms(sp)})
 
+        progress("contract steps timed")
         extras = world == 1 and contract and not args.no_extras
         s_h = stream.cuda_stream
-        # the literal "Lambert+GGX" of BASELINE configs[1] (EXT model: no reference counterpart)
-        ext = guarded(ext_variant, device_index, s_h, args.steps, spp) if (world == 1 and not sponza and not args.no_extras) else None
-        tree = guarded(tree_variant, device_index, s_h) if (extras and not args.no_tree_variant) else None
-        big = guarded(big_variant, device_index, s_h) if (extras and not args.no_tree_variant) else None
-        c3 = guarded(config3_variant, device_index, s_h) if extras else None
-        c5 = guarded(config5_share, device_index, s_h) if extras else None
-        # the compute side of the scaling curve on this one device: extra key, N = 1 only
-        shard_costs = None
-        if extras and not args.no_tree_variant:
-            shard_costs = guarded(lambda: {"what": "ms per step of shard 0 of N on ONE MI355X (no exchange): the compute side of the 1 -> N curve",
-                                           "cornell_64spp": shard_cost(lambda: make_cornell(device_index, s_h), SPP, DEPTH),
-                                           "sponza_class_32spp": shard_cost(lambda: make_hall(device_index, s_h)[0], TREE_SPP, DEPTH, reps=2),
-                                           # BASELINE configs[3] at its own sample count: a rank's 128 frame slots are ONE batch of four times
-                                           # the 32-spp line's launches, so the traversal launches' drain (their longest rays, ~60 us whatever
-                                           # the launch holds) weighs a quarter as much
-                                           "sponza_class_128spp": shard_cost(lambda: make_hall(device_index, s_h)[0], TREE_FULL_SPP, DEPTH, reps=2)})
-        post_chain = guarded(post_chain_variant, device_index, s_h) if extras else None
-        realtime = guarded(realtime_frame_variant, device_index, s_h) if extras else None
-        ingest = guarded(ingest_variant, device_index, s_h) if extras else None
-
+        out = None
         if rank == 0:
             # sanity of the product of the timed region: finite image, every pixel accumulated spp frames
             img = (r.comm_readback() if exchange.startswith("cap_comm") else image.cpu().numpy()).reshape(HEIGHT, WIDTH, 4)
@@ -971,15 +962,73 @@ def main():
                               "parallelism": "tiles%d" % world, "exchange": exchange, "wide_tree_sha1_per_rank": wide_sha_per_rank},
                    # BASELINE configs[1] reads "Lambert+GGX": that literal configuration is the EXT model's line below (ext_variant);
                    # `value` is the reference's own shading model on the same scene, camera, resolution, spp and depth
-                   "value_literal_config": ext.get("value") if isinstance(ext, dict) else None,
+                   "value_literal_config": None,
                    # the north star's roofline target is about traversal-bound frames: big_variant's closest-hit kernel (16.8 M triangles)
-                   "north_star_traversal_bound": big.get("north_star") if isinstance(big, dict) else None,
+                   "north_star_traversal_bound": None,
                    "exchange": exchange, "stage_ms_per_rank": stage_ms_per_rank,
-                   "roofline": roofline, "ext_variant": ext, "tree_variant": tree, "big_variant": big, "config3_variant": c3,
-                   "config5_share": c5, "shard_cost": shard_costs, "post_chain": post_chain,
-                   "realtime_frame": realtime, "ingest": ingest}
-            out["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()  # rank 0, N = 1 only
-            print(json.dumps(out), flush=True)
+                   "roofline": roofline, "ext_variant": None, "tree_variant": None, "big_variant": None, "config3_variant": None,
+                   "config5_share": None, "shard_cost": None, "post_chain": None, "realtime_frame": None, "ingest": None, "cpu_baseline": None}
+            if not (args.no_cpu_baseline or world > 1):  # rank 0, N = 1 only; before the extra lines, so that the line below is complete without them
+                progress("cpu_baseline")
+                out["cpu_baseline"] = cpu_baseline()
+
+        # The extra lines (N = 1): each fills its key as it finishes.  A watchdog prints the line as far as it has got and ends the
+        # process should one of them not return (a GPU call that never completes cannot be interrupted from Python): the contract
+        # line, its roofline and the CPU baseline are never lost to an extra.
+        import threading
+        lock, finished = threading.Lock(), threading.Event()
+
+        def put(key, val):
+            with lock:
+                if out is not None:
+                    out[key] = val
+                    if key == "ext_variant" and isinstance(val, dict):
+                        out["value_literal_config"] = val.get("value")
+                    if key == "big_variant" and isinstance(val, dict):
+                        out["north_star_traversal_bound"] = val.get("north_star")
+
+        def watchdog(limit_s):
+            if finished.wait(limit_s):
+                return
+            with lock:
+                for k in ("ext_variant", "tree_variant", "big_variant", "config3_variant", "config5_share", "shard_cost", "post_chain", "realtime_frame", "ingest"):
+                    if out[k] is None:
+                        out[k] = {"error": "watchdog: the extra lines did not finish within %d s; this one had not returned" % limit_s}
+                        break
+                progress("watchdog: printing the line without the unfinished extras")
+                print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        if rank == 0 and world == 1:
+            threading.Thread(target=watchdog, args=(int(os.environ.get("CAP_BENCH_EXTRAS_LIMIT_S", "420")),), daemon=True).start()
+        # the literal "Lambert+GGX" of BASELINE configs[1] (EXT model: no reference counterpart)
+        if world == 1 and not sponza and not args.no_extras:
+            put("ext_variant", guarded(ext_variant, device_index, s_h, args.steps, spp))
+        if extras and not args.no_tree_variant:
+            put("tree_variant", guarded(tree_variant, device_index, s_h))
+            put("big_variant", guarded(big_variant, device_index, s_h))
+        if extras:
+            put("config3_variant", guarded(config3_variant, device_index, s_h))
+            put("config5_share", guarded(config5_share, device_index, s_h))
+        # the compute side of the scaling curve on this one device: extra key, N = 1 only
+        if extras and not args.no_tree_variant:
+            progress("shard_cost")
+            put("shard_cost", guarded(lambda: {"what": "ms per step of shard 0 of N on ONE MI355X (no exchange): the compute side of the 1 -> N curve",
+                                               "cornell_64spp": shard_cost(lambda: make_cornell(device_index, s_h), SPP, DEPTH),
+                                               "sponza_class_32spp": shard_cost(lambda: make_hall(device_index, s_h)[0], TREE_SPP, DEPTH, reps=2),
+                                               # BASELINE configs[3] at its own sample count: a rank's 128 frame slots are ONE batch of four times
+                                               # the 32-spp line's launches, so the traversal launches' drain (their longest rays, ~60 us whatever
+                                               # the launch holds) weighs a quarter as much
+                                               "sponza_class_128spp": shard_cost(lambda: make_hall(device_index, s_h)[0], TREE_FULL_SPP, DEPTH, reps=2)}))
+        if extras:
+            put("post_chain", guarded(post_chain_variant, device_index, s_h))
+            put("realtime_frame", guarded(realtime_frame_variant, device_index, s_h))
+            put("ingest", guarded(ingest_variant, device_index, s_h))
+        finished.set()
+        if rank == 0:
+            with lock:
+                progress("done")
+                print(json.dumps(out), flush=True)
         r.close()
     if world > 1:
         dist.barrier()
