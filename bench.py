@@ -1000,7 +1000,7 @@ def main():
                 os._exit(0)
 
         if rank == 0 and world == 1:
-            threading.Thread(target=watchdog, args=(int(os.environ.get("CAP_BENCH_EXTRAS_LIMIT_S", "420")),), daemon=True).start()
+            threading.Thread(target=watchdog, args=(int(os.environ.get("CAP_BENCH_EXTRAS_LIMIT_S", "180")),), daemon=True).start()
         # the literal "Lambert+GGX" of BASELINE configs[1] (EXT model: no reference counterpart)
         if world == 1 and not sponza and not args.no_extras:
             put("ext_variant", guarded(ext_variant, device_index, s_h, args.steps, spp))
